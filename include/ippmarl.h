@@ -1,0 +1,210 @@
+/*
+ * ippmarl.h -- C-ABI of libippmarl.so: the MI355X (gfx950) implementation of the ipp-marl hot path
+ * (multi-UAV environment step + COMA target/advantage arithmetic).
+ *
+ * The reference (dmar-bonn/ipp-marl) is pure Python and has no FFI; its seam is the Python object
+ * surface (COMAWrapper / Agent / Mapping / ...).  This header is the boundary a maintainer binds with
+ * ctypes; every entry point cites the reference function(s) it replaces, paths
+ * relative to marl_framework/.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; ippm_last_error() gives a thread-local message;
+ *   - the CALLER owns every buffer: plain device pointers (e.g. torch.Tensor.data_ptr()), contiguous,
+ *     dtype/shape as documented; the library allocates only the opaque context (a few KB of tables);
+ *   - every launch takes an explicit hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     nothing synchronises except ippm_sync and ippm_read_counters;
+ *   - no global mutable state: contexts are independent and may be used from different threads;
+ *   - batched over E independent environments ("envs"); N = agents per env; maps are gx rows x gy columns,
+ *     row index = x-cell, contiguous index = y-cell (reference: map[xl:xr, yu:yd], mappings.py:46-49).
+ *
+ * Array layouts (E envs, N agents, A actions, S = cfg.tile_stride)
+ *   episode   int64  [E]          episode number of each env (seeds truth, start states, Philox streams)
+ *   pos       int32  [E,N,3]      UAV position in metres (x,y,z)
+ *   rect      int32  [E,N,4]      clipped footprint [yu,yd,xl,xr], half-open when sliced (cameras.py:62-77)
+ *   truth     uint8  [E,gx,gy]    ground truth in {0,1}
+ *   local     float  [E,N,gx,gy]  per-agent occupancy posterior
+ *   global    float  [E,gx,gy]    fused team posterior
+ *   code      uint8  [E,N,S,S]    last measurement of each agent as 1-byte codes (1 = observed occupied);
+ *                                 cell (x,y) of the footprint lives at [x-xl][y-(yu & ~3)] so that four
+ *                                 grid-aligned cells share one aligned 32-bit word
+ *   flips     uint8  same layout as code; 1 = this cell's observation is flipped (parity mode)
+ *   comm      uint8  [E,N,N]      comm[e,i,j] = 1 iff agent i receives agent j's message (diagonal = 1)
+ *   mask      uint8  [E,N,A]      action mask after boundary + collision masking
+ *   action    int32  [E,N]
+ *   ws        int32  [E,N+1,IPPM_WS_WORDS]  fusion workspace (deferred-clamp state + per-step op plan);
+ *                                 initialised by ippm_reset_episode, otherwise opaque (zero-fill to start)
+ *   sums      double [E,8]        reward accumulators: [0]=S1 [1]=S2 [2]=T (running weighted entropy of the
+ *                                 global map), [3..5] scratch; initialised by ippm_reset_episode
+ */
+#ifndef IPPMARL_H
+#define IPPMARL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IPPM_VERSION 100
+#define IPPM_MAX_AGENTS 16
+#define IPPM_MAX_LATTICE 64 /* lattice points per horizontal axis */
+#define IPPM_MAX_Z 8        /* altitude levels */
+#define IPPM_MAX_ACTIONS 27
+#define IPPM_FEAT 11        /* the reference's networks hard-wire an 11x11 lattice (actor/network.py:19-21) */
+#define IPPM_ACTOR_PLANES 7
+#define IPPM_CRITIC_PLANES 12
+#define IPPM_WS_WORDS 160
+
+/* Derived constants, computed on the host in float64 with the reference's expression order
+ * (ippmarl/derived.py) and handed over as plain integers/floats. */
+typedef struct ippm_config {
+  int32_t n_agents;
+  int32_t grid_x, grid_y;             /* cells: GridMap.x_dim / y_dim (grid_maps.py:17-50) */
+  int32_t space_x, space_y, space_z;  /* lattice dims (state_space.py:16-21) */
+  int32_t spacing, min_altitude;      /* metres */
+  int32_t x_dim_m, y_dim_m;           /* world size in metres */
+  int32_t n_actions;                  /* 4 | 6 | 9 | 27 (action_space.py) */
+  int32_t budget;                     /* episode has budget+1 steps */
+  int32_t env_seed;                   /* params.environment.seed (start states: state_space.py:29) */
+  int32_t tile_stride;                /* S: row stride (and row count) of code/flips tiles, multiple of 4 */
+  int32_t fix_range;                  /* 0: per-episode range from {0,15,25,100} (communication_log.py:22-31) */
+  int32_t reserved0;
+  int32_t centre_x[IPPM_MAX_LATTICE]; /* floor(x_m / res_x) per lattice index (cameras.py:66) */
+  int32_t centre_y[IPPM_MAX_LATTICE]; /* floor(y_m / res_x) -- the reference uses res_x for both axes */
+  int32_t radius_x[IPPM_MAX_Z];       /* floor(0.5*floor(2 z tan(ax/2)/res_x)) per altitude index */
+  int32_t radius_y[IPPM_MAX_Z];
+  float logit_meas[IPPM_MAX_Z][2];    /* ln(y/(1-y)) in float32 for y = f32(round(noise,3)), f32(round(1-noise,3)) */
+  float meas_value[IPPM_MAX_Z][2];    /* the two measurement values themselves (simulations.py:47-51) */
+  uint32_t flip_threshold[IPPM_MAX_Z];/* observation flipped iff philox word < threshold = floor(noise*2^32) */
+  float prior;                        /* must be 0.5 on this path (full-grid prior shift) */
+  float clip_lo, clip_hi;             /* 1e-4, 0.9999 (mappings.py:110-111, state.py:119-120) */
+  double comm_range;                  /* metres, used when fix_range != 0 */
+  double failure_rate;                /* link drop probability (communication_log.py:46-54) */
+  uint64_t philox_seed;               /* key of the counter-based RNG (production randomness) */
+  double gamma, lambda_;              /* TD(lambda) (batch_memory.py:17-21) */
+} ippm_config;
+
+typedef struct ippm_ctx ippm_ctx;
+
+/* Algorithmic work counters accumulated by the kernels (cells, not bytes; see DESIGN.md for bytes/cell). */
+typedef struct ippm_counters {
+  uint64_t sense_cells;        /* K3: footprint cells sensed+updated */
+  uint64_t fuse_local_cells;   /* K4: cells read+written by local fusion (union per map) */
+  uint64_t fuse_local_ops;     /* K4: sum over (cell, op) pairs = the reference's per-neighbour work */
+  uint64_t fuse_global_cells;  /* K5: cells read+written by global fusion */
+  uint64_t fuse_global_ops;
+  uint64_t feature_cells;      /* K6: map cells streamed by the feature builders */
+  uint64_t reserved[2];
+} ippm_counters;
+
+const char* ippm_last_error(void);
+int ippm_version(void);
+
+int ippm_ctx_create(const ippm_config* cfg, ippm_ctx** out);
+int ippm_ctx_destroy(ippm_ctx* ctx);
+int ippm_sync(ippm_ctx* ctx, void* stream);
+int ippm_read_counters(ippm_ctx* ctx, ippm_counters* out, int reset, void* stream); /* synchronises */
+
+/* ---- reset ---------------------------------------------------------------------------------------
+ * ippm_reset_episode replaces Mapping.__init__ -> Simulation.simulate_map -> gaussian_random_field
+ * (mapping/simulations.py:34-40, mapping/ground_truths.py:42-56: half-plane split drawn from the legacy
+ * MT19937 stream np.random.seed(episode)), AgentStateSpace.get_random_agent_state
+ * (agent/state_space.py:28-51: RandomState(seed*episode*agent_id)), Mapping.init_priors
+ * (mappings.py:126-132) and CommunicationLog.__init__'s per-episode range (communication_log.py:22-31).
+ * The MT19937 streams are regenerated on the device, bit-exactly.
+ * truth may be NULL (caller supplies its own terrain; split_pct int32 [E,2] is required otherwise);
+ * local, global, comm_range_out (float [E]) and sums may be NULL. */
+int ippm_reset_episode(ippm_ctx* ctx, const int64_t* episode, int32_t* pos, uint8_t* truth, float* local,
+                       float* global, int32_t* split_pct, float* comm_range_out, int32_t* ws, double* sums,
+                       int32_t n_envs, void* stream);
+
+/* ---- K2: Camera.project_field_of_view (sensors/cameras.py:46-79) ------------------------------------ */
+int ippm_footprint(ippm_ctx* ctx, const int32_t* pos, int32_t* rect, int32_t* rect_unclipped, int32_t n_envs,
+                   void* stream);
+
+/* ---- K3: Mapping.update_grid_map = Simulation.get_measurement + apply_update ---------------------------
+ * (mapping/mappings.py:32-78,109-124; mapping/simulations.py:42-65).  Computes rect from pos, senses the
+ * footprint (flip source: explicit `flips` tiles, or Philox(seed; episode, agent, stage) when NULL),
+ * Bayes-updates local[e,i] in place and stores the measurement codes.  `stage` = 0 for the start-position
+ * sensing, t+1 for step t.  agent_sel >= 0 restricts the call to one agent (drop-in single-agent API). */
+int ippm_sense_update(ippm_ctx* ctx, const int64_t* episode, const int32_t* pos, const uint8_t* truth,
+                      float* local, const uint8_t* flips, uint8_t* code, int32_t* rect, int32_t* ws,
+                      int32_t stage, int32_t agent_sel, int32_t n_envs, void* stream);
+
+/* ---- comm: CommunicationLog.get_messages (agent/communication_log.py:39-58) ---------------------------
+ * draws: float64 [E,N,N] replacing np.random.random_sample() per ordered pair, or NULL -> Philox.
+ * comm_range: float [E] per-env range or NULL -> cfg.comm_range. */
+int ippm_comm_matrix(ippm_ctx* ctx, const int64_t* episode, const int32_t* pos, const float* comm_range,
+                     const double* draws, uint8_t* comm, int32_t t, int32_t n_envs, void* stream);
+
+/* ---- K4: Agent.receive_messages -> Mapping.fuse_map(..., "local") (agent/agent.py:62-71,
+ * mappings.py:82-89).  For each agent i the measurements of the received agents j != i are fused into
+ * local[e,i] in ascending j; every map cell is read and written at most once.  `ws` carries the deferred
+ * full-grid input clip of the reference (DESIGN.md "deferred clamp"). */
+int ippm_fuse_local(ippm_ctx* ctx, float* local, const uint8_t* code, const int32_t* rect, const int32_t* pos,
+                    const uint8_t* comm, int32_t* ws, int32_t n_envs, void* stream);
+
+/* ---- K5: Mapping.fuse_map(..., "global") + get_global_reward (mappings.py:91-102, utils/reward.py:11-82,
+ * utils/state.py:53-121).  Fuses all N measurements into global[e] in place and returns
+ * reward[e] = (22*S1/S2 - 0.5, 10*S1/(gx*gy) - 0.17) and sums[e] = (S1, S2, T, ...) in float64, where T is
+ * the running weighted entropy of the map (initialised by ippm_reset_episode; re-seed it with
+ * ippm_weighted_entropy if the map is replaced from outside). */
+int ippm_fuse_global_reward(ippm_ctx* ctx, float* global, const uint8_t* code, const int32_t* rect,
+                            const int32_t* pos, int32_t* ws, double* sums, float* reward, int32_t n_envs,
+                            void* stream);
+
+/* Full-grid weighted entropy sum(w(p) H(p)) per map (utils/state.py:53-121, "reward" mode); n_maps maps of
+ * gx*gy floats; out float64 [n_maps].  truth != NULL: weights from ground truth ("eval" mode), map m uses
+ * truth[m / maps_per_truth]. */
+int ippm_weighted_entropy(ippm_ctx* ctx, const float* maps, const uint8_t* truth, int32_t maps_per_truth,
+                          double* out, int32_t n_maps, void* stream);
+
+/* get_global_reward on two explicit maps (utils/reward.py:11-82): sums float64 [n_maps,2] = (S1,S2);
+ * reward float [n_maps,2] = (relative, absolute) or NULL. */
+int ippm_reward_from_maps(ippm_ctx* ctx, const float* before, const float* after, double* sums, float* reward,
+                          int32_t n_maps, void* stream);
+
+/* ---- K1: AgentActionSpace.get_action_mask + apply_collision_mask + ActorNetwork.do_eps_exploration +
+ * action_to_position (agent/action_space.py:25-589, actor/network.py:90-96, coma_wrapper.py:97-104).
+ * Sequential over the agents of an env (agent i is masked against the already-moved j < i).
+ * policy: 0 = explicit `action_in`; 1 = uniform over the valid mask (Philox); 2 = sample from
+ * probs*mask (Philox, "train"); 3 = argmax of probs*mask ("eval").  probs float [E,N,A] (policy 2/3).
+ * fault[e] != 0 when an agent's mask became empty (the reference's torch.multinomial raises there). */
+int ippm_mask_act_move(ippm_ctx* ctx, const int64_t* episode, int32_t* pos, const float* probs,
+                       const int32_t* action_in, int32_t policy, int32_t t, uint8_t* mask, int32_t* action,
+                       int32_t* fault, int32_t n_envs, void* stream);
+
+/* ---- K6: network inputs (actor/transformations.py:14-176, critic/transformations.py:17-132,
+ * utils/state.py:22-41).  obs float [E,N,11,11,7]; state float [E,N,11,11,12].
+ * ippm_actor_features must run after ippm_fuse_local of step t (uses the fused local maps, the published
+ * measurements/rects/positions and comm); ippm_critic_features after ippm_fuse_global_reward and
+ * ippm_mask_act_move of step t with pos_pre = the pre-move positions. */
+int ippm_actor_features(ippm_ctx* ctx, const float* local, const uint8_t* code, const int32_t* rect,
+                        const int32_t* pos, const uint8_t* comm, int32_t t, float* obs, int32_t n_envs,
+                        void* stream);
+int ippm_critic_features(ippm_ctx* ctx, const float* global, const int32_t* rect, const int32_t* pos_pre,
+                         const int32_t* action, const float* obs, float* state, int32_t n_envs, void* stream);
+
+/* ---- K7: COMA counterfactual advantage (actor/learner.py:55-95).  probs/q float [B,A], mask uint8 [B,A],
+ * action int32 [B] -> advantage float [B], pi_tilde float [B,A] (may be NULL). */
+int ippm_coma_advantage(ippm_ctx* ctx, const float* probs, const float* q, const uint8_t* mask,
+                        const int32_t* action, float* advantage, float* pi_tilde, int32_t batch, void* stream);
+
+/* ---- K8: BatchMemory.build_td_targets (batch_memory.py:120-162) over `chains` independent transition
+ * lists of length `len` (row-major [chains,len]): reward float, done uint8, q_sel float = target critic
+ * Q(s_t)[a_t] -> td_target, discounted_return float. */
+int ippm_td_lambda(ippm_ctx* ctx, const float* reward, const uint8_t* done, const float* q_sel, float* td_target,
+                   float* disc_return, int32_t chains, int32_t len, void* stream);
+
+/* Host helpers (no GPU needed): exported so that CPU-only tests can pin the device's integer streams and
+ * resize weights to NumPy / the oracle. */
+int ippm_area_weights(int32_t n_src, int32_t n_dst, int32_t* bin0, float* w0, float* w1);
+int ippm_host_philox(const uint32_t* ctr_key6, uint32_t* out4);           /* Philox4x32-10(c0..c3,k0,k1) */
+int ippm_host_start_state(int32_t env_seed, int64_t episode, int32_t agent, int32_t spacing, int32_t space_x,
+                          int32_t space_y, int32_t* out3);                /* state_space.py:28-51 */
+int ippm_host_truth_params(int64_t episode, int32_t* out2);               /* ground_truths.py:43-48 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IPPMARL_H */

@@ -1,0 +1,172 @@
+// Context management, error reporting and host-side helpers of libippmarl.so.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "ippm_internal.h"
+
+static thread_local std::string g_last_error;
+void ippm_set_error(const std::string& msg) { g_last_error = msg; }
+int ippm_check_hip(hipError_t err, const char* what) {
+  if (err == hipSuccess) return 0;
+  g_last_error = std::string(what) + ": " + hipGetErrorString(err);
+  return -100 - (int)err;
+}
+
+extern "C" const char* ippm_last_error(void) { return g_last_error.c_str(); }
+extern "C" int ippm_version(void) { return IPPM_VERSION; }
+
+// Exact area-average weights, the definition used for cv2.resize(INTER_AREA) (utils/state.py:22-41):
+// output bin o covers source interval [o*s, (o+1)*s), s = n_src/n_dst; weight = overlap / s.
+// Same float64 expressions as oracle/ipp_oracle.py::area_weights.  Per source index: first bin, weight
+// into it and into the next bin (n_src >= n_dst => at most two bins).
+extern "C" int ippm_area_weights(int32_t n_src, int32_t n_dst, int32_t* bin0, float* w0, float* w1) {
+  if (n_src < n_dst || n_dst <= 0) { ippm_set_error("ippm_area_weights: needs n_src >= n_dst > 0"); return -1; }
+  const double s = (double)n_src / (double)n_dst;
+  std::vector<double> W((size_t)n_dst * n_src, 0.0);
+  for (int o = 0; o < n_dst; ++o) {
+    const double lo = o * s, hi = (o + 1) * s;
+    const int i1 = std::min(n_src, (int)std::ceil(hi));
+    for (int i = (int)std::floor(lo); i < i1; ++i)
+      W[(size_t)o * n_src + i] = std::max(0.0, std::min(hi, (double)i + 1) - std::max(lo, (double)i)) / s;
+  }
+  for (int i = 0; i < n_src; ++i) {
+    int b = -1;
+    for (int o = 0; o < n_dst; ++o)
+      if (W[(size_t)o * n_src + i] > 1e-12) { b = o; break; }
+    if (b < 0) b = std::min(n_dst - 1, (int)(i / s));
+    bin0[i] = b;
+    w0[i] = (float)W[(size_t)b * n_src + i];
+    w1[i] = b + 1 < n_dst ? (float)W[(size_t)(b + 1) * n_src + i] : 0.f;
+  }
+  return 0;
+}
+
+// host-callable mirrors of device RNG pieces so that CPU-only tests can pin them to NumPy / the oracle
+extern "C" int ippm_host_philox(const uint32_t* ctr_key6, uint32_t* out4) {
+  Philox4 r = ippm_philox(ctr_key6[0], ctr_key6[1], ctr_key6[2], ctr_key6[3], ctr_key6[4], ctr_key6[5]);
+  for (int i = 0; i < 4; ++i) out4[i] = r.v[i];
+  return 0;
+}
+extern "C" int ippm_host_start_state(int32_t env_seed, int64_t episode, int32_t agent, int32_t spacing, int32_t space_x,
+                                     int32_t space_y, int32_t* out3) {
+  ippm_start_state(env_seed, episode, agent, spacing, space_x, space_y, out3);
+  return 0;
+}
+extern "C" int ippm_host_truth_params(int64_t episode, int32_t* out2) {
+  ippm_truth_params(episode, &out2[0], &out2[1]);
+  return 0;
+}
+
+static int build_tables(ippm_ctx* ctx) {
+  const ippm_config& c = ctx->cfg;
+  std::vector<int32_t> ti;
+  std::vector<float> t0, t1;
+  auto add = [&](int n) -> int {
+    const int off = (int)ti.size();
+    std::vector<int32_t> b(n);
+    std::vector<float> a0(n), a1(n);
+    ippm_area_weights(n, IPPM_FEAT, b.data(), a0.data(), a1.data());
+    ti.insert(ti.end(), b.begin(), b.end());
+    for (int o = 0; o <= IPPM_FEAT; ++o) {  // bstart[o] = first source index with bin0 >= o
+      int first = n;
+      for (int i = 0; i < n; ++i)
+        if (b[i] >= o) { first = i; break; }
+      ti.push_back(first);
+    }
+    t0.insert(t0.end(), a0.begin(), a0.end());
+    t1.insert(t1.end(), a1.begin(), a1.end());
+    t0.resize(ti.size(), 0.f);
+    t1.resize(ti.size(), 0.f);
+    return off;
+  };
+  const bool feats = c.grid_x >= IPPM_FEAT && c.grid_y >= IPPM_FEAT;
+  ctx->off_rows = feats ? add(c.grid_x) : 0;
+  ctx->off_cols = feats ? add(c.grid_y) : 0;
+  for (int k = 0; k < IPPM_MAX_Z; ++k) {
+    ctx->n_fp[k] = 0;
+    ctx->off_fp[k] = 0;
+    if (k < c.space_z && feats && 2 * c.radius_y[k] >= IPPM_FEAT) {
+      ctx->n_fp[k] = 2 * c.radius_y[k];
+      ctx->off_fp[k] = add(ctx->n_fp[k]);
+    }
+  }
+  if (ti.empty()) { ti.push_back(0); t0.push_back(0.f); t1.push_back(0.f); }
+  IPPM_HIP(hipMalloc(&ctx->tab_bin0, ti.size() * sizeof(int32_t)));
+  IPPM_HIP(hipMalloc(&ctx->tab_w0, t0.size() * sizeof(float)));
+  IPPM_HIP(hipMalloc(&ctx->tab_w1, t1.size() * sizeof(float)));
+  IPPM_HIP(hipMemcpy(ctx->tab_bin0, ti.data(), ti.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  IPPM_HIP(hipMemcpy(ctx->tab_w0, t0.data(), t0.size() * sizeof(float), hipMemcpyHostToDevice));
+  IPPM_HIP(hipMemcpy(ctx->tab_w1, t1.data(), t1.size() * sizeof(float), hipMemcpyHostToDevice));
+  IPPM_HIP(hipMalloc(&ctx->d_fp_off, IPPM_MAX_Z * sizeof(int32_t)));
+  IPPM_HIP(hipMalloc(&ctx->d_fp_n, IPPM_MAX_Z * sizeof(int32_t)));
+  IPPM_HIP(hipMemcpy(ctx->d_fp_off, ctx->off_fp, IPPM_MAX_Z * sizeof(int32_t), hipMemcpyHostToDevice));
+  IPPM_HIP(hipMemcpy(ctx->d_fp_n, ctx->n_fp, IPPM_MAX_Z * sizeof(int32_t), hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int ippm_ctx_create(const ippm_config* cfg, ippm_ctx** out) {
+  if (!cfg || !out) { ippm_set_error("ippm_ctx_create: null argument"); return -1; }
+  const ippm_config& c = *cfg;
+  auto bad = [](const char* m) { ippm_set_error(std::string("ippm_ctx_create: ") + m); return -2; };
+  if (c.n_agents < 1 || c.n_agents > IPPM_MAX_AGENTS) return bad("n_agents out of range");
+  if (c.grid_x < 1 || c.grid_y < 1) return bad("empty grid");
+  if (c.space_x < 1 || c.space_x > IPPM_MAX_LATTICE || c.space_y < 1 || c.space_y > IPPM_MAX_LATTICE) return bad("lattice too large");
+  if (c.space_z < 1 || c.space_z > IPPM_MAX_Z) return bad("too many altitude levels");
+  if (!(c.n_actions == 4 || c.n_actions == 6 || c.n_actions == 9 || c.n_actions == 27)) return bad("num_actions must be 4, 6, 9 or 27");
+  if (c.prior != 0.5f) return bad("mapping.prior != 0.5 is not supported on the HIP path (the reference shifts every cell of a map by "
+                                  "-logit(prior) per fused message; see DESIGN.md)");
+  if (c.tile_stride % 4 != 0) return bad("tile_stride must be a multiple of 4");
+  for (int k = 0; k < c.space_z; ++k)
+    if (2 * c.radius_x[k] > c.tile_stride || 2 * c.radius_y[k] + 3 > c.tile_stride) return bad("tile_stride too small for the footprint");
+  if (c.spacing <= 0 || c.budget <= 0) return bad("spacing and budget must be positive");
+  ippm_ctx* ctx = new ippm_ctx();
+  std::memset(ctx, 0, sizeof(*ctx));
+  ctx->cfg = c;
+  ctx->vec = (c.grid_y % 4 == 0) ? 4 : 1;
+  int rc = ippm_check_hip(hipMalloc(&ctx->dcfg, sizeof(ippm_config)), "hipMalloc(cfg)");
+  if (!rc) rc = ippm_check_hip(hipMemcpy(ctx->dcfg, cfg, sizeof(ippm_config), hipMemcpyHostToDevice), "hipMemcpy(cfg)");
+  if (!rc) rc = ippm_check_hip(hipMalloc(&ctx->dcounters, 8 * sizeof(unsigned long long)), "hipMalloc(counters)");
+  if (!rc) rc = ippm_check_hip(hipMemset(ctx->dcounters, 0, 8 * sizeof(unsigned long long)), "hipMemset(counters)");
+  if (!rc) rc = build_tables(ctx);
+  if (rc) { ippm_ctx_destroy(ctx); return rc; }
+  *out = ctx;
+  return 0;
+}
+
+extern "C" int ippm_ctx_destroy(ippm_ctx* ctx) {
+  if (!ctx) return 0;
+  if (ctx->dcfg) (void)hipFree(ctx->dcfg);
+  if (ctx->dcounters) (void)hipFree(ctx->dcounters);
+  if (ctx->tab_bin0) (void)hipFree(ctx->tab_bin0);
+  if (ctx->tab_w0) (void)hipFree(ctx->tab_w0);
+  if (ctx->tab_w1) (void)hipFree(ctx->tab_w1);
+  if (ctx->d_fp_off) (void)hipFree(ctx->d_fp_off);
+  if (ctx->d_fp_n) (void)hipFree(ctx->d_fp_n);
+  delete ctx;
+  return 0;
+}
+
+extern "C" int ippm_sync(ippm_ctx* ctx, void* stream) {
+  (void)ctx;
+  IPPM_HIP(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+  return 0;
+}
+
+extern "C" int ippm_read_counters(ippm_ctx* ctx, ippm_counters* out, int reset, void* stream) {
+  if (!ctx || !out) { ippm_set_error("ippm_read_counters: null argument"); return -1; }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  IPPM_HIP(hipStreamSynchronize(s));
+  unsigned long long host[8];
+  IPPM_HIP(hipMemcpy(host, ctx->dcounters, sizeof(host), hipMemcpyDeviceToHost));
+  out->sense_cells = host[0];
+  out->fuse_local_cells = host[1];
+  out->fuse_local_ops = host[2];
+  out->fuse_global_cells = host[3];
+  out->fuse_global_ops = host[4];
+  out->feature_cells = host[5];
+  out->reserved[0] = host[6];
+  out->reserved[1] = host[7];
+  if (reset) IPPM_HIP(hipMemset(ctx->dcounters, 0, sizeof(host)));
+  return 0;
+}

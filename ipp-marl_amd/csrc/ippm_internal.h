@@ -1,0 +1,220 @@
+// Internal declarations shared by the HIP translation units of libippmarl.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "ippmarl.h"
+
+// ---- workspace layout: int32 [E, N+1, IPPM_WS_WORDS]; slot N of an env is its global map ------------
+// words 0..7  : persistent deferred-clamp state (DESIGN.md "deferred clamp")
+// words 8..15 : plan header written by the plan kernels
+// words 16..  : op list, 8 words per op
+// IPPM_WS_WORDS (160) comes from ippmarl.h
+#define WS_FLAG_A 0   // region A may hold values outside [clip_lo, clip_hi]
+#define WS_RECT_A 1   // .. 1..4 = [yu,yd,xl,xr]
+#define WS_FLAG_S 5   // the agent's current footprint rect may hold out-of-range values (set by K3)
+#define WS_PLAN 8
+#define PL_NOPS 0
+#define PL_X0 1
+#define PL_X1 2
+#define PL_Y0 3
+#define PL_Y1 4
+#define PL_LAST 5     // index of the last op (its outputs stay unclamped)
+#define WS_OPS 16
+#define OP_WORDS 8
+#define OP_TYPE 0     // 0 = clamp only, 1 = fuse measurement
+#define OP_SRC 1      // source agent j of the measurement
+#define OP_ALT 2      // altitude index of j
+#define OP_YU 3
+#define OP_YD 4
+#define OP_XL 5
+#define OP_XR 6
+#define IPPM_MAX_OPS (IPPM_MAX_AGENTS + 2)
+
+// sums layout: double [E, 8]
+#define SUM_S1 0
+#define SUM_S2 1
+#define SUM_T 2
+#define SUM_ACC1 3
+#define SUM_ACCD 4
+#define SUM_ACCT 5
+
+struct ResizeTab {           // area-average weights of one source length -> 11 bins (each source index
+  const int32_t* bin0;       // overlaps at most two bins when n_src >= 11)
+  const float* w0;
+  const float* w1;
+  int32_t n;
+};
+
+struct ippm_ctx {
+  ippm_config cfg;           // host copy
+  ippm_config* dcfg;         // device copy
+  unsigned long long* dcounters;  // device, 8 words (ippm_counters)
+  // K6 tables (device): rows (gx), cols (gy), and one per altitude level for the 2r x 2r footprint image
+  int32_t* tab_bin0;
+  float* tab_w0;
+  float* tab_w1;
+  int32_t off_rows, off_cols, off_fp[IPPM_MAX_Z];
+  int32_t n_fp[IPPM_MAX_Z];
+  int32_t* d_fp_off;         // device copies of off_fp / n_fp
+  int32_t* d_fp_n;
+  int vec;                   // 4 when grid_y % 4 == 0 (aligned float4 path), else 1
+};
+
+void ippm_set_error(const std::string& msg);
+int ippm_check_hip(hipError_t err, const char* what);
+#define IPPM_HIP(call)                                       \
+  do {                                                       \
+    int _rc = ippm_check_hip((call), #call);                 \
+    if (_rc) return _rc;                                     \
+  } while (0)
+#define IPPM_LAUNCH_CHECK(name) IPPM_HIP(hipGetLastError())
+
+// ---- device helpers ------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+
+__device__ __forceinline__ float ippm_clipf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+// ln(x/(1-x)) for x already clipped to [clip_lo, clip_hi]
+__device__ __forceinline__ float ippm_logit(float x) {
+  return __logf(x * __builtin_amdgcn_rcpf(1.0f - x));
+}
+
+// 1 - 1/(1+e^L) evaluated as 1/(1+e^-L): accurate relative to both p and 1-p in float32
+__device__ __forceinline__ float ippm_sigmoid(float l) {
+  return __builtin_amdgcn_rcpf(1.0f + __expf(-l));
+}
+
+// Shannon entropy in bits of p clipped to [lo,hi] (utils/state.py:118-121)
+__device__ __forceinline__ float ippm_entropy(float p, float lo, float hi) {
+  p = ippm_clipf(p, lo, hi);
+  float q = 1.0f - p;
+  return -p * __log2f(p) - q * __log2f(q);
+}
+
+// class weight (utils/state.py:60-73 with class_weighting [0,1]): thresholds on the unclipped value
+__device__ __forceinline__ float ippm_weight(float p) { return p > 0.501f ? 1.0f : (p < 0.499f ? 0.0f : 0.5f); }
+
+__device__ __forceinline__ float ippm_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Philox4x32-10 (Salmon et al., SC'11); mirrored in oracle/ipp_oracle.py::philox4x32
+struct Philox4 {
+  uint32_t v[4];
+};
+__host__ __device__ __forceinline__ Philox4 ippm_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                                        uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  Philox4 o;
+  o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+  return o;
+}
+#define IPPM_DOMAIN_FLIP 0u
+#define IPPM_DOMAIN_ACTION 1u
+#define IPPM_DOMAIN_COMM 2u
+__host__ __device__ __forceinline__ uint32_t ippm_stream_word(uint32_t agent, uint32_t stage, uint32_t domain) {
+  return (agent & 0xFFu) | ((stage & 0xFFFFu) << 8) | ((domain & 0xFFu) << 24);
+}
+
+// lattice index of a position (agent/state_space.py:53-57)
+__device__ __forceinline__ void ippm_pos_to_index(const ippm_config* c, int px, int py, int pz, int& ix, int& iy,
+                                                  int& iz) {
+  ix = px / c->spacing;
+  iy = py / c->spacing;
+  iz = pz / c->spacing - 1;
+}
+__device__ __forceinline__ int ippm_alt_index(const ippm_config* c, int pz) {
+  int k = (pz - c->min_altitude) / c->spacing;
+  return k < 0 ? 0 : (k >= c->space_z ? c->space_z - 1 : k);
+}
+
+// Camera.project_field_of_view with host-tabulated centre cells / radii (sensors/cameras.py:62-77)
+__device__ __forceinline__ void ippm_footprint_rect(const ippm_config* c, int px, int py, int pz, int* clipped,
+                                                    int* full) {
+  int ix = px / c->spacing, iy = py / c->spacing, k = ippm_alt_index(c, pz);
+  int xl = c->centre_x[ix] - c->radius_x[k], xr = c->centre_x[ix] + c->radius_x[k];
+  int yu = c->centre_y[iy] - c->radius_y[k], yd = c->centre_y[iy] + c->radius_y[k];
+  if (full) { full[0] = yu; full[1] = yd; full[2] = xl; full[3] = xr; }
+  int gx1 = c->grid_x - 1, gy1 = c->grid_y - 1;
+  clipped[0] = min(max(yu, 0), gy1);
+  clipped[1] = min(max(yd, 0), gy1);
+  clipped[2] = min(max(xl, 0), gx1);
+  clipped[3] = min(max(xr, 0), gx1);
+}
+
+
+// ---- legacy NumPy MT19937: first outputs of RandomState(seed) and the masked-rejection bounded draw ----
+#define MT_NOUT 16
+__host__ __device__ inline void ippm_mt19937_first_outputs(uint32_t seed, uint32_t* out) {
+  // init_genrand recurrence; output k of the first twist needs old[k], old[k+1], old[k+397]
+  uint32_t lo[MT_NOUT + 1], hi[MT_NOUT];
+  uint32_t s = seed;
+#pragma unroll
+  for (int pos = 0; pos <= MT_NOUT; ++pos) {
+    lo[pos] = s;
+    s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)pos + 1u;
+  }
+  for (int pos = MT_NOUT + 1; pos < 397; ++pos) s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)pos + 1u;
+#pragma unroll
+  for (int k = 0; k < MT_NOUT; ++k) {
+    hi[k] = s;
+    s = 1812433253u * (s ^ (s >> 30)) + (uint32_t)(397 + k) + 1u;
+  }
+#pragma unroll
+  for (int k = 0; k < MT_NOUT; ++k) {
+    uint32_t y = (lo[k] & 0x80000000u) | (lo[k + 1] & 0x7fffffffu);
+    uint32_t v = hi[k] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    v ^= v >> 11;
+    v ^= (v << 7) & 0x9d2c5680u;
+    v ^= (v << 15) & 0xefc60000u;
+    v ^= v >> 18;
+    out[k] = v;
+  }
+}
+
+// RandomState.randint(low, low+rng+1): masked rejection on 32-bit outputs (numpy legacy bounded integers)
+__host__ __device__ inline uint32_t ippm_mt_bounded(const uint32_t* out, int& cursor, uint32_t rng) {
+  uint32_t mask = rng;
+  mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+  uint32_t v = 0;
+  while (cursor < MT_NOUT) {
+    v = out[cursor++] & mask;
+    if (v <= rng) return v;
+  }
+  return v <= rng ? v : rng;  // unreachable in practice: 16 rejections in a row
+}
+
+// agent/state_space.py:29-32
+__host__ __device__ inline void ippm_start_state(int env_seed, int64_t episode, int agent, int spacing, int space_x,
+                                                 int space_y, int* out3) {
+  uint32_t out[MT_NOUT];
+  ippm_mt19937_first_outputs((uint32_t)((int64_t)env_seed * episode * (int64_t)agent), out);
+  int cur = 0;
+  out3[0] = spacing * (int)ippm_mt_bounded(out, cur, (uint32_t)(space_x - 1));
+  out3[1] = spacing * (int)ippm_mt_bounded(out, cur, (uint32_t)(space_y - 1));
+  out3[2] = 15;
+}
+
+// mapping/ground_truths.py:43-48: np.random.seed(episode); randint(4); randint(30, 61)
+__host__ __device__ inline void ippm_truth_params(int64_t episode, int* split, int* pct) {
+  uint32_t out[MT_NOUT];
+  ippm_mt19937_first_outputs((uint32_t)episode, out);
+  int cur = 0;
+  *split = (int)ippm_mt_bounded(out, cur, 3u);
+  *pct = 30 + (int)ippm_mt_bounded(out, cur, 30u);
+}
+
+#endif  // __HIPCC__

@@ -1,0 +1,167 @@
+"""Batched, device-resident multi-UAV environment: E independent episodes stepped by HIP kernels.
+
+Struct-of-arrays state lives in torch tensors on one GPU (torch is only the allocator/stream provider);
+every arithmetic step is a kernel of libippmarl.so.  One ``build_observations`` + ``steps`` pair is what
+the reference's COMAWrapper.build_observations / COMAWrapper.steps (coma_wrapper.py:37-183) do for ONE
+environment, here for all E at once:
+
+    reset(episodes)                       Mapping/Agent construction + t=0 start sensing  (episode_generator.py:39-47,
+                                          agent.py:43-49)
+    build_observations(t)                 publish -> comm-range receive/fuse (K4) -> actor features (K6)
+    steps(t, ...)                         global fuse + reward (K5), sequential mask/act/move (K1),
+                                          critic features (K6), sense + update at the new positions (K3)
+
+Randomness: explicit inputs (flip tiles, actions, comm draws) in parity mode, otherwise the counter-based
+Philox4x32-10 keyed by (philox_seed; episode, agent, step) -- independent of how envs are sharded over GPUs.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _ffi
+from .derived import DerivedConstants
+
+POLICY_EXPLICIT, POLICY_UNIFORM, POLICY_SAMPLE, POLICY_ARGMAX = 0, 1, 2, 3
+
+
+class VecEnv:
+    def __init__(self, params: Dict, n_envs: int, device: str = "cuda:0", philox_seed: int = 3):
+        if not torch.cuda.is_available():
+            raise _ffi.IppmError("VecEnv needs an AMD GPU (HIP): there is no CPU path for the env step")
+        self.params = params
+        self.d = DerivedConstants(params, philox_seed=philox_seed)
+        self.E = int(n_envs)
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.ctx = _ffi.Context(self.d)
+        d, E, dev = self.d, self.E, self.device
+        N, A, S = d.n_agents, d.n_actions, d.tile_stride
+        z = lambda *shape, dtype: torch.zeros(*shape, dtype=dtype, device=dev)  # noqa: E731
+        self.episode = z(E, dtype=torch.int64)
+        self.pos = z(E, N, 3, dtype=torch.int32)
+        self.pos_pre = z(E, N, 3, dtype=torch.int32)
+        self.rect = z(E, N, 4, dtype=torch.int32)
+        self.truth = z(E, d.grid_x, d.grid_y, dtype=torch.uint8)
+        self.local = z(E, N, d.grid_x, d.grid_y, dtype=torch.float32)
+        self.glob = z(E, d.grid_x, d.grid_y, dtype=torch.float32)
+        self.code = z(E, N, S, S, dtype=torch.uint8)
+        self.comm = z(E, N, N, dtype=torch.uint8)
+        self.comm_range = z(E, dtype=torch.float32)
+        self.mask = z(E, N, A, dtype=torch.uint8)
+        self.action = z(E, N, dtype=torch.int32)
+        self.fault = z(E, dtype=torch.int32)
+        self.ws = z(E, N + 1, _ffi.WS_WORDS, dtype=torch.int32)
+        self.sums = z(E, 8, dtype=torch.float64)
+        self.reward = z(E, 2, dtype=torch.float32)
+        self.split_pct = z(E, 2, dtype=torch.int32)
+        self.obs = None
+        self.state = None
+        self.t = 0
+
+    # ------------------------------------------------------------------------------------------------
+    @property
+    def stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _p(self, t):
+        return _ffi.ptr(t)
+
+    def state_bytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in vars(self).values() if isinstance(t, torch.Tensor))
+
+    def footprints(self, pos: Optional[torch.Tensor] = None):
+        pos = self.pos if pos is None else pos
+        rect = torch.empty(self.E, self.d.n_agents, 4, dtype=torch.int32, device=self.device)
+        full = torch.empty_like(rect)
+        self.ctx.call("ippm_footprint", self._p(pos), self._p(rect), self._p(full), self.E, self.stream)
+        return rect, full
+
+    # ------------------------------------------------------------------------------------------------
+    def reset(self, episodes, truth: Optional[torch.Tensor] = None, start_positions: Optional[torch.Tensor] = None,
+              flips: Optional[torch.Tensor] = None):
+        """Starts episode ``episodes[e]`` in env e (all envs at once) and performs the t=0 start-position sensing."""
+        d = self.d
+        ep = torch.as_tensor(episodes, dtype=torch.int64).reshape(self.E)
+        if int(ep.max()) * d.env_seed * max(d.n_agents - 1, 1) >= 2 ** 32 or int(ep.min()) < 0:
+            raise ValueError("episode * seed * agent_id must stay below 2**32 (NumPy legacy seeding limit)")
+        self.episode.copy_(ep.to(self.device))
+        self.ctx.call("ippm_reset_episode", self._p(self.episode), self._p(self.pos),
+                      None if truth is not None else self._p(self.truth), self._p(self.local), self._p(self.glob),
+                      self._p(self.split_pct), self._p(self.comm_range), self._p(self.ws), self._p(self.sums), self.E,
+                      self.stream)
+        if truth is not None:
+            self.truth.copy_(torch.as_tensor(truth).to(self.device, torch.uint8))
+        if start_positions is not None:
+            self.pos.copy_(torch.as_tensor(start_positions).to(self.device, torch.int32))
+        self.t = 0
+        self.sense(stage=0, flips=flips)
+
+    def sense(self, stage: int, flips: Optional[torch.Tensor] = None, agent: int = -1):
+        """K3 at the current positions (stage 0 = start sensing, t+1 = sensing of step t)."""
+        self.ctx.call("ippm_sense_update", self._p(self.episode), self._p(self.pos), self._p(self.truth), self._p(self.local),
+                      self._p(flips), self._p(self.code), self._p(self.rect), self._p(self.ws), stage, agent, self.E,
+                      self.stream)
+
+    def build_observations(self, t: int, comm_draws: Optional[torch.Tensor] = None, features: bool = True):
+        """comm matrix -> local fusion (K4) -> actor observation [E,N,11,11,7] (K6)."""
+        self.ctx.call("ippm_comm_matrix", self._p(self.episode), self._p(self.pos), self._p(self.comm_range),
+                      self._p(comm_draws), self._p(self.comm), t, self.E, self.stream)
+        self.ctx.call("ippm_fuse_local", self._p(self.local), self._p(self.code), self._p(self.rect), self._p(self.pos),
+                      self._p(self.comm), self._p(self.ws), self.E, self.stream)
+        if not features:
+            return None
+        if self.obs is None:
+            self.obs = torch.empty(self.E, self.d.n_agents, _ffi.FEAT, _ffi.FEAT, _ffi.ACTOR_PLANES, dtype=torch.float32,
+                                   device=self.device)
+        self.ctx.call("ippm_actor_features", self._p(self.local), self._p(self.code), self._p(self.rect), self._p(self.pos),
+                      self._p(self.comm), t, self._p(self.obs), self.E, self.stream)
+        return self.obs
+
+    def steps(self, t: int, policy: int = POLICY_UNIFORM, probs: Optional[torch.Tensor] = None,
+              actions: Optional[torch.Tensor] = None, flips: Optional[torch.Tensor] = None, features: bool = True):
+        """K5 (global fusion + reward of the measurements published this step), K1, critic features, K3.
+
+        Returns (reward [E,2] = (relative, absolute), done: bool, state [E,N,11,11,12] or None)."""
+        d = self.d
+        self.ctx.call("ippm_fuse_global_reward", self._p(self.glob), self._p(self.code), self._p(self.rect), self._p(self.pos),
+                      self._p(self.ws), self._p(self.sums), self._p(self.reward), self.E, self.stream)
+        if features:
+            self.pos_pre.copy_(self.pos)
+        if probs is not None:
+            probs = probs.to(torch.float32).contiguous()
+        if actions is not None:
+            actions = actions.to(self.device, torch.int32).contiguous()
+        self.ctx.call("ippm_mask_act_move", self._p(self.episode), self._p(self.pos), self._p(probs), self._p(actions), policy, t,
+                      self._p(self.mask), self._p(self.action), self._p(self.fault), self.E, self.stream)
+        state = None
+        if features:
+            if self.obs is None:
+                raise _ffi.IppmError("steps(features=True) needs build_observations(features=True) first")
+            if self.state is None:
+                self.state = torch.empty(self.E, d.n_agents, _ffi.FEAT, _ffi.FEAT, _ffi.CRITIC_PLANES, dtype=torch.float32,
+                                         device=self.device)
+            # rect still holds the pre-move (published) footprints: K3 below overwrites it
+            self.ctx.call("ippm_critic_features", self._p(self.glob), self._p(self.rect), self._p(self.pos_pre),
+                          self._p(self.action), self._p(self.obs), self._p(self.state), self.E, self.stream)
+            state = self.state
+        self.sense(stage=t + 1, flips=flips)
+        self.t = t + 1
+        return self.reward, t == d.budget, state
+
+    # ------------------------------------------------------------------------------------------------
+    def counters(self, reset: bool = False) -> dict:
+        return self.ctx.counters(self.stream, reset)
+
+    def pack_flips(self, tiles, rects: np.ndarray) -> torch.Tensor:
+        """tiles[e][i]: uint8 [h,w] (1 = flipped) for clipped rect rects[e,i] = [yu,yd,xl,xr] -> device layout."""
+        S, N = self.d.tile_stride, self.d.n_agents
+        out = np.zeros((self.E, N, S, S), dtype=np.uint8)
+        for e in range(self.E):
+            for i in range(N):
+                yu, yd, xl, xr = (int(v) for v in rects[e, i])
+                off = yu & 3
+                out[e, i, : xr - xl, off: off + yd - yu] = np.asarray(tiles[e][i], dtype=np.uint8).reshape(xr - xl, yd - yu)
+        return torch.from_numpy(out).to(self.device)

@@ -764,19 +764,22 @@ def philox_correctness(seed: int, episode: int, agent: int, s: int, rect, gy: in
     xs = np.arange(xl, xr, dtype=np.int64)[:, None]
     ys = np.arange(yu, yd, dtype=np.int64)[None, :]
     lin = xs * gy + ys
-    r = philox4x32(lin >> 2, episode, philox_stream_word(agent, s, DOMAIN_FLIP), 0, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    r = philox4x32(lin >> 2, episode & 0xFFFFFFFF, philox_stream_word(agent, s, DOMAIN_FLIP), (episode >> 32) & 0xFFFFFFFF,
+                   seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
     lane = lin & 3
     word = np.where(lane == 0, r[0], np.where(lane == 1, r[1], np.where(lane == 2, r[2], r[3])))
     return (word >= np.uint32(philox_flip_threshold(noise))).astype(np.int64)
 
 
 def philox_action_word(seed: int, episode: int, agent: int, t: int) -> int:
-    r = philox4x32(0, episode, philox_stream_word(agent, t, DOMAIN_ACTION), 0, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    r = philox4x32(0, episode & 0xFFFFFFFF, philox_stream_word(agent, t, DOMAIN_ACTION), (episode >> 32) & 0xFFFFFFFF,
+                   seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
     return int(r[0])
 
 
 def philox_comm_draw(seed: int, episode: int, i: int, j: int, t: int) -> float:
-    r = philox4x32(j, episode, philox_stream_word(i, t, DOMAIN_COMM), 0, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    r = philox4x32(j, episode & 0xFFFFFFFF, philox_stream_word(i, t, DOMAIN_COMM), (episode >> 32) & 0xFFFFFFFF,
+                   seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
     return float(int(r[0]) * (1.0 / 4294967296.0))
 
 
