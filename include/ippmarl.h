@@ -22,8 +22,9 @@
  *   pos       int32  [E,N,3]      UAV position in metres (x,y,z)
  *   rect      int32  [E,N,4]      clipped footprint [yu,yd,xl,xr], half-open when sliced (cameras.py:62-77)
  *   truth     uint8  [E,gx,gy]    ground truth in {0,1}
- *   local     float  [E,N,gx,gy]  per-agent occupancy posterior
- *   global    float  [E,gx,gy]    fused team posterior
+ *   local     float  [E,N,gx,gy]  per-agent occupancy belief, stored as LOG-ODDS ln(p/(1-p)) (0 = prior 0.5);
+ *   global    float  [E,gx,gy]    fused team belief, log-odds.  ippm_logodds_to_prob / ippm_prob_to_logodds
+ *                                 convert at the boundary (DESIGN.md "log-odds storage")
  *   code      uint8  [E,N,S,S]    last measurement of each agent as 1-byte codes (1 = observed occupied);
  *                                 cell (x,y) of the footprint lives at [x-xl][y-(yu & ~3)] so that four
  *                                 grid-aligned cells share one aligned 32-bit word
@@ -78,6 +79,9 @@ typedef struct ippm_config {
   uint32_t flip_threshold[IPPM_MAX_Z];/* observation flipped iff philox word < threshold = floor(noise*2^32) */
   float prior;                        /* must be 0.5 on this path (full-grid prior shift) */
   float clip_lo, clip_hi;             /* 1e-4, 0.9999 (mappings.py:110-111, state.py:119-120) */
+  float logit_prior;                  /* ln(prior/(1-prior)) = 0 */
+  float logit_clip;                   /* ln(clip_hi/(1-clip_hi)) = 9.21024...; the clip is symmetric in log-odds */
+  float logit_weight_thr;             /* ln(0.501/0.499): class-weight thresholds of utils/state.py:65-66 */
   double comm_range;                  /* metres, used when fix_range != 0 */
   double failure_rate;                /* link drop probability (communication_log.py:46-54) */
   uint64_t philox_seed;               /* key of the counter-based RNG (production randomness) */
@@ -99,6 +103,7 @@ typedef struct ippm_counters {
 
 const char* ippm_last_error(void);
 int ippm_version(void);
+int ippm_config_size(void); /* sizeof(ippm_config): lets a binding verify its struct mirror */
 
 int ippm_ctx_create(const ippm_config* cfg, ippm_ctx** out);
 int ippm_ctx_destroy(ippm_ctx* ctx);
@@ -117,6 +122,10 @@ int ippm_read_counters(ippm_ctx* ctx, ippm_counters* out, int reset, void* strea
 int ippm_reset_episode(ippm_ctx* ctx, const int64_t* episode, int32_t* pos, uint8_t* truth, float* local,
                        float* global, int32_t* split_pct, float* comm_range_out, int32_t* ws, double* sums,
                        int32_t n_envs, void* stream);
+
+/* Elementwise conversions between the stored log-odds and the reference's probabilities (n floats). */
+int ippm_logodds_to_prob(ippm_ctx* ctx, const float* src, float* dst, int64_t n, void* stream);
+int ippm_prob_to_logodds(ippm_ctx* ctx, const float* src, float* dst, int64_t n, void* stream);
 
 /* ---- K2: Camera.project_field_of_view (sensors/cameras.py:46-79) ------------------------------------ */
 int ippm_footprint(ippm_ctx* ctx, const int32_t* pos, int32_t* rect, int32_t* rect_unclipped, int32_t n_envs,

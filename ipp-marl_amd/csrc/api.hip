@@ -15,6 +15,7 @@ int ippm_check_hip(hipError_t err, const char* what) {
 
 extern "C" const char* ippm_last_error(void) { return g_last_error.c_str(); }
 extern "C" int ippm_version(void) { return IPPM_VERSION; }
+extern "C" int ippm_config_size(void) { return (int)sizeof(ippm_config); }
 
 // Exact area-average weights, the definition used for cv2.resize(INTER_AREA) (utils/state.py:22-41):
 // output bin o covers source interval [o*s, (o+1)*s), s = n_src/n_dst; weight = overlap / s.
@@ -114,6 +115,7 @@ extern "C" int ippm_ctx_create(const ippm_config* cfg, ippm_ctx** out) {
   if (c.space_x < 1 || c.space_x > IPPM_MAX_LATTICE || c.space_y < 1 || c.space_y > IPPM_MAX_LATTICE) return bad("lattice too large");
   if (c.space_z < 1 || c.space_z > IPPM_MAX_Z) return bad("too many altitude levels");
   if (!(c.n_actions == 4 || c.n_actions == 6 || c.n_actions == 9 || c.n_actions == 27)) return bad("num_actions must be 4, 6, 9 or 27");
+  if (!(c.logit_clip > 0.f) || !(c.logit_weight_thr > 0.f)) return bad("logit_clip / logit_weight_thr not set");
   if (c.prior != 0.5f) return bad("mapping.prior != 0.5 is not supported on the HIP path (the reference shifts every cell of a map by "
                                   "-logit(prior) per fused message; see DESIGN.md)");
   if (c.tile_stride % 4 != 0) return bad("tile_stride must be a multiple of 4");
@@ -126,8 +128,8 @@ extern "C" int ippm_ctx_create(const ippm_config* cfg, ippm_ctx** out) {
   ctx->vec = (c.grid_y % 4 == 0) ? 4 : 1;
   int rc = ippm_check_hip(hipMalloc(&ctx->dcfg, sizeof(ippm_config)), "hipMalloc(cfg)");
   if (!rc) rc = ippm_check_hip(hipMemcpy(ctx->dcfg, cfg, sizeof(ippm_config), hipMemcpyHostToDevice), "hipMemcpy(cfg)");
-  if (!rc) rc = ippm_check_hip(hipMalloc(&ctx->dcounters, 8 * sizeof(unsigned long long)), "hipMalloc(counters)");
-  if (!rc) rc = ippm_check_hip(hipMemset(ctx->dcounters, 0, 8 * sizeof(unsigned long long)), "hipMemset(counters)");
+  if (!rc) rc = ippm_check_hip(hipMalloc(&ctx->dcounters, IPPM_COUNTER_SLOTS * 8 * sizeof(unsigned long long)), "hipMalloc(counters)");
+  if (!rc) rc = ippm_check_hip(hipMemset(ctx->dcounters, 0, IPPM_COUNTER_SLOTS * 8 * sizeof(unsigned long long)), "hipMemset(counters)");
   if (!rc) rc = build_tables(ctx);
   if (rc) { ippm_ctx_destroy(ctx); return rc; }
   *out = ctx;
@@ -157,8 +159,10 @@ extern "C" int ippm_read_counters(ippm_ctx* ctx, ippm_counters* out, int reset, 
   if (!ctx || !out) { ippm_set_error("ippm_read_counters: null argument"); return -1; }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   IPPM_HIP(hipStreamSynchronize(s));
-  unsigned long long host[8];
-  IPPM_HIP(hipMemcpy(host, ctx->dcounters, sizeof(host), hipMemcpyDeviceToHost));
+  unsigned long long raw[IPPM_COUNTER_SLOTS * 8], host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  IPPM_HIP(hipMemcpy(raw, ctx->dcounters, sizeof(raw), hipMemcpyDeviceToHost));
+  for (int sl = 0; sl < IPPM_COUNTER_SLOTS; ++sl)
+    for (int k = 0; k < 8; ++k) host[k] += raw[sl * 8 + k];
   out->sense_cells = host[0];
   out->fuse_local_cells = host[1];
   out->fuse_local_ops = host[2];
@@ -167,6 +171,6 @@ extern "C" int ippm_read_counters(ippm_ctx* ctx, ippm_counters* out, int reset, 
   out->feature_cells = host[5];
   out->reserved[0] = host[6];
   out->reserved[1] = host[7];
-  if (reset) IPPM_HIP(hipMemset(ctx->dcounters, 0, sizeof(host)));
+  if (reset) IPPM_HIP(hipMemset(ctx->dcounters, 0, sizeof(raw)));
   return 0;
 }

@@ -73,6 +73,19 @@ __global__ void k_fill_f32(float* __restrict__ p, float v, size_t n) {
   for (; i < n; i += stride) p[i] = v;
 }
 
+// posterior <-> log-odds conversion at the API boundary (drop-in classes exchange probabilities)
+__global__ void k_logodds_to_prob(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = ippm_sigmoid(src[i]);
+}
+__global__ void k_prob_to_logodds(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float p = src[i];
+    dst[i] = __logf(p) - __logf(1.0f - p);  // p in {0,1} gives -inf/+inf: clamped on first use like the reference's clip
+  }
+}
+
 // ======================================================================================================
 // K2: footprint projection
 // ======================================================================================================
@@ -168,7 +181,7 @@ k_sense_update(const ippm_config* __restrict__ c, const int64_t* __restrict__ ep
   const int k = ippm_alt_index(c, p[2]);
   const float lm0 = c->logit_meas[k][0], lm1 = c->logit_meas[k][1];
   const uint32_t thr = c->flip_threshold[k];
-  const float lo = c->clip_lo, hi = c->clip_hi;
+  const float lc = c->logit_clip;
   const RowGeom g = make_geom<VEC>(yu, yd);
   const int tile_y0 = yu & ~3;
   const int rows_per_wg = (h + gridDim.x - 1) / gridDim.x;
@@ -208,10 +221,10 @@ k_sense_update(const ippm_config* __restrict__ c, const int64_t* __restrict__ ep
             flip = p1.v[(cell + q) & 3] < thr ? 1u : 0u;
           }
           const uint32_t obs = ((tw >> (8 * q)) & 1u) ^ flip;
-          const float l = ippm_logit(ippm_clipf(m.v[q], lo, hi)) + (obs ? lm1 : lm0);
-          const float pnew = ippm_sigmoid(l);
-          exceed |= (pnew > hi) | (pnew < lo);
-          m.v[q] = pnew;
+          // mappings.py:109-124 in log-odds: clip the prior belief, add the measurement's log-odds
+          const float l = ippm_clampl(m.v[q], lc) + (obs ? lm1 : lm0);
+          exceed |= fabsf(l) > lc;
+          m.v[q] = l;
           cw |= obs << (8 * q);
         }
       }
@@ -220,7 +233,8 @@ k_sense_update(const ippm_config* __restrict__ c, const int64_t* __restrict__ ep
     }
   }
   if (ws && __any(exceed) && lane == 0) ws[(size_t)(e * (n + 1) + i) * IPPM_WS_WORDS + WS_FLAG_S] = 1;
-  if (counters && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&counters[0], (unsigned long long)h * w);
+  if (counters && blockIdx.x == 0 && threadIdx.x == 0)
+    atomicAdd(&counters[(blockIdx.y & (IPPM_COUNTER_SLOTS - 1)) * 8 + 0], (unsigned long long)h * w);
 }
 
 // ======================================================================================================
@@ -341,13 +355,12 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
   const int nops = hdr[PL_NOPS];
   if (nops == 0) return;
   __shared__ int32_t s_ops[IPPM_MAX_OPS * OP_WORDS];
-  __shared__ float s_red[4][4];
+  __shared__ float s_red[4][6];
   for (int q = threadIdx.x; q < nops * OP_WORDS; q += blockDim.x) s_ops[q] = w[WS_OPS + q];
   __syncthreads();
   const int gx = c->grid_x, gy = c->grid_y, S = c->tile_stride;
   const int X0 = hdr[PL_X0], X1 = hdr[PL_X1], last_op = hdr[PL_LAST];
-  const float lo = c->clip_lo, hi = c->clip_hi;
-  const float llo = ippm_logit(lo), lhi = ippm_logit(hi);
+  const float lc = c->logit_clip, wt = c->logit_weight_thr;
   const RowGeom g = make_geom<VEC>(hdr[PL_Y0], hdr[PL_Y1]);
   const int rows = X1 - X0;
   const int rows_per_wg = (rows + gridDim.x - 1) / gridDim.x;
@@ -393,7 +406,7 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
           const int yy = y + q;
           if (yy >= op[OP_YU] && yy < op[OP_YD]) {
             // every op of the reference clips its input over the whole grid (mappings.py:110-111)
-            L[q] = lastt[q] < 0 ? ippm_logit(ippm_clipf(mv.v[q], lo, hi)) : fminf(fmaxf(L[q], llo), lhi);
+            L[q] = ippm_clampl(lastt[q] < 0 ? mv.v[q] : L[q], lc);
             if (op[OP_TYPE]) { L[q] += ((cw >> (8 * q)) & 1u) ? lm1 : lm0; fused[q] = true; }
             lastt[q] = o;
             ++opcells;
@@ -405,17 +418,13 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
         if (lastt[q] < 0) continue;
         ++cells;
         const float b = mv.v[q];
-        float a;
-        if (!fused[q]) a = ippm_clipf(b, lo, hi);               // clamp-only cells: no logit round trip
-        else {
-          a = ippm_sigmoid(L[q]);
-          if (lastt[q] != last_op) a = ippm_clipf(a, lo, hi);   // a later op clips the whole grid again
-        }
-        exceed |= (a > hi) | (a < lo);
+        float a = L[q];
+        if (lastt[q] != last_op) a = ippm_clampl(a, lc);        // a later op clips the whole grid again
+        exceed |= fabsf(a) > lc;
         mv.v[q] = a;
         if (REWARD && fused[q]) {
-          const float wa = ippm_weight(a), wb = ippm_weight(b);
-          const float hb = ippm_entropy(b, lo, hi), ha = ippm_entropy(a, lo, hi);
+          const float wa = ippm_weight_l(a, wt), wb = ippm_weight_l(b, wt);
+          const float hb = ippm_entropy_l(b, lc), ha = ippm_entropy_l(a, lc);
           a1 += wa * (hb - ha);
           aD += (wa - wb) * hb;
           aT += wa * ha - wb * hb;
@@ -425,21 +434,20 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
     }
   }
   if (__any(exceed) && lane == 0) w[WS_FLAG_A] = 1;
-  // block reduction of the reward terms and work counters
-  if (REWARD) {
-    a1 = ippm_wave_sum(a1); aD = ippm_wave_sum(aD); aT = ippm_wave_sum(aT);
-    if (lane == 0) { s_red[wv][0] = a1; s_red[wv][1] = aD; s_red[wv][2] = aT; }
+  // block reduction of the reward terms and work counters: one atomic per workgroup and quantity
+  {
+    const float fc = ippm_wave_sum((float)cells), fo = ippm_wave_sum((float)opcells);
+    if (REWARD) { a1 = ippm_wave_sum(a1); aD = ippm_wave_sum(aD); aT = ippm_wave_sum(aT); }
+    if (lane == 0) { s_red[wv][0] = a1; s_red[wv][1] = aD; s_red[wv][2] = aT; s_red[wv][3] = fc; s_red[wv][4] = fo; }
     __syncthreads();
-    if (threadIdx.x < 3) {
-      float t = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
-      atomicAdd(&sums[(size_t)e * 8 + SUM_ACC1 + threadIdx.x], (double)t);
-    }
-  }
-  if (counters) {
-    float fc = ippm_wave_sum((float)cells), fo = ippm_wave_sum((float)opcells);
-    if (lane == 0) {
-      atomicAdd(&counters[REWARD ? 3 : 1], (unsigned long long)fc);
-      atomicAdd(&counters[REWARD ? 4 : 2], (unsigned long long)fo);
+    if (threadIdx.x < 5) {
+      const float t = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
+      if (threadIdx.x < 3) {
+        if (REWARD) atomicAdd(&sums[(size_t)e * 8 + SUM_ACC1 + threadIdx.x], (double)t);
+      } else if (counters && t > 0.f) {
+        const int slot = (blockIdx.y * gridDim.x + blockIdx.x) & (IPPM_COUNTER_SLOTS - 1);
+        atomicAdd(&counters[slot * 8 + (REWARD ? 3 : 1) + (threadIdx.x - 3)], (unsigned long long)t);
+      }
     }
   }
 }
@@ -468,12 +476,12 @@ k_weighted_entropy(const ippm_config* __restrict__ c, const float* __restrict__ 
   const size_t total = (size_t)c->grid_x * c->grid_y;
   const float* p = maps + (size_t)m * total;
   const uint8_t* t = truth ? truth + (size_t)(m / maps_per_truth) * total : nullptr;
-  const float lo = c->clip_lo, hi = c->clip_hi;
+  const float lc = c->logit_clip, wt = c->logit_weight_thr;
   float acc = 0.f;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const float v = p[i];
-    const float wgt = t ? (float)t[i] : ippm_weight(v);
-    acc += wgt * ippm_entropy(v, lo, hi);
+    const float wgt = t ? (float)t[i] : ippm_weight_l(v, wt);
+    acc += wgt * ippm_entropy_l(v, lc);
   }
   acc = ippm_wave_sum(acc);
   __shared__ float s[4];
@@ -636,14 +644,28 @@ extern "C" int ippm_reset_episode(ippm_ctx* ctx, const int64_t* episode, int32_t
   }
   if (local) {
     hipLaunchKernelGGL(k_fill_f32, dim3(min(4096, grid1(cells * n_envs * c.n_agents))), dim3(256), 0, S_(stream), local,
-                       c.prior, cells * n_envs * c.n_agents);
+                       c.logit_prior, cells * n_envs * c.n_agents);
     IPPM_LAUNCH_CHECK("fill_local");
   }
   if (global) {
-    hipLaunchKernelGGL(k_fill_f32, dim3(min(4096, grid1(cells * n_envs))), dim3(256), 0, S_(stream), global, c.prior,
+    hipLaunchKernelGGL(k_fill_f32, dim3(min(4096, grid1(cells * n_envs))), dim3(256), 0, S_(stream), global, c.logit_prior,
                        cells * n_envs);
     IPPM_LAUNCH_CHECK("fill_global");
   }
+  return 0;
+}
+
+extern "C" int ippm_logodds_to_prob(ippm_ctx* ctx, const float* src, float* dst, int64_t n, void* stream) {
+  if (!ctx || !src || !dst) { ippm_set_error("ippm_logodds_to_prob: null argument"); return -1; }
+  hipLaunchKernelGGL(k_logodds_to_prob, dim3(min(4096, grid1((size_t)n))), dim3(256), 0, S_(stream), src, dst, (size_t)n);
+  IPPM_LAUNCH_CHECK("logodds_to_prob");
+  return 0;
+}
+
+extern "C" int ippm_prob_to_logodds(ippm_ctx* ctx, const float* src, float* dst, int64_t n, void* stream) {
+  if (!ctx || !src || !dst) { ippm_set_error("ippm_prob_to_logodds: null argument"); return -1; }
+  hipLaunchKernelGGL(k_prob_to_logodds, dim3(min(4096, grid1((size_t)n))), dim3(256), 0, S_(stream), src, dst, (size_t)n);
+  IPPM_LAUNCH_CHECK("prob_to_logodds");
   return 0;
 }
 

@@ -96,7 +96,7 @@ k_actor_features(const ippm_config* __restrict__ c, const float* __restrict__ lo
   const float* map = local + (size_t)(e * n + i) * gx * gy;
   // pass 1: plane q = R(local map), plane F = R(footprint indicator)
   auto src_map = [&](int r, int col, float* v) {
-    v[0] = map[(size_t)r * gy + col];
+    v[0] = ippm_sigmoid(map[(size_t)r * gy + col]);  // maps hold log-odds; the resize averages probabilities
     float f = 0.5f;
     for (int j = 0; j < n; ++j) {
       if (j == i || !s_recv[j]) continue;
@@ -159,7 +159,7 @@ k_actor_features(const ippm_config* __restrict__ c, const float* __restrict__ lo
     dst[5] = ippm_clipf(q, lo, hi);
     dst[6] = f;
   }
-  if (counters && threadIdx.x == 0) atomicAdd(&counters[5], (unsigned long long)gx * gy);
+  if (counters && threadIdx.x == 0) atomicAdd(&counters[(blockIdx.x & (IPPM_COUNTER_SLOTS - 1)) * 8 + 5], (unsigned long long)gx * gy);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -189,7 +189,7 @@ k_critic_features(const ippm_config* __restrict__ c, const float* __restrict__ g
   __syncthreads();
   const float* map = global + (size_t)e * gx * gy;
   auto src_map = [&](int r, int col, float* v) {
-    v[0] = map[(size_t)r * gy + col];
+    v[0] = ippm_sigmoid(map[(size_t)r * gy + col]);
     float f = 0.5f;
     for (int j = 0; j < n; ++j)
       if (r >= s_rect[j][2] && r < s_rect[j][3] && col >= s_rect[j][0] && col < s_rect[j][1]) f = 1.f;
@@ -222,7 +222,7 @@ k_critic_features(const ippm_config* __restrict__ c, const float* __restrict__ g
     dst[10] = f;
     dst[11] = am;
   }
-  if (counters && threadIdx.x == 0) atomicAdd(&counters[5], (unsigned long long)gx * gy);
+  if (counters && threadIdx.x == 0) atomicAdd(&counters[(blockIdx.x & (IPPM_COUNTER_SLOTS - 1)) * 8 + 5], (unsigned long long)gx * gy);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -235,11 +235,11 @@ k_reward_pair(const ippm_config* __restrict__ c, const float* __restrict__ befor
   const size_t total = (size_t)c->grid_x * c->grid_y;
   const float* b = before + (size_t)m * total;
   const float* a = after + (size_t)m * total;
-  const float lo = c->clip_lo, hi = c->clip_hi;
+  const float lc = c->logit_clip, wt = c->logit_weight_thr;
   float s1 = 0.f, s2 = 0.f;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const float wa = ippm_weight(a[i]);
-    const float hb = ippm_entropy(b[i], lo, hi), ha = ippm_entropy(a[i], lo, hi);
+    const float wa = ippm_weight_l(a[i], wt);
+    const float hb = ippm_entropy_l(b[i], lc), ha = ippm_entropy_l(a[i], lc);
     s1 += wa * (hb - ha);
     s2 += wa * hb;
   }

@@ -32,6 +32,7 @@
 #define OP_XL 5
 #define OP_XR 6
 #define IPPM_MAX_OPS (IPPM_MAX_AGENTS + 2)
+#define IPPM_COUNTER_SLOTS 64  // work counters are spread over 64 slots to keep atomics off one address
 
 // sums layout: double [E, 8]
 #define SUM_S1 0
@@ -51,7 +52,7 @@ struct ResizeTab {           // area-average weights of one source length -> 11 
 struct ippm_ctx {
   ippm_config cfg;           // host copy
   ippm_config* dcfg;         // device copy
-  unsigned long long* dcounters;  // device, 8 words (ippm_counters)
+  unsigned long long* dcounters;  // device, IPPM_COUNTER_SLOTS x 8 words (summed into ippm_counters on read)
   // K6 tables (device): rows (gx), cols (gy), and one per altitude level for the 2r x 2r footprint image
   int32_t* tab_bin0;
   float* tab_w0;
@@ -77,25 +78,36 @@ int ippm_check_hip(hipError_t err, const char* what);
 
 __device__ __forceinline__ float ippm_clipf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 
-// ln(x/(1-x)) for x already clipped to [clip_lo, clip_hi]
-__device__ __forceinline__ float ippm_logit(float x) {
-  return __logf(x * __builtin_amdgcn_rcpf(1.0f - x));
-}
+// Maps are stored as float32 LOG-ODDS L = ln(p/(1-p)) (DESIGN.md "log-odds storage"): the reference's
+// clip(p, 1e-4, 0.9999) is clamp(L, -lc, +lc) with lc = ln(0.9999/0.0001), its Bayes update is an add.
+__device__ __forceinline__ float ippm_clampl(float l, float lc) { return fminf(fmaxf(l, -lc), lc); }
 
-// 1 - 1/(1+e^L) evaluated as 1/(1+e^-L): accurate relative to both p and 1-p in float32
+// p = 1 - 1/(1+e^L) evaluated as 1/(1+e^-L): accurate relative to p (and e^L-small p) in float32
 __device__ __forceinline__ float ippm_sigmoid(float l) {
   return __builtin_amdgcn_rcpf(1.0f + __expf(-l));
 }
+__device__ __forceinline__ float ippm_logit(float x) { return __logf(x * __builtin_amdgcn_rcpf(1.0f - x)); }
 
-// Shannon entropy in bits of p clipped to [lo,hi] (utils/state.py:118-121)
+// Shannon entropy in bits of p = sigmoid(clamp(L)) (utils/state.py:118-121), symmetric in the sign of L;
+// the small side q = e/(1+e) keeps full relative precision
+__device__ __forceinline__ float ippm_entropy_l(float l, float lc) {
+  const float a = fminf(fabsf(l), lc);
+  const float e = __expf(-a);
+  const float big = __builtin_amdgcn_rcpf(1.0f + e);
+  const float small = e * big;
+  return -big * __log2f(big) - small * __log2f(small);
+}
+// entropy of a probability (used on the 11x11 resized planes)
 __device__ __forceinline__ float ippm_entropy(float p, float lo, float hi) {
   p = ippm_clipf(p, lo, hi);
   float q = 1.0f - p;
   return -p * __log2f(p) - q * __log2f(q);
 }
 
-// class weight (utils/state.py:60-73 with class_weighting [0,1]): thresholds on the unclipped value
+// class weight (utils/state.py:60-73 with class_weighting [0,1]): thresholds 0.501 / 0.499 on the unclipped value
 __device__ __forceinline__ float ippm_weight(float p) { return p > 0.501f ? 1.0f : (p < 0.499f ? 0.0f : 0.5f); }
+// same test on log-odds: wt = ln(0.501/0.499)
+__device__ __forceinline__ float ippm_weight_l(float l, float wt) { return l > wt ? 1.0f : (l < -wt ? 0.0f : 0.5f); }
 
 __device__ __forceinline__ float ippm_wave_sum(float v) {
 #pragma unroll

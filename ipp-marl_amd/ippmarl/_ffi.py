@@ -28,6 +28,7 @@ class IppmConfig(C.Structure):
         ("logit_meas", (C.c_float * 2) * MAX_Z), ("meas_value", (C.c_float * 2) * MAX_Z),
         ("flip_threshold", C.c_uint32 * MAX_Z),
         ("prior", C.c_float), ("clip_lo", C.c_float), ("clip_hi", C.c_float),
+        ("logit_prior", C.c_float), ("logit_clip", C.c_float), ("logit_weight_thr", C.c_float),
         ("comm_range", C.c_double), ("failure_rate", C.c_double),
         ("philox_seed", C.c_uint64), ("gamma", C.c_double), ("lambda_", C.c_double),
     ]
@@ -49,6 +50,8 @@ PROTOTYPES = {
     "ippm_sync": [P, P],
     "ippm_read_counters": [P, C.POINTER(IppmCounters), C.c_int, P],
     "ippm_reset_episode": [P, P, P, P, P, P, P, P, P, P, I32, P],
+    "ippm_logodds_to_prob": [P, P, P, I64, P],
+    "ippm_prob_to_logodds": [P, P, P, I64, P],
     "ippm_footprint": [P, P, P, P, I32, P],
     "ippm_sense_update": [P, P, P, P, P, P, P, P, P, I32, I32, I32, P],
     "ippm_comm_matrix": [P, P, P, P, P, P, I32, I32, P],
@@ -88,6 +91,10 @@ def load_library() -> C.CDLL:
     lib.ippm_last_error.argtypes = []
     lib.ippm_version.restype = C.c_int
     lib.ippm_version.argtypes = []
+    lib.ippm_config_size.restype = C.c_int
+    lib.ippm_config_size.argtypes = []
+    if lib.ippm_config_size() != C.sizeof(IppmConfig):
+        raise IppmError(f"ippm_config layout mismatch: library {lib.ippm_config_size()} B, binding {C.sizeof(IppmConfig)} B")
     for name, args in PROTOTYPES.items():
         fn = getattr(lib, name)
         fn.argtypes = args
@@ -121,6 +128,7 @@ def make_config(d: DerivedConstants) -> IppmConfig:
             c.meas_value[k][o] = float(d.meas_value[k, o])
         c.flip_threshold[k] = int(d.flip_threshold[k])
     c.prior, c.clip_lo, c.clip_hi = d.prior, CLIP_LO, CLIP_HI
+    c.logit_prior, c.logit_clip, c.logit_weight_thr = d.logit_prior, d.logit_clip, d.logit_weight_thr
     c.comm_range, c.failure_rate = d.comm_range, d.failure_rate
     c.philox_seed = d.philox_seed & 0xFFFFFFFFFFFFFFFF
     c.gamma, c.lambda_ = d.gamma, d.lam

@@ -86,6 +86,10 @@ class DerivedConstants:
             with np.errstate(divide="ignore"):
                 self.logit_meas[k] = np.log(y / (1 - y))
             self.flip_threshold[k] = int(math.floor(nz * 4294967296.0))
+        # log-odds constants of the device representation (maps are stored as ln(p/(1-p)))
+        self.logit_prior = float(np.log(self.prior / (1 - self.prior))) if 0 < self.prior < 1 else 0.0
+        self.logit_clip = float(np.log(CLIP_HI / (1 - CLIP_HI)))
+        self.logit_weight_thr = float(np.log(0.501 / 0.499))
         # code/flip tile stride: widest footprint + 3 cells of alignment slack, multiple of 4
         need = max(max(2 * r for r in rx), max(2 * r for r in ry) + 3, 4)
         self.tile_stride = (need + 3) // 4 * 4

@@ -45,6 +45,7 @@ class VecEnv:
         self.pos_pre = z(E, N, 3, dtype=torch.int32)
         self.rect = z(E, N, 4, dtype=torch.int32)
         self.truth = z(E, d.grid_x, d.grid_y, dtype=torch.uint8)
+        # beliefs are stored as float32 log-odds (0 = prior 0.5); posterior_local()/posterior_global() export p
         self.local = z(E, N, d.grid_x, d.grid_y, dtype=torch.float32)
         self.glob = z(E, d.grid_x, d.grid_y, dtype=torch.float32)
         self.code = z(E, N, S, S, dtype=torch.uint8)
@@ -71,6 +72,18 @@ class VecEnv:
 
     def state_bytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in vars(self).values() if isinstance(t, torch.Tensor))
+
+    def _to_prob(self, logodds: torch.Tensor) -> torch.Tensor:
+        out = torch.empty_like(logodds)
+        self.ctx.call("ippm_logodds_to_prob", self._p(logodds), self._p(out), logodds.numel(), self.stream)
+        return out
+
+    def posterior_local(self) -> torch.Tensor:
+        """Occupancy probabilities of the agents' local maps, float32 [E,N,gx,gy] (the reference's local_map)."""
+        return self._to_prob(self.local)
+
+    def posterior_global(self) -> torch.Tensor:
+        return self._to_prob(self.glob)
 
     def footprints(self, pos: Optional[torch.Tensor] = None):
         pos = self.pos if pos is None else pos

@@ -70,11 +70,11 @@ def test_golden_episode_replay(golden, tag):
         np.testing.assert_allclose(state[0].cpu().numpy(), fx["state"][t], rtol=RTOL, atol=2e-6, err_msg=f"state t={t}")
         assert done == bool(fx["done"][t, 0])
         if t == 0:
-            np.testing.assert_allclose(env.glob[0].cpu().numpy(), fx["global_t0"], rtol=RTOL)
+            np.testing.assert_allclose(env.posterior_global()[0].cpu().numpy(), fx["global_t0"], rtol=RTOL)
         if t == 7:
-            np.testing.assert_allclose(env.glob[0].cpu().numpy(), fx["global_t7"], rtol=RTOL)
-    np.testing.assert_allclose(env.local[0].cpu().numpy(), fx["final_local"], rtol=RTOL)
-    np.testing.assert_allclose(env.glob[0].cpu().numpy(), fx["final_global"], rtol=RTOL)
+            np.testing.assert_allclose(env.posterior_global()[0].cpu().numpy(), fx["global_t7"], rtol=RTOL)
+    np.testing.assert_allclose(env.posterior_local()[0].cpu().numpy(), fx["final_local"], rtol=RTOL)
+    np.testing.assert_allclose(env.posterior_global()[0].cpu().numpy(), fx["final_global"], rtol=RTOL)
 
 
 def _oracle_philox_episode(params, episode, seed, learned_probs=None):
@@ -113,8 +113,9 @@ def test_production_randomness_matches_oracle(name, over, n_envs):
     for t in range(T):
         obs = env.build_observations(t, features=feats)
         comm = env.comm.cpu().numpy()
-        local = env.local.cpu().numpy()
+        local = env.posterior_local().cpu().numpy()
         reward, done, state = env.steps(t, policy=POLICY_UNIFORM, features=feats)
+        glob = env.posterior_global().cpu().numpy()
         for e, (ep, log) in enumerate(oracles):
             rec = log[t]
             n = env.d.n_agents
@@ -127,14 +128,15 @@ def test_production_randomness_matches_oracle(name, over, n_envs):
             assert np.array_equal(env.pos[e].cpu().numpy(), rec["next_positions"]), (t, e)
             assert np.array_equal(env.rect[e].cpu().numpy(), rec["next_rects"]), (t, e)
             np.testing.assert_allclose(local[e], np.array(rec["fused_local"]), rtol=RTOL, err_msg=f"fused local t={t} e={e}")
-            np.testing.assert_allclose(env.glob[e].cpu().numpy(), rec["global_map"], rtol=RTOL, err_msg=f"global t={t} e={e}")
+            np.testing.assert_allclose(glob[e], rec["global_map"], rtol=RTOL, err_msg=f"global t={t} e={e}")
             np.testing.assert_allclose(reward[e].cpu().numpy(), [rec["relative_reward"], rec["absolute_reward"]], rtol=RTOL, atol=1e-6)
             np.testing.assert_allclose(env.sums[e, :2].cpu().numpy(), [rec["s1"], rec["s2"]], rtol=RTOL, atol=1e-6)
             if feats:
                 np.testing.assert_allclose(obs[e].cpu().numpy(), np.array(rec["observations"]), rtol=RTOL, atol=2e-6)
                 np.testing.assert_allclose(state[e].cpu().numpy(), np.array(rec["states"]), rtol=RTOL, atol=2e-6)
+    final = env.posterior_local().cpu().numpy()
     for e, (ep, log) in enumerate(oracles):
-        np.testing.assert_allclose(env.local[e].cpu().numpy(), np.array([a["local_map"] for a in ep.agents]), rtol=RTOL)
+        np.testing.assert_allclose(final[e], np.array([a["local_map"] for a in ep.agents]), rtol=RTOL)
 
 
 def test_saturation_and_deferred_clamp():
@@ -159,15 +161,15 @@ def test_saturation_and_deferred_clamp():
     exceeded = False
     for t in range(d.budget + 1):
         obs = env.build_observations(t)
-        np.testing.assert_allclose(env.local[0].cpu().numpy(), np.array(log[t]["fused_local"]), rtol=RTOL, err_msg=f"t={t}")
+        np.testing.assert_allclose(env.posterior_local()[0].cpu().numpy(), np.array(log[t]["fused_local"]), rtol=RTOL, err_msg=f"t={t}")
         np.testing.assert_allclose(obs[0].cpu().numpy(), np.array(log[t]["observations"]), rtol=RTOL, atol=2e-6)
         acts = torch.tensor([log[t]["actions"]], dtype=torch.int32)
         reward, _, state = env.steps(t, policy=POLICY_EXPLICIT, actions=acts)
-        np.testing.assert_allclose(env.glob[0].cpu().numpy(), log[t]["global_map"], rtol=RTOL, err_msg=f"global t={t}")
+        np.testing.assert_allclose(env.posterior_global()[0].cpu().numpy(), log[t]["global_map"], rtol=RTOL, err_msg=f"global t={t}")
         np.testing.assert_allclose(float(reward[0, 0]), log[t]["relative_reward"], rtol=RTOL, atol=1e-6)
-        exceeded |= bool((env.local[0] > 0.9999).any())
+        exceeded |= bool((env.local[0].abs() > env.d.logit_clip).any())
     assert exceeded, "scenario no longer saturates: the deferred-clamp path is not exercised"
-    np.testing.assert_allclose(env.local[0].cpu().numpy(), np.array([a["local_map"] for a in ep.agents]), rtol=RTOL)
+    np.testing.assert_allclose(env.posterior_local()[0].cpu().numpy(), np.array([a["local_map"] for a in ep.agents]), rtol=RTOL)
 
 
 def test_full_size_properties():
@@ -197,8 +199,10 @@ def test_full_size_properties():
     full = torch.zeros(E, dtype=torch.float64, device=env.device)
     env.ctx.call("ippm_weighted_entropy", env._p(env.glob), None, 1, env._p(full), E, env.stream)
     torch.testing.assert_close(env.sums[:, 2], full, rtol=1e-6, atol=1e-3)
-    # (3) posteriors stay probabilities; unobserved cells stay at the prior
-    assert float(env.local.min()) > 0.0 and float(env.local.max()) < 1.0
+    # (3) beliefs stay finite log-odds; posteriors are probabilities
+    assert bool(torch.isfinite(env.local).all()) and bool(torch.isfinite(env.glob).all())
+    pg = env.posterior_global()
+    assert float(pg.min()) > 0.0 and float(pg.max()) < 1.0
     assert bool(torch.isfinite(returns).all())
     # (4) positions stay on the lattice and inside the world
     p = env.pos.cpu().numpy()
