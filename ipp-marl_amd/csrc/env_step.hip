@@ -6,6 +6,8 @@
 //     the 1-byte truth/code/flip planes ride along as one aligned 32-bit word per lane;
 //   - narrow footprints pack several rows into one 64-lane wavefront (lanes-per-row = next pow2);
 //   - every map cell is read and written at most once per kernel, whatever the number of fused measurements.
+#include <cstdlib>
+
 #include "ippm_internal.h"
 
 // ======================================================================================================
@@ -625,6 +627,11 @@ __global__ void k_mask_act_move(const ippm_config* __restrict__ c, const int64_t
 // ======================================================================================================
 static inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int grid1(size_t n, int b = 256) { return (int)((n + b - 1) / b); }
+// tuning knob (row splits per tile/map); the defaults are the measured best on MI355X
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
 
 extern "C" int ippm_reset_episode(ippm_ctx* ctx, const int64_t* episode, int32_t* pos, uint8_t* truth, float* local,
                                   float* global, int32_t* split_pct, float* comm_range_out, int32_t* ws, double* sums,
@@ -685,7 +692,7 @@ extern "C" int ippm_sense_update(ippm_ctx* ctx, const int64_t* episode, const in
   if (!flips && !episode) { ippm_set_error("ippm_sense_update: Philox flips need the episode ids"); return -1; }
   if (agent_sel >= ctx->cfg.n_agents) { ippm_set_error("ippm_sense_update: agent_sel out of range"); return -1; }
   const int maps = agent_sel >= 0 ? n_envs : n_envs * ctx->cfg.n_agents;
-  dim3 grid(4, maps), block(256);
+  dim3 grid(env_int("IPPM_SPLIT_K3", 4), maps), block(256);
   if (ctx->vec == 4)
     hipLaunchKernelGGL(k_sense_update<4>, grid, block, 0, S_(stream), ctx->dcfg, episode, pos, truth, local, flips, code, rect,
                        ws, ctx->dcounters, stage, agent_sel);
@@ -712,7 +719,7 @@ extern "C" int ippm_fuse_local(ippm_ctx* ctx, float* local, const uint8_t* code,
   const int maps = n_envs * ctx->cfg.n_agents;
   hipLaunchKernelGGL(k_plan, dim3(grid1(maps, 64)), dim3(64), 0, S_(stream), ctx->dcfg, rect, pos, comm, ws, 0, n_envs);
   IPPM_LAUNCH_CHECK("plan_local");
-  dim3 grid(8, maps), block(256);
+  dim3 grid(env_int("IPPM_SPLIT_K4", 8), maps), block(256);
   if (ctx->vec == 4)
     hipLaunchKernelGGL((k_apply_ops<4, false>), grid, block, 0, S_(stream), ctx->dcfg, local, code, ws, nullptr, ctx->dcounters);
   else
@@ -730,7 +737,7 @@ extern "C" int ippm_fuse_global_reward(ippm_ctx* ctx, float* global, const uint8
   }
   hipLaunchKernelGGL(k_plan, dim3(grid1(n_envs, 64)), dim3(64), 0, S_(stream), ctx->dcfg, rect, pos, nullptr, ws, 1, n_envs);
   IPPM_LAUNCH_CHECK("plan_global");
-  dim3 grid(16, n_envs), block(256);
+  dim3 grid(env_int("IPPM_SPLIT_K5", 16), n_envs), block(256);
   if (ctx->vec == 4)
     hipLaunchKernelGGL((k_apply_ops<4, true>), grid, block, 0, S_(stream), ctx->dcfg, global, code, ws, sums, ctx->dcounters);
   else

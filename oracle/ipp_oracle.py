@@ -66,6 +66,11 @@ class Derived:
         self.comm_range = uav["communication_range"]
         self.fix_range = uav["fix_range"]
         self.failure_rate = uav["failure_rate"]
+        # exact=False reproduces the reference's dtype flow bit for bit, including its float32 re-quantisation of
+        # every map at the start of each fusion (mappings.py:83,93,100: np.float32(own_map_state.copy())).
+        # exact=True keeps the maps in float64 throughout: the mathematically exact recursion, free of that
+        # storage noise (see tests/conftest.py::assert_posteriors for how the two are used).
+        self.exact = False
 
 
 def position_to_index(d: Derived, position) -> np.ndarray:
@@ -212,7 +217,7 @@ def bayes_update(x: np.ndarray, y: np.ndarray, prior: float) -> np.ndarray:
 
 
 def init_prior_map(d: Derived) -> np.ndarray:
-    return np.full((int(d.gx), int(d.gy)), d.prior, dtype="float32")
+    return np.full((int(d.gx), int(d.gy)), d.prior, dtype="float64" if d.exact else "float32")
 
 
 def update_grid_map(d: Derived, truth: np.ndarray, position, map_state: np.ndarray, correctness: np.ndarray):
@@ -241,7 +246,7 @@ def tile_shape(fc) -> Tuple[int, int]:
 def fuse_map(d: Derived, own: np.ndarray, others, agent_id, fusion_mode: str) -> np.ndarray:
     """mappings.py:80-104: sequential FULL-GRID updates with each other agent's map2communicate
     (0.5 outside its footprint => logit 0, but the input clip still applies to every cell)."""
-    fused = np.float32(own.copy())
+    fused = own.astype(np.float64) if d.exact else np.float32(own.copy())
     if fusion_mode == "local":
         for key in others:
             if key == agent_id:
@@ -569,8 +574,9 @@ class OracleEpisode:
 
     def __init__(self, params: Dict, episode: int, correctness: Callable, choose_action: Callable,
                  comm_draw: Optional[Callable] = None, truth: Optional[np.ndarray] = None,
-                 build_features: bool = True, start_positions: Optional[Sequence] = None):
+                 build_features: bool = True, start_positions: Optional[Sequence] = None, exact: bool = False):
         self.d = Derived(params)
+        self.d.exact = exact
         self.episode = episode
         self.truth = make_truth(self.d, episode) if truth is None else truth
         self.correctness = correctness

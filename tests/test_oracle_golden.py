@@ -184,3 +184,27 @@ def test_philox_known_answer():
     assert [int(x) for x in r] == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
     r = O.philox4x32(0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344, 0xA4093822, 0x299F31D0)
     assert [int(x) for x in r] == [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+
+
+@pytest.mark.parametrize("tag", list(EPISODES))
+def test_exact_mode_differs_only_by_reference_quantisation(golden, tag):
+    """The oracle's exact-float64 mode (what the GPU path is held to at 1e-5, every cell) against the reference's
+    own output: identical integers, and floats that differ only by the reference's float32 map re-quantisation."""
+    from conftest import assert_posteriors
+    fx = golden(tag)
+    params = make_params(EPISODES[tag]["name"], **EPISODES[tag]["over"])
+    d = O.Derived(params)
+    n = d.n_agents
+    corr = unpack_correctness(fx)
+    comm = fx["comm_draws"]
+    ep = O.OracleEpisode(params, int(fx["episode"]), correctness=lambda i, s, shape: corr[s * n + i].reshape(shape),
+                         choose_action=lambda i, t, mask, obs: fx["actions"][t, i],
+                         comm_draw=lambda i, j, t: comm[(t * n + i) * n + j], exact=True)
+    log = ep.run()
+    for t, rec in enumerate(log):
+        assert np.array_equal(rec["next_positions"], fx["positions"][t + 1])
+        assert np.array_equal(rec["masks"], fx["masks"][t])
+        np.testing.assert_allclose(rec["relative_reward"], fx["rewards"][t, 0], rtol=RTOL, atol=1e-6)
+        np.testing.assert_allclose(np.array(rec["observations"]), fx["obs"][t], rtol=RTOL, atol=1e-6)
+    assert_posteriors(np.array([a["local_map"] for a in ep.agents]), fx["final_local"], strict=False, msg="final local")
+    assert_posteriors(ep.global_map, fx["final_global"], strict=False, msg="final global")
