@@ -162,7 +162,7 @@ __device__ __forceinline__ void store_bytes(uint8_t* p, uint32_t w) {
 // ======================================================================================================
 // K3: sense + Bayesian update of the agent's own footprint tile
 // ======================================================================================================
-template <int VEC>
+template <int VEC, int UNR>
 __global__ void __launch_bounds__(256)
 k_sense_update(const ippm_config* __restrict__ c, const int64_t* __restrict__ episode,
                const int32_t* __restrict__ pos, const uint8_t* __restrict__ truth, float* __restrict__ local,
@@ -197,41 +197,55 @@ k_sense_update(const ippm_config* __restrict__ c, const int64_t* __restrict__ ep
   const int64_t ep = episode ? episode[e] : 0;
   const uint32_t sw = ippm_stream_word((uint32_t)i, (uint32_t)stage, IPPM_DOMAIN_FLIP);
   const uint32_t k0 = (uint32_t)c->philox_seed, k1 = (uint32_t)(c->philox_seed >> 32);
+  const int stride = 4 * g.rpw;
   bool exceed = false;
-  for (int row = r0 + wv * g.rpw + sub; row < r1; row += 4 * g.rpw) {
-    const int x = xl + row;
-    for (int gi = gl; gi < g.groups; gi += g.lpr) {
-      const int y = g.y0 + gi * VEC;
-      const size_t cell = (size_t)x * gy + y;
-      CellVec<VEC> m = load_cells<VEC>(map + cell);
-      const uint32_t tw = load_bytes<VEC>(tr + cell);
-      const size_t tcell = (size_t)row * S + (y - tile_y0);
-      uint32_t fw = 0;
-      Philox4 ph;
-      if (fl) fw = load_bytes<VEC>(fl + tcell);
-      else if (VEC == 4) ph = ippm_philox((uint32_t)(cell >> 2), (uint32_t)ep, sw, (uint32_t)(ep >> 32), k0, k1);
-      uint32_t cw = 0;
+  for (int gi = gl; gi < g.groups; gi += g.lpr) {
+    const int y = g.y0 + gi * VEC;
+    for (int row = r0 + wv * g.rpw + sub; row < r1; row += stride * UNR) {
+      // UNR independent rows per lane: all their loads are in flight before the first use
+      CellVec<VEC> m[UNR];
+      uint32_t tw[UNR], fw[UNR];
 #pragma unroll
-      for (int q = 0; q < VEC; ++q) {
-        const int yy = y + q;
-        if (yy >= yu && yy < yd) {
-          uint32_t flip;
-          if (fl) flip = (fw >> (8 * q)) & 1u;
-          else if (VEC == 4) flip = ph.v[q] < thr ? 1u : 0u;
-          else {
-            Philox4 p1 = ippm_philox((uint32_t)((cell + q) >> 2), (uint32_t)ep, sw, (uint32_t)(ep >> 32), k0, k1);
-            flip = p1.v[(cell + q) & 3] < thr ? 1u : 0u;
-          }
-          const uint32_t obs = ((tw >> (8 * q)) & 1u) ^ flip;
-          // mappings.py:109-124 in log-odds: clip the prior belief, add the measurement's log-odds
-          const float l = ippm_clampl(m.v[q], lc) + (obs ? lm1 : lm0);
-          exceed |= fabsf(l) > lc;
-          m.v[q] = l;
-          cw |= obs << (8 * q);
+      for (int u = 0; u < UNR; ++u) {
+        const int rr = row + u * stride;
+        tw[u] = 0; fw[u] = 0;
+        if (rr < r1) {
+          const size_t cell = (size_t)(xl + rr) * gy + y;
+          m[u] = load_cells<VEC>(map + cell);
+          tw[u] = load_bytes<VEC>(tr + cell);
+          if (fl) fw[u] = load_bytes<VEC>(fl + (size_t)rr * S + (y - tile_y0));
         }
       }
-      store_cells<VEC>(map + cell, m);
-      store_bytes<VEC>(cd + tcell, cw);
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int rr = row + u * stride;
+        if (rr >= r1) continue;
+        const size_t cell = (size_t)(xl + rr) * gy + y;
+        Philox4 ph;
+        if (!fl && VEC == 4) ph = ippm_philox((uint32_t)(cell >> 2), (uint32_t)ep, sw, (uint32_t)(ep >> 32), k0, k1);
+        uint32_t cw = 0;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+          const int yy = y + q;
+          if (yy >= yu && yy < yd) {
+            uint32_t flip;
+            if (fl) flip = (fw[u] >> (8 * q)) & 1u;
+            else if (VEC == 4) flip = ph.v[q] < thr ? 1u : 0u;
+            else {
+              Philox4 p1 = ippm_philox((uint32_t)((cell + q) >> 2), (uint32_t)ep, sw, (uint32_t)(ep >> 32), k0, k1);
+              flip = p1.v[(cell + q) & 3] < thr ? 1u : 0u;
+            }
+            const uint32_t obs = ((tw[u] >> (8 * q)) & 1u) ^ flip;
+            // mappings.py:109-124 in log-odds: clip the prior belief, add the measurement's log-odds
+            const float l = ippm_clampl(m[u].v[q], lc) + (obs ? lm1 : lm0);
+            exceed |= fabsf(l) > lc;
+            m[u].v[q] = l;
+            cw |= obs << (8 * q);
+          }
+        }
+        store_cells<VEC>(map + cell, m[u]);
+        store_bytes<VEC>(cd + (size_t)rr * S + (y - tile_y0), cw);
+      }
     }
   }
   if (ws && __any(exceed) && lane == 0) ws[(size_t)(e * (n + 1) + i) * IPPM_WS_WORDS + WS_FLAG_S] = 1;
@@ -344,22 +358,25 @@ __global__ void k_plan(const ippm_config* __restrict__ c, const int32_t* __restr
 // K4 / K5: apply the planned ops to a map, each touched cell read once and written once.
 // REWARD: also accumulate the information-gain reward terms of K5 (utils/reward.py:68-82).
 // ======================================================================================================
+// Ops of one plan chunk held in registers while a row group is processed.
+#define APPLY_CH 6
+
 template <int VEC, bool REWARD>
 __global__ void __launch_bounds__(256)
 k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const uint8_t* __restrict__ code,
-            int32_t* __restrict__ ws, double* __restrict__ sums, unsigned long long* __restrict__ counters) {
+            const int32_t* __restrict__ plan_ro, int32_t* __restrict__ ws, double* __restrict__ sums,
+            unsigned long long* __restrict__ counters) {
   const int n = c->n_agents;
   const int m = blockIdx.y;  // map index: (e,i) for local maps, e for global maps
   const int e = REWARD ? m : m / n;
   const int slot = REWARD ? n : m % n;
-  int32_t* w = ws + (size_t)(e * (n + 1) + slot) * IPPM_WS_WORDS;
-  const int32_t* hdr = w + WS_PLAN;
+  const size_t wbase = (size_t)(e * (n + 1) + slot) * IPPM_WS_WORDS;
+  // the plan is read through a read-only, wavefront-uniform pointer: scalar loads, ops live in SGPRs
+  const int32_t* __restrict__ hdr = plan_ro + wbase + WS_PLAN;
+  const int32_t* __restrict__ ops = plan_ro + wbase + WS_OPS;
   const int nops = hdr[PL_NOPS];
   if (nops == 0) return;
-  __shared__ int32_t s_ops[IPPM_MAX_OPS * OP_WORDS];
   __shared__ float s_red[4][6];
-  for (int q = threadIdx.x; q < nops * OP_WORDS; q += blockDim.x) s_ops[q] = w[WS_OPS + q];
-  __syncthreads();
   const int gx = c->grid_x, gy = c->grid_y, S = c->tile_stride;
   const int X0 = hdr[PL_X0], X1 = hdr[PL_X1], last_op = hdr[PL_LAST];
   const float lc = c->logit_clip, wt = c->logit_weight_thr;
@@ -378,10 +395,10 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
     const int x = X0 + row;
     for (int gi = gl; gi < g.groups; gi += g.lpr) {
       const int y = g.y0 + gi * VEC;
-      // which ops cover any of my cells?
+      // pass 0: does any op cover one of my cells?  (no memory traffic for cells outside every footprint)
       bool need = false;
       for (int o = 0; o < nops; ++o) {
-        const int32_t* op = s_ops + o * OP_WORDS;
+        const int32_t* op = ops + o * OP_WORDS;
         need |= (x >= op[OP_XL] && x < op[OP_XR] && y + VEC > op[OP_YU] && y < op[OP_YD]);
       }
       if (!need) continue;
@@ -391,27 +408,42 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
       int lastt[VEC];
       bool fused[VEC];
 #pragma unroll
-      for (int q = 0; q < VEC; ++q) { L[q] = 0.f; lastt[q] = -1; fused[q] = false; }
-      for (int o = 0; o < nops; ++o) {
-        const int32_t* op = s_ops + o * OP_WORDS;
-        if (!(x >= op[OP_XL] && x < op[OP_XR] && y + VEC > op[OP_YU] && y < op[OP_YD])) continue;
-        uint32_t cw = 0;
-        float lm0 = 0.f, lm1 = 0.f;
-        if (op[OP_TYPE]) {
-          const int j = op[OP_SRC];
-          cw = load_bytes<VEC>(code_e + (size_t)j * S * S + (size_t)(x - op[OP_XL]) * S + (y - (op[OP_YU] & ~3)));
-          lm0 = c->logit_meas[op[OP_ALT]][0];
-          lm1 = c->logit_meas[op[OP_ALT]][1];
-        }
+      for (int q = 0; q < VEC; ++q) { L[q] = mv.v[q]; lastt[q] = -1; fused[q] = false; }
+      for (int o0 = 0; o0 < nops; o0 += APPLY_CH) {
+        // pass 1: issue every measurement-code load of this chunk before any of them is used
+        uint32_t cw[APPLY_CH];
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) {
-          const int yy = y + q;
-          if (yy >= op[OP_YU] && yy < op[OP_YD]) {
-            // every op of the reference clips its input over the whole grid (mappings.py:110-111)
-            L[q] = ippm_clampl(lastt[q] < 0 ? mv.v[q] : L[q], lc);
-            if (op[OP_TYPE]) { L[q] += ((cw >> (8 * q)) & 1u) ? lm1 : lm0; fused[q] = true; }
-            lastt[q] = o;
-            ++opcells;
+        for (int k = 0; k < APPLY_CH; ++k) {
+          cw[k] = 0;
+          const int o = o0 + k;
+          if (o < nops) {
+            const int32_t* op = ops + o * OP_WORDS;
+            if (op[OP_TYPE] && x >= op[OP_XL] && x < op[OP_XR] && y + VEC > op[OP_YU] && y < op[OP_YD])
+              cw[k] = load_bytes<VEC>(code_e + (size_t)op[OP_SRC] * S * S + (size_t)(x - op[OP_XL]) * S + (y - (op[OP_YU] & ~3)));
+          }
+        }
+        // pass 2: the ordered clamp/add chain (mappings.py:80-124 in log-odds)
+#pragma unroll
+        for (int k = 0; k < APPLY_CH; ++k) {
+          const int o = o0 + k;
+          if (o < nops) {
+            const int32_t* op = ops + o * OP_WORDS;
+            if (x >= op[OP_XL] && x < op[OP_XR]) {
+              const int type = op[OP_TYPE], yu = op[OP_YU], yd = op[OP_YD];
+              const float lm0 = c->logit_meas[op[OP_ALT]][0], lm1 = c->logit_meas[op[OP_ALT]][1];
+#pragma unroll
+              for (int q = 0; q < VEC; ++q) {
+                const int yy = y + q;
+                if (yy >= yu && yy < yd) {
+                  // every op of the reference clips its input over the whole grid (mappings.py:110-111)
+                  float l = ippm_clampl(L[q], lc);
+                  if (type) { l += ((cw[k] >> (8 * q)) & 1u) ? lm1 : lm0; fused[q] = true; }
+                  L[q] = l;
+                  lastt[q] = o;
+                  ++opcells;
+                }
+              }
+            }
           }
         }
       }
@@ -435,7 +467,7 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
       store_cells<VEC>(map + cell, mv);
     }
   }
-  if (__any(exceed) && lane == 0) w[WS_FLAG_A] = 1;
+  if (__any(exceed) && lane == 0) ws[wbase + WS_FLAG_A] = 1;
   // block reduction of the reward terms and work counters: one atomic per workgroup and quantity
   {
     const float fc = ippm_wave_sum((float)cells), fo = ippm_wave_sum((float)opcells);
@@ -447,8 +479,8 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
       if (threadIdx.x < 3) {
         if (REWARD) atomicAdd(&sums[(size_t)e * 8 + SUM_ACC1 + threadIdx.x], (double)t);
       } else if (counters && t > 0.f) {
-        const int slot = (blockIdx.y * gridDim.x + blockIdx.x) & (IPPM_COUNTER_SLOTS - 1);
-        atomicAdd(&counters[slot * 8 + (REWARD ? 3 : 1) + (threadIdx.x - 3)], (unsigned long long)t);
+        const int cslot = (blockIdx.y * gridDim.x + blockIdx.x) & (IPPM_COUNTER_SLOTS - 1);
+        atomicAdd(&counters[cslot * 8 + (REWARD ? 3 : 1) + (threadIdx.x - 3)], (unsigned long long)t);
       }
     }
   }
@@ -692,13 +724,19 @@ extern "C" int ippm_sense_update(ippm_ctx* ctx, const int64_t* episode, const in
   if (!flips && !episode) { ippm_set_error("ippm_sense_update: Philox flips need the episode ids"); return -1; }
   if (agent_sel >= ctx->cfg.n_agents) { ippm_set_error("ippm_sense_update: agent_sel out of range"); return -1; }
   const int maps = agent_sel >= 0 ? n_envs : n_envs * ctx->cfg.n_agents;
-  dim3 grid(env_int("IPPM_SPLIT_K3", 4), maps), block(256);
-  if (ctx->vec == 4)
-    hipLaunchKernelGGL(k_sense_update<4>, grid, block, 0, S_(stream), ctx->dcfg, episode, pos, truth, local, flips, code, rect,
-                       ws, ctx->dcounters, stage, agent_sel);
-  else
-    hipLaunchKernelGGL(k_sense_update<1>, grid, block, 0, S_(stream), ctx->dcfg, episode, pos, truth, local, flips, code, rect,
-                       ws, ctx->dcounters, stage, agent_sel);
+  dim3 grid(env_int("IPPM_SPLIT_K3", 2), maps), block(256);
+  const int unr = env_int("IPPM_UNROLL_K3", 2);
+#define IPPM_K3_LAUNCH(V, U)                                                                                              \
+  hipLaunchKernelGGL((k_sense_update<V, U>), grid, block, 0, S_(stream), ctx->dcfg, episode, pos, truth, local, flips, code, \
+                     rect, ws, ctx->dcounters, stage, agent_sel)
+  if (ctx->vec == 4) {
+    if (unr >= 4) IPPM_K3_LAUNCH(4, 4);
+    else if (unr >= 2) IPPM_K3_LAUNCH(4, 2);
+    else IPPM_K3_LAUNCH(4, 1);
+  } else {
+    IPPM_K3_LAUNCH(1, 1);
+  }
+#undef IPPM_K3_LAUNCH
   IPPM_LAUNCH_CHECK("sense_update");
   return 0;
 }
@@ -721,9 +759,9 @@ extern "C" int ippm_fuse_local(ippm_ctx* ctx, float* local, const uint8_t* code,
   IPPM_LAUNCH_CHECK("plan_local");
   dim3 grid(env_int("IPPM_SPLIT_K4", 8), maps), block(256);
   if (ctx->vec == 4)
-    hipLaunchKernelGGL((k_apply_ops<4, false>), grid, block, 0, S_(stream), ctx->dcfg, local, code, ws, nullptr, ctx->dcounters);
+    hipLaunchKernelGGL((k_apply_ops<4, false>), grid, block, 0, S_(stream), ctx->dcfg, local, code, ws, ws, nullptr, ctx->dcounters);
   else
-    hipLaunchKernelGGL((k_apply_ops<1, false>), grid, block, 0, S_(stream), ctx->dcfg, local, code, ws, nullptr, ctx->dcounters);
+    hipLaunchKernelGGL((k_apply_ops<1, false>), grid, block, 0, S_(stream), ctx->dcfg, local, code, ws, ws, nullptr, ctx->dcounters);
   IPPM_LAUNCH_CHECK("fuse_local");
   return 0;
 }
@@ -739,9 +777,9 @@ extern "C" int ippm_fuse_global_reward(ippm_ctx* ctx, float* global, const uint8
   IPPM_LAUNCH_CHECK("plan_global");
   dim3 grid(env_int("IPPM_SPLIT_K5", 16), n_envs), block(256);
   if (ctx->vec == 4)
-    hipLaunchKernelGGL((k_apply_ops<4, true>), grid, block, 0, S_(stream), ctx->dcfg, global, code, ws, sums, ctx->dcounters);
+    hipLaunchKernelGGL((k_apply_ops<4, true>), grid, block, 0, S_(stream), ctx->dcfg, global, code, ws, ws, sums, ctx->dcounters);
   else
-    hipLaunchKernelGGL((k_apply_ops<1, true>), grid, block, 0, S_(stream), ctx->dcfg, global, code, ws, sums, ctx->dcounters);
+    hipLaunchKernelGGL((k_apply_ops<1, true>), grid, block, 0, S_(stream), ctx->dcfg, global, code, ws, ws, sums, ctx->dcounters);
   IPPM_LAUNCH_CHECK("fuse_global");
   hipLaunchKernelGGL(k_reward_finalize, dim3(grid1(n_envs)), dim3(256), 0, S_(stream), ctx->dcfg, sums, reward, n_envs);
   IPPM_LAUNCH_CHECK("reward_finalize");
