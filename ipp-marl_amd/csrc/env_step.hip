@@ -6,6 +6,7 @@
 //     the 1-byte truth/code/flip planes ride along as one aligned 32-bit word per lane;
 //   - narrow footprints pack several rows into one 64-lane wavefront (lanes-per-row = next pow2);
 //   - every map cell is read and written at most once per kernel, whatever the number of fused measurements.
+#include <algorithm>
 #include <cstdlib>
 
 #include "ippm_internal.h"
@@ -167,17 +168,19 @@ __global__ void __launch_bounds__(256)
 k_sense_update(const ippm_config* __restrict__ c, const int64_t* __restrict__ episode,
                const int32_t* __restrict__ pos, const uint8_t* __restrict__ truth, float* __restrict__ local,
                const uint8_t* __restrict__ flips, uint8_t* __restrict__ code, int32_t* __restrict__ rect_out,
-               int32_t* __restrict__ ws, unsigned long long* __restrict__ counters, int stage, int agent_sel) {
+               int32_t* __restrict__ ws, unsigned long long* __restrict__ counters, int stage, int agent_sel,
+               int split) {
   const int n = c->n_agents;
+  const int tile = blockIdx.x / split, part = blockIdx.x % split;  // (tile, row part) flattened: grid.x has no 65535 limit
   int e, i;
-  if (agent_sel >= 0) { e = blockIdx.y; i = agent_sel; }
-  else { e = blockIdx.y / n; i = blockIdx.y % n; }
+  if (agent_sel >= 0) { e = tile; i = agent_sel; }
+  else { e = tile / n; i = tile % n; }
   const int gx = c->grid_x, gy = c->grid_y, S = c->tile_stride;
   const int32_t* p = pos + (size_t)(e * n + i) * 3;
   int r[4];
   ippm_footprint_rect(c, p[0], p[1], p[2], r, nullptr);
   const int yu = r[0], yd = r[1], xl = r[2], xr = r[3];
-  if (blockIdx.x == 0 && threadIdx.x < 4) rect_out[(size_t)(e * n + i) * 4 + threadIdx.x] = r[threadIdx.x];
+  if (part == 0 && threadIdx.x < 4) rect_out[(size_t)(e * n + i) * 4 + threadIdx.x] = r[threadIdx.x];
   const int h = xr - xl, w = yd - yu;
   if (h <= 0 || w <= 0) return;
   const int k = ippm_alt_index(c, p[2]);
@@ -186,8 +189,8 @@ k_sense_update(const ippm_config* __restrict__ c, const int64_t* __restrict__ ep
   const float lc = c->logit_clip;
   const RowGeom g = make_geom<VEC>(yu, yd);
   const int tile_y0 = yu & ~3;
-  const int rows_per_wg = (h + gridDim.x - 1) / gridDim.x;
-  const int r0 = blockIdx.x * rows_per_wg, r1 = min(h, r0 + rows_per_wg);
+  const int rows_per_wg = (h + split - 1) / split;
+  const int r0 = part * rows_per_wg, r1 = min(h, r0 + rows_per_wg);
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int sub = lane / g.lpr, gl = lane % g.lpr;
   float* map = local + (size_t)(e * n + i) * gx * gy;
@@ -249,8 +252,8 @@ k_sense_update(const ippm_config* __restrict__ c, const int64_t* __restrict__ ep
     }
   }
   if (ws && __any(exceed) && lane == 0) ws[(size_t)(e * (n + 1) + i) * IPPM_WS_WORDS + WS_FLAG_S] = 1;
-  if (counters && blockIdx.x == 0 && threadIdx.x == 0)
-    atomicAdd(&counters[(blockIdx.y & (IPPM_COUNTER_SLOTS - 1)) * 8 + 0], (unsigned long long)h * w);
+  if (counters && part == 0 && threadIdx.x == 0)
+    atomicAdd(&counters[(tile & (IPPM_COUNTER_SLOTS - 1)) * 8 + 0], (unsigned long long)h * w);
 }
 
 // ======================================================================================================
@@ -358,32 +361,40 @@ __global__ void k_plan(const ippm_config* __restrict__ c, const int32_t* __restr
 // K4 / K5: apply the planned ops to a map, each touched cell read once and written once.
 // REWARD: also accumulate the information-gain reward terms of K5 (utils/reward.py:68-82).
 // ======================================================================================================
-// Ops of one plan chunk held in registers while a row group is processed.
-#define APPLY_CH 6
-
+// Work decomposition: one workgroup column per (map, op).  The workgroups of op k walk the rows of ITS
+// rectangle (dense lanes, like K3) and own every 4-cell group that no later op touches; an owned group gets the
+// complete ordered chain of all ops covering each of its cells.  Every group of the union is therefore read
+// and written exactly once, by exactly one workgroup, whatever the overlap pattern.
 template <int VEC, bool REWARD>
 __global__ void __launch_bounds__(256)
 k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const uint8_t* __restrict__ code,
             const int32_t* __restrict__ plan_ro, int32_t* __restrict__ ws, double* __restrict__ sums,
-            unsigned long long* __restrict__ counters) {
+            unsigned long long* __restrict__ counters, int split) {
   const int n = c->n_agents;
-  const int m = blockIdx.y;  // map index: (e,i) for local maps, e for global maps
+  const int m = blockIdx.x / split, part = blockIdx.x % split;  // map index: (e,i) for local maps, e for global maps
+  const int k = blockIdx.y;  // op whose rectangle this workgroup walks
   const int e = REWARD ? m : m / n;
   const int slot = REWARD ? n : m % n;
   const size_t wbase = (size_t)(e * (n + 1) + slot) * IPPM_WS_WORDS;
-  // the plan is read through a read-only, wavefront-uniform pointer: scalar loads, ops live in SGPRs
   const int32_t* __restrict__ hdr = plan_ro + wbase + WS_PLAN;
-  const int32_t* __restrict__ ops = plan_ro + wbase + WS_OPS;
   const int nops = hdr[PL_NOPS];
-  if (nops == 0) return;
+  if (k >= nops) return;
+  __shared__ int4 s_ops[IPPM_MAX_OPS][2];  // {type, src, alt, yu}, {yd, xl, xr, -}
   __shared__ float s_red[4][6];
+  if (threadIdx.x < nops * 2) {
+    const int32_t* op = plan_ro + wbase + WS_OPS + (threadIdx.x >> 1) * OP_WORDS + (threadIdx.x & 1) * 4;
+    s_ops[threadIdx.x >> 1][threadIdx.x & 1] = make_int4(op[0], op[1], op[2], op[3]);
+  }
+  __syncthreads();
   const int gx = c->grid_x, gy = c->grid_y, S = c->tile_stride;
-  const int X0 = hdr[PL_X0], X1 = hdr[PL_X1], last_op = hdr[PL_LAST];
+  const int last_op = hdr[PL_LAST];
   const float lc = c->logit_clip, wt = c->logit_weight_thr;
-  const RowGeom g = make_geom<VEC>(hdr[PL_Y0], hdr[PL_Y1]);
-  const int rows = X1 - X0;
-  const int rows_per_wg = (rows + gridDim.x - 1) / gridDim.x;
-  const int r0 = blockIdx.x * rows_per_wg, r1 = min(rows, r0 + rows_per_wg);
+  const int4 ka = s_ops[k][0], kb = s_ops[k][1];
+  const int kyu = ka.w, kyd = kb.x, kxl = kb.y, kxr = kb.z;
+  const RowGeom g = make_geom<VEC>(kyu, kyd);
+  const int rows = kxr - kxl;
+  const int rows_per_wg = (rows + split - 1) / split;
+  const int r0 = part * rows_per_wg, r1 = min(rows, r0 + rows_per_wg);
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int sub = lane / g.lpr, gl = lane % g.lpr;
   float* map = maps + (size_t)m * gx * gy;
@@ -392,16 +403,16 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
   float a1 = 0.f, aD = 0.f, aT = 0.f;
   unsigned cells = 0, opcells = 0;
   for (int row = r0 + wv * g.rpw + sub; row < r1; row += 4 * g.rpw) {
-    const int x = X0 + row;
+    const int x = kxl + row;
     for (int gi = gl; gi < g.groups; gi += g.lpr) {
       const int y = g.y0 + gi * VEC;
-      // pass 0: does any op cover one of my cells?  (no memory traffic for cells outside every footprint)
-      bool need = false;
-      for (int o = 0; o < nops; ++o) {
-        const int32_t* op = ops + o * OP_WORDS;
-        need |= (x >= op[OP_XL] && x < op[OP_XR] && y + VEC > op[OP_YU] && y < op[OP_YD]);
+      // ownership: a later op touching any cell of this group takes it over
+      bool mine = true;
+      for (int o = k + 1; o < nops; ++o) {
+        const int4 oa = s_ops[o][0], ob = s_ops[o][1];
+        mine &= !(x >= ob.y && x < ob.z && y + VEC > oa.w && y < ob.x);
       }
-      if (!need) continue;
+      if (!mine) continue;
       const size_t cell = (size_t)x * gy + y;
       CellVec<VEC> mv = load_cells<VEC>(map + cell);
       float L[VEC];
@@ -409,41 +420,28 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
       bool fused[VEC];
 #pragma unroll
       for (int q = 0; q < VEC; ++q) { L[q] = mv.v[q]; lastt[q] = -1; fused[q] = false; }
-      for (int o0 = 0; o0 < nops; o0 += APPLY_CH) {
-        // pass 1: issue every measurement-code load of this chunk before any of them is used
-        uint32_t cw[APPLY_CH];
-#pragma unroll
-        for (int k = 0; k < APPLY_CH; ++k) {
-          cw[k] = 0;
-          const int o = o0 + k;
-          if (o < nops) {
-            const int32_t* op = ops + o * OP_WORDS;
-            if (op[OP_TYPE] && x >= op[OP_XL] && x < op[OP_XR] && y + VEC > op[OP_YU] && y < op[OP_YD])
-              cw[k] = load_bytes<VEC>(code_e + (size_t)op[OP_SRC] * S * S + (size_t)(x - op[OP_XL]) * S + (y - (op[OP_YU] & ~3)));
-          }
+      // ordered clamp/add chain over the ops 0..k covering my cells (mappings.py:80-124 in log-odds)
+      for (int o = 0; o <= k; ++o) {
+        const int4 oa = s_ops[o][0], ob = s_ops[o][1];
+        const int yu = oa.w, yd = ob.x;
+        if (!(x >= ob.y && x < ob.z && y + VEC > yu && y < yd)) continue;
+        uint32_t cw = 0;
+        float lm0 = 0.f, lm1 = 0.f;
+        if (oa.x) {
+          cw = load_bytes<VEC>(code_e + (size_t)oa.y * S * S + (size_t)(x - ob.y) * S + (y - (yu & ~3)));
+          lm0 = c->logit_meas[oa.z][0];
+          lm1 = c->logit_meas[oa.z][1];
         }
-        // pass 2: the ordered clamp/add chain (mappings.py:80-124 in log-odds)
 #pragma unroll
-        for (int k = 0; k < APPLY_CH; ++k) {
-          const int o = o0 + k;
-          if (o < nops) {
-            const int32_t* op = ops + o * OP_WORDS;
-            if (x >= op[OP_XL] && x < op[OP_XR]) {
-              const int type = op[OP_TYPE], yu = op[OP_YU], yd = op[OP_YD];
-              const float lm0 = c->logit_meas[op[OP_ALT]][0], lm1 = c->logit_meas[op[OP_ALT]][1];
-#pragma unroll
-              for (int q = 0; q < VEC; ++q) {
-                const int yy = y + q;
-                if (yy >= yu && yy < yd) {
-                  // every op of the reference clips its input over the whole grid (mappings.py:110-111)
-                  float l = ippm_clampl(L[q], lc);
-                  if (type) { l += ((cw[k] >> (8 * q)) & 1u) ? lm1 : lm0; fused[q] = true; }
-                  L[q] = l;
-                  lastt[q] = o;
-                  ++opcells;
-                }
-              }
-            }
+        for (int q = 0; q < VEC; ++q) {
+          const int yy = y + q;
+          if (yy >= yu && yy < yd) {
+            // every op of the reference clips its input over the whole grid (mappings.py:110-111)
+            float l = ippm_clampl(L[q], lc);
+            if (oa.x) { l += ((cw >> (8 * q)) & 1u) ? lm1 : lm0; fused[q] = true; }
+            L[q] = l;
+            lastt[q] = o;
+            ++opcells;
           }
         }
       }
@@ -477,9 +475,9 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
     if (threadIdx.x < 5) {
       const float t = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
       if (threadIdx.x < 3) {
-        if (REWARD) atomicAdd(&sums[(size_t)e * 8 + SUM_ACC1 + threadIdx.x], (double)t);
+        if (REWARD && t != 0.f) atomicAdd(&sums[(size_t)e * 8 + SUM_ACC1 + threadIdx.x], (double)t);
       } else if (counters && t > 0.f) {
-        const int cslot = (blockIdx.y * gridDim.x + blockIdx.x) & (IPPM_COUNTER_SLOTS - 1);
+        const int cslot = blockIdx.x & (IPPM_COUNTER_SLOTS - 1);
         atomicAdd(&counters[cslot * 8 + (REWARD ? 3 : 1) + (threadIdx.x - 3)], (unsigned long long)t);
       }
     }
@@ -724,11 +722,12 @@ extern "C" int ippm_sense_update(ippm_ctx* ctx, const int64_t* episode, const in
   if (!flips && !episode) { ippm_set_error("ippm_sense_update: Philox flips need the episode ids"); return -1; }
   if (agent_sel >= ctx->cfg.n_agents) { ippm_set_error("ippm_sense_update: agent_sel out of range"); return -1; }
   const int maps = agent_sel >= 0 ? n_envs : n_envs * ctx->cfg.n_agents;
-  dim3 grid(env_int("IPPM_SPLIT_K3", 2), maps), block(256);
+  const int split = std::max(1, env_int("IPPM_SPLIT_K3", 2));
+  dim3 grid((unsigned)maps * split), block(256);
   const int unr = env_int("IPPM_UNROLL_K3", 2);
 #define IPPM_K3_LAUNCH(V, U)                                                                                              \
   hipLaunchKernelGGL((k_sense_update<V, U>), grid, block, 0, S_(stream), ctx->dcfg, episode, pos, truth, local, flips, code, \
-                     rect, ws, ctx->dcounters, stage, agent_sel)
+                     rect, ws, ctx->dcounters, stage, agent_sel, split)
   if (ctx->vec == 4) {
     if (unr >= 4) IPPM_K3_LAUNCH(4, 4);
     else if (unr >= 2) IPPM_K3_LAUNCH(4, 2);
@@ -757,11 +756,12 @@ extern "C" int ippm_fuse_local(ippm_ctx* ctx, float* local, const uint8_t* code,
   const int maps = n_envs * ctx->cfg.n_agents;
   hipLaunchKernelGGL(k_plan, dim3(grid1(maps, 64)), dim3(64), 0, S_(stream), ctx->dcfg, rect, pos, comm, ws, 0, n_envs);
   IPPM_LAUNCH_CHECK("plan_local");
-  dim3 grid(env_int("IPPM_SPLIT_K4", 8), maps), block(256);
+  const int split = std::max(1, env_int("IPPM_SPLIT_K4", 2));
+  dim3 grid((unsigned)maps * split, ctx->cfg.n_agents + 1), block(256);
   if (ctx->vec == 4)
-    hipLaunchKernelGGL((k_apply_ops<4, false>), grid, block, 0, S_(stream), ctx->dcfg, local, code, ws, ws, nullptr, ctx->dcounters);
+    hipLaunchKernelGGL((k_apply_ops<4, false>), grid, block, 0, S_(stream), ctx->dcfg, local, code, ws, ws, nullptr, ctx->dcounters, split);
   else
-    hipLaunchKernelGGL((k_apply_ops<1, false>), grid, block, 0, S_(stream), ctx->dcfg, local, code, ws, ws, nullptr, ctx->dcounters);
+    hipLaunchKernelGGL((k_apply_ops<1, false>), grid, block, 0, S_(stream), ctx->dcfg, local, code, ws, ws, nullptr, ctx->dcounters, split);
   IPPM_LAUNCH_CHECK("fuse_local");
   return 0;
 }
@@ -775,11 +775,12 @@ extern "C" int ippm_fuse_global_reward(ippm_ctx* ctx, float* global, const uint8
   }
   hipLaunchKernelGGL(k_plan, dim3(grid1(n_envs, 64)), dim3(64), 0, S_(stream), ctx->dcfg, rect, pos, nullptr, ws, 1, n_envs);
   IPPM_LAUNCH_CHECK("plan_global");
-  dim3 grid(env_int("IPPM_SPLIT_K5", 16), n_envs), block(256);
+  const int split = std::max(1, env_int("IPPM_SPLIT_K5", 2));
+  dim3 grid((unsigned)n_envs * split, ctx->cfg.n_agents + 1), block(256);
   if (ctx->vec == 4)
-    hipLaunchKernelGGL((k_apply_ops<4, true>), grid, block, 0, S_(stream), ctx->dcfg, global, code, ws, ws, sums, ctx->dcounters);
+    hipLaunchKernelGGL((k_apply_ops<4, true>), grid, block, 0, S_(stream), ctx->dcfg, global, code, ws, ws, sums, ctx->dcounters, split);
   else
-    hipLaunchKernelGGL((k_apply_ops<1, true>), grid, block, 0, S_(stream), ctx->dcfg, global, code, ws, ws, sums, ctx->dcounters);
+    hipLaunchKernelGGL((k_apply_ops<1, true>), grid, block, 0, S_(stream), ctx->dcfg, global, code, ws, ws, sums, ctx->dcounters, split);
   IPPM_LAUNCH_CHECK("fuse_global");
   hipLaunchKernelGGL(k_reward_finalize, dim3(grid1(n_envs)), dim3(256), 0, S_(stream), ctx->dcfg, sums, reward, n_envs);
   IPPM_LAUNCH_CHECK("reward_finalize");
