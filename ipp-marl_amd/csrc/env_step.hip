@@ -112,16 +112,17 @@ struct RowGeom {
   int groups;  // VEC-wide groups per row
   int lpr;     // lanes per row (power of two <= 64)
   int rpw;     // rows per wavefront
+  int shift;   // log2(lpr)
 };
 template <int VEC>
 __device__ __forceinline__ RowGeom make_geom(int ya, int yb) {
   RowGeom g;
   g.y0 = ya & ~(VEC - 1);
   g.groups = (yb - g.y0 + VEC - 1) / VEC;
-  int l = 1;
-  while (l < g.groups && l < 64) l <<= 1;
-  g.lpr = l;
-  g.rpw = 64 / l;
+  const int gm1 = max(g.groups - 1, 0);
+  g.shift = gm1 == 0 ? 0 : min(32 - __clz(gm1), 6);
+  g.lpr = 1 << g.shift;
+  g.rpw = 64 >> g.shift;
   return g;
 }
 
@@ -192,7 +193,7 @@ k_sense_update(const ippm_config* __restrict__ c, const int64_t* __restrict__ ep
   const int rows_per_wg = (h + split - 1) / split;
   const int r0 = part * rows_per_wg, r1 = min(h, r0 + rows_per_wg);
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int sub = lane / g.lpr, gl = lane % g.lpr;
+  const int sub = lane >> g.shift, gl = lane & (g.lpr - 1);
   float* map = local + (size_t)(e * n + i) * gx * gy;
   const uint8_t* tr = truth + (size_t)e * gx * gy;
   uint8_t* cd = code + (size_t)(e * n + i) * S * S;
@@ -229,22 +230,21 @@ k_sense_update(const ippm_config* __restrict__ c, const int64_t* __restrict__ ep
         uint32_t cw = 0;
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
-          const int yy = y + q;
-          if (yy >= yu && yy < yd) {
-            uint32_t flip;
-            if (fl) flip = (fw[u] >> (8 * q)) & 1u;
-            else if (VEC == 4) flip = ph.v[q] < thr ? 1u : 0u;
-            else {
-              Philox4 p1 = ippm_philox((uint32_t)((cell + q) >> 2), (uint32_t)ep, sw, (uint32_t)(ep >> 32), k0, k1);
-              flip = p1.v[(cell + q) & 3] < thr ? 1u : 0u;
-            }
-            const uint32_t obs = ((tw[u] >> (8 * q)) & 1u) ^ flip;
-            // mappings.py:109-124 in log-odds: clip the prior belief, add the measurement's log-odds
-            const float l = ippm_clampl(m[u].v[q], lc) + (obs ? lm1 : lm0);
-            exceed |= fabsf(l) > lc;
-            m[u].v[q] = l;
-            cw |= obs << (8 * q);
+          // branch-free: cells of an edge group that lie outside the footprint keep their value
+          const bool in = (unsigned)(y + q - yu) < (unsigned)w;
+          uint32_t flip;
+          if (fl) flip = (fw[u] >> (8 * q)) & 1u;
+          else if (VEC == 4) flip = ph.v[q] < thr ? 1u : 0u;
+          else {
+            Philox4 p1 = ippm_philox((uint32_t)((cell + q) >> 2), (uint32_t)ep, sw, (uint32_t)(ep >> 32), k0, k1);
+            flip = p1.v[(cell + q) & 3] < thr ? 1u : 0u;
           }
+          const uint32_t obs = ((tw[u] >> (8 * q)) & 1u) ^ flip;
+          // mappings.py:109-124 in log-odds: clip the prior belief, add the measurement's log-odds
+          const float l = ippm_clampl(m[u].v[q], lc) + (obs ? lm1 : lm0);
+          exceed |= in & (fabsf(l) > lc);
+          m[u].v[q] = in ? l : m[u].v[q];
+          cw |= (in ? obs : 0u) << (8 * q);
         }
         store_cells<VEC>(map + cell, m[u]);
         store_bytes<VEC>(cd + (size_t)rr * S + (y - tile_y0), cw);
@@ -396,7 +396,7 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
   const int rows_per_wg = (rows + split - 1) / split;
   const int r0 = part * rows_per_wg, r1 = min(rows, r0 + rows_per_wg);
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int sub = lane / g.lpr, gl = lane % g.lpr;
+  const int sub = lane >> g.shift, gl = lane & (g.lpr - 1);
   float* map = maps + (size_t)m * gx * gy;
   const uint8_t* code_e = code + (size_t)e * n * S * S;
   bool exceed = false;
@@ -420,46 +420,45 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
       bool fused[VEC];
 #pragma unroll
       for (int q = 0; q < VEC; ++q) { L[q] = mv.v[q]; lastt[q] = -1; fused[q] = false; }
-      // ordered clamp/add chain over the ops 0..k covering my cells (mappings.py:80-124 in log-odds)
+      // ordered clamp/add chain over the ops 0..k covering my cells (mappings.py:80-124 in log-odds);
+      // per-cell logic is select-based (divergent branches cost scalar exec-mask work on every op)
       for (int o = 0; o <= k; ++o) {
         const int4 oa = s_ops[o][0], ob = s_ops[o][1];
-        const int yu = oa.w, yd = ob.x;
-        if (!(x >= ob.y && x < ob.z && y + VEC > yu && y < yd)) continue;
+        const int yu = oa.w, wdt = ob.x - oa.w;
+        const bool rowin = (unsigned)(x - ob.y) < (unsigned)(ob.z - ob.y);
+        const bool cov = rowin && (y + VEC > yu) && (y < ob.x);
+        const bool isf = oa.x != 0;
         uint32_t cw = 0;
-        float lm0 = 0.f, lm1 = 0.f;
-        if (oa.x) {
-          cw = load_bytes<VEC>(code_e + (size_t)oa.y * S * S + (size_t)(x - ob.y) * S + (y - (yu & ~3)));
-          lm0 = c->logit_meas[oa.z][0];
-          lm1 = c->logit_meas[oa.z][1];
-        }
+        if (cov && isf) cw = load_bytes<VEC>(code_e + (size_t)oa.y * S * S + (size_t)(x - ob.y) * S + (y - (yu & ~3)));
+        const float lm0 = isf ? c->logit_meas[oa.z][0] : 0.f, lm1 = isf ? c->logit_meas[oa.z][1] : 0.f;
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
-          const int yy = y + q;
-          if (yy >= yu && yy < yd) {
-            // every op of the reference clips its input over the whole grid (mappings.py:110-111)
-            float l = ippm_clampl(L[q], lc);
-            if (oa.x) { l += ((cw >> (8 * q)) & 1u) ? lm1 : lm0; fused[q] = true; }
-            L[q] = l;
-            lastt[q] = o;
-            ++opcells;
-          }
+          const bool in = cov && ((unsigned)(y + q - yu) < (unsigned)wdt);
+          // every op of the reference clips its input over the whole grid (mappings.py:110-111)
+          const float l = ippm_clampl(L[q], lc) + (((cw >> (8 * q)) & 1u) ? lm1 : lm0);
+          L[q] = in ? l : L[q];
+          lastt[q] = in ? o : lastt[q];
+          fused[q] |= in && isf;
+          opcells += in ? 1u : 0u;
         }
       }
 #pragma unroll
       for (int q = 0; q < VEC; ++q) {
-        if (lastt[q] < 0) continue;
-        ++cells;
+        const bool touched = lastt[q] >= 0;
+        cells += touched ? 1u : 0u;
         const float b = mv.v[q];
         float a = L[q];
-        if (lastt[q] != last_op) a = ippm_clampl(a, lc);        // a later op clips the whole grid again
-        exceed |= fabsf(a) > lc;
+        a = (lastt[q] != last_op) ? ippm_clampl(a, lc) : a;     // a later op clips the whole grid again
+        a = touched ? a : b;
+        exceed |= fabsf(a) > lc && touched;
         mv.v[q] = a;
-        if (REWARD && fused[q]) {
+        if (REWARD) {
+          const float sel = fused[q] ? 1.f : 0.f;
           const float wa = ippm_weight_l(a, wt), wb = ippm_weight_l(b, wt);
           const float hb = ippm_entropy_l(b, lc), ha = ippm_entropy_l(a, lc);
-          a1 += wa * (hb - ha);
-          aD += (wa - wb) * hb;
-          aT += wa * ha - wb * hb;
+          a1 += sel * (wa * (hb - ha));
+          aD += sel * ((wa - wb) * hb);
+          aT += sel * (wa * ha - wb * hb);
         }
       }
       store_cells<VEC>(map + cell, mv);
