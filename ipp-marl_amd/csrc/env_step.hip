@@ -8,6 +8,7 @@
 //   - every map cell is read and written at most once per kernel, whatever the number of fused measurements.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "ippm_internal.h"
 
@@ -365,11 +366,20 @@ __global__ void k_plan(const ippm_config* __restrict__ c, const int32_t* __restr
 // rectangle (dense lanes, like K3) and own every 4-cell group that no later op touches; an owned group gets the
 // complete ordered chain of all ops covering each of its cells.  Every group of the union is therefore read
 // and written exactly once, by exactly one workgroup, whatever the overlap pattern.
-template <int VEC, bool REWARD>
+//
+// A lane keeps its column group while it walks down the rows, so everything that depends on columns only (which
+// cells of the group each op covers) is folded into a few bit masks once per column chunk; per row only the
+// row-range tests remain.  NK = ops held in registers (scalar loads, fully unrolled).
+struct OpRec {
+  int info;  // type | src << 8 | alt << 16
+  int yu, yd, xl, xr;
+};
+
+template <int VEC, bool REWARD, int NK>
 __global__ void __launch_bounds__(256)
 k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const uint8_t* __restrict__ code,
             const int32_t* __restrict__ plan_ro, int32_t* __restrict__ ws, double* __restrict__ sums,
-            unsigned long long* __restrict__ counters, int split) {
+            unsigned long long* __restrict__ counters, int split, int min_ops) {
   const int n = c->n_agents;
   const int m = blockIdx.x / split, part = blockIdx.x % split;  // map index: (e,i) for local maps, e for global maps
   const int k = blockIdx.y;  // op whose rectangle this workgroup walks
@@ -378,19 +388,24 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
   const size_t wbase = (size_t)(e * (n + 1) + slot) * IPPM_WS_WORDS;
   const int32_t* __restrict__ hdr = plan_ro + wbase + WS_PLAN;
   const int nops = hdr[PL_NOPS];
-  if (k >= nops) return;
-  __shared__ int4 s_ops[IPPM_MAX_OPS][2];  // {type, src, alt, yu}, {yd, xl, xr, -}
+  if (k >= nops || nops > NK || nops < min_ops) return;  // (another instantiation handles other plan sizes)
   __shared__ float s_red[4][6];
-  if (threadIdx.x < nops * 2) {
-    const int32_t* op = plan_ro + wbase + WS_OPS + (threadIdx.x >> 1) * OP_WORDS + (threadIdx.x & 1) * 4;
-    s_ops[threadIdx.x >> 1][threadIdx.x & 1] = make_int4(op[0], op[1], op[2], op[3]);
+  OpRec op[NK];
+#pragma unroll
+  for (int o = 0; o < NK; ++o) {
+    const int32_t* p = plan_ro + wbase + WS_OPS + o * OP_WORDS;  // uniform address: scalar loads
+    const bool on = o < nops;
+    op[o].info = on ? (p[OP_TYPE] | (p[OP_SRC] << 8) | (p[OP_ALT] << 16)) : 0;
+    op[o].yu = on ? p[OP_YU] : 0; op[o].yd = on ? p[OP_YD] : 0;
+    op[o].xl = on ? p[OP_XL] : 0; op[o].xr = on ? p[OP_XR] : 0;  // empty rect: never covers
   }
-  __syncthreads();
+  int kyu = 0, kyd = 0, kxl = 0, kxr = 0;
+#pragma unroll
+  for (int o = 0; o < NK; ++o)
+    if (o == k) { kyu = op[o].yu; kyd = op[o].yd; kxl = op[o].xl; kxr = op[o].xr; }
   const int gx = c->grid_x, gy = c->grid_y, S = c->tile_stride;
-  const int last_op = hdr[PL_LAST];
+  const bool k_is_last = hdr[PL_LAST] == k;
   const float lc = c->logit_clip, wt = c->logit_weight_thr;
-  const int4 ka = s_ops[k][0], kb = s_ops[k][1];
-  const int kyu = ka.w, kyd = kb.x, kxl = kb.y, kxr = kb.z;
   const RowGeom g = make_geom<VEC>(kyu, kyd);
   const int rows = kxr - kxl;
   const int rows_per_wg = (rows + split - 1) / split;
@@ -402,58 +417,83 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
   bool exceed = false;
   float a1 = 0.f, aD = 0.f, aT = 0.f;
   unsigned cells = 0, opcells = 0;
-  for (int row = r0 + wv * g.rpw + sub; row < r1; row += 4 * g.rpw) {
-    const int x = kxl + row;
-    for (int gi = gl; gi < g.groups; gi += g.lpr) {
-      const int y = g.y0 + gi * VEC;
-      // ownership: a later op touching any cell of this group takes it over
-      bool mine = true;
-      for (int o = k + 1; o < nops; ++o) {
-        const int4 oa = s_ops[o][0], ob = s_ops[o][1];
-        mine &= !(x >= ob.y && x < ob.z && y + VEC > oa.w && y < ob.x);
-      }
-      if (!mine) continue;
-      const size_t cell = (size_t)x * gy + y;
-      CellVec<VEC> mv = load_cells<VEC>(map + cell);
-      float L[VEC];
-      int lastt[VEC];
-      bool fused[VEC];
+  using Mask = typename std::conditional<(NK * VEC > 32), unsigned long long, unsigned>::type;
+  static_assert(NK * VEC <= 64, "op masks are at most 64 bits");
+  constexpr unsigned QM = (1u << VEC) - 1u;
+  for (int gi = gl; gi < g.groups; gi += g.lpr) {
+    const int y = g.y0 + gi * VEC;
+    // column-only part: cmask holds, VEC bits per op, which cells of my group lie inside the op's column range
+    Mask cmask = 0;
 #pragma unroll
-      for (int q = 0; q < VEC; ++q) { L[q] = mv.v[q]; lastt[q] = -1; fused[q] = false; }
-      // ordered clamp/add chain over the ops 0..k covering my cells (mappings.py:80-124 in log-odds);
-      // per-cell logic is select-based (divergent branches cost scalar exec-mask work on every op)
-      for (int o = 0; o <= k; ++o) {
-        const int4 oa = s_ops[o][0], ob = s_ops[o][1];
-        const int yu = oa.w, wdt = ob.x - oa.w;
-        const bool rowin = (unsigned)(x - ob.y) < (unsigned)(ob.z - ob.y);
-        const bool cov = rowin && (y + VEC > yu) && (y < ob.x);
-        const bool isf = oa.x != 0;
-        uint32_t cw = 0;
-        if (cov && isf) cw = load_bytes<VEC>(code_e + (size_t)oa.y * S * S + (size_t)(x - ob.y) * S + (y - (yu & ~3)));
-        const float lm0 = isf ? c->logit_meas[oa.z][0] : 0.f, lm1 = isf ? c->logit_meas[oa.z][1] : 0.f;
+    for (int o = 0; o < NK; ++o) {
+      unsigned mq = 0;
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) mq |= ((unsigned)(y + q - op[o].yu) < (unsigned)(op[o].yd - op[o].yu)) ? (1u << q) : 0u;
+      cmask |= (Mask)mq << (o * VEC);
+    }
+    for (int row = r0 + wv * g.rpw + sub; row < r1; row += 4 * g.rpw) {
+      const int x = kxl + row;
+      // row part: act = cells covered by op o in this row, for all ops
+      Mask act = 0;
+#pragma unroll
+      for (int o = 0; o < NK; ++o) {
+        const bool rowin = (unsigned)(x - op[o].xl) < (unsigned)(op[o].xr - op[o].xl);
+        act |= rowin ? (cmask & ((Mask)QM << (o * VEC))) : (Mask)0;
+      }
+      // ownership: a later op touching any cell of this group takes it over
+      if (k + 1 < NK && (act >> ((k + 1) * VEC)) != 0) continue;
+      const size_t cell = (size_t)x * gy + y;
+      // issue every load of this group (map cells + the measurement codes of all covering ops) before any use
+      CellVec<VEC> mv = load_cells<VEC>(map + cell);
+      uint32_t cw[NK];
+#pragma unroll
+      for (int o = 0; o < NK; ++o) {
+        cw[o] = 0;
+        if (o <= k && (op[o].info & 0xFF) && ((unsigned)(act >> (o * VEC)) & QM))
+          cw[o] = load_bytes<VEC>(code_e + (size_t)((op[o].info >> 8) & 0xFF) * S * S + (size_t)(x - op[o].xl) * S +
+                                  (y - (op[o].yu & ~3)));
+      }
+      const CellVec<VEC> old = mv;
+      float L[VEC];
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) L[q] = mv.v[q];
+      unsigned touched = 0, fusedm = 0;
+      // ordered clamp/add chain (mappings.py:80-124 in log-odds); ops that cover no lane of the wavefront are skipped
+#pragma unroll
+      for (int o = 0; o < NK; ++o) {
+        if (o > k) break;
+        const unsigned inm = (unsigned)(act >> (o * VEC)) & QM;
+        if (!__any(inm != 0u)) continue;
+        const bool isf = (op[o].info & 0xFF) != 0;
+        const int alt = (op[o].info >> 16) & 0xFF;
+        const float lm0 = isf ? c->logit_meas[alt][0] : 0.f, lm1 = isf ? c->logit_meas[alt][1] : 0.f;
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
-          const bool in = cov && ((unsigned)(y + q - yu) < (unsigned)wdt);
           // every op of the reference clips its input over the whole grid (mappings.py:110-111)
-          const float l = ippm_clampl(L[q], lc) + (((cw >> (8 * q)) & 1u) ? lm1 : lm0);
-          L[q] = in ? l : L[q];
-          lastt[q] = in ? o : lastt[q];
-          fused[q] |= in && isf;
-          opcells += in ? 1u : 0u;
+          const float l = ippm_clampl(L[q], lc) + (((cw[o] >> (8 * q)) & 1u) ? lm1 : lm0);
+          L[q] = ((inm >> q) & 1u) ? l : L[q];
         }
+        touched |= inm;
+        fusedm |= isf ? inm : 0u;
+        opcells += __popc(inm);
       }
+      cells += __popc(touched);
+      // outputs of the plan's last op stay unclamped; every other cell was clipped again by a later full-grid op
+      const unsigned keep = k_is_last ? ((unsigned)(act >> (k * VEC)) & QM) : 0u;
 #pragma unroll
       for (int q = 0; q < VEC; ++q) {
-        const bool touched = lastt[q] >= 0;
-        cells += touched ? 1u : 0u;
         const float b = mv.v[q];
-        float a = L[q];
-        a = (lastt[q] != last_op) ? ippm_clampl(a, lc) : a;     // a later op clips the whole grid again
-        a = touched ? a : b;
-        exceed |= fabsf(a) > lc && touched;
+        float a = ((keep >> q) & 1u) ? L[q] : ippm_clampl(L[q], lc);
+        a = ((touched >> q) & 1u) ? a : b;
+        exceed |= fabsf(a) > lc && ((touched >> q) & 1u);
         mv.v[q] = a;
-        if (REWARD) {
-          const float sel = fused[q] ? 1.f : 0.f;
+      }
+      if (REWARD && __any(fusedm != 0)) {
+        // information-gain terms of the cells that received a measurement (utils/reward.py:68-82)
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+          const float sel = ((fusedm >> q) & 1u) ? 1.f : 0.f;
+          const float b = old.v[q], a = mv.v[q];
           const float wa = ippm_weight_l(a, wt), wb = ippm_weight_l(b, wt);
           const float hb = ippm_entropy_l(b, lc), ha = ippm_entropy_l(a, lc);
           a1 += sel * (wa * (hb - ha));
@@ -466,6 +506,115 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
   }
   if (__any(exceed) && lane == 0) ws[wbase + WS_FLAG_A] = 1;
   // block reduction of the reward terms and work counters: one atomic per workgroup and quantity
+  {
+    const float fc = ippm_wave_sum((float)cells), fo = ippm_wave_sum((float)opcells);
+    if (REWARD) { a1 = ippm_wave_sum(a1); aD = ippm_wave_sum(aD); aT = ippm_wave_sum(aT); }
+    if (lane == 0) { s_red[wv][0] = a1; s_red[wv][1] = aD; s_red[wv][2] = aT; s_red[wv][3] = fc; s_red[wv][4] = fo; }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+      const float t = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
+      if (threadIdx.x < 3) {
+        if (REWARD && t != 0.f) atomicAdd(&sums[(size_t)e * 8 + SUM_ACC1 + threadIdx.x], (double)t);
+      } else if (counters && t > 0.f) {
+        const int cslot = blockIdx.x & (IPPM_COUNTER_SLOTS - 1);
+        atomicAdd(&counters[cslot * 8 + (REWARD ? 3 : 1) + (threadIdx.x - 3)], (unsigned long long)t);
+      }
+    }
+  }
+}
+
+// Fallback for plans with more than 10 ops (more than 8 agents): walks the bounding hull of the plan with the op
+// table in LDS.  Same per-cell semantics, no attempt at speed.
+template <int VEC, bool REWARD>
+__global__ void __launch_bounds__(256)
+k_apply_ops_generic(const ippm_config* __restrict__ c, float* __restrict__ maps, const uint8_t* __restrict__ code,
+                    int32_t* __restrict__ ws, double* __restrict__ sums, unsigned long long* __restrict__ counters, int split,
+                    int min_ops) {
+  const int n = c->n_agents;
+  const int m = blockIdx.x / split, part = blockIdx.x % split;
+  const int e = REWARD ? m : m / n;
+  const int slot = REWARD ? n : m % n;
+  int32_t* w = ws + (size_t)(e * (n + 1) + slot) * IPPM_WS_WORDS;
+  const int32_t* hdr = w + WS_PLAN;
+  const int nops = hdr[PL_NOPS];
+  if (nops < min_ops) return;
+  __shared__ int32_t s_ops[IPPM_MAX_OPS * OP_WORDS];
+  __shared__ float s_red[4][6];
+  for (int q = threadIdx.x; q < nops * OP_WORDS; q += blockDim.x) s_ops[q] = w[WS_OPS + q];
+  __syncthreads();
+  const int gx = c->grid_x, gy = c->grid_y, S = c->tile_stride;
+  const int X0 = hdr[PL_X0], X1 = hdr[PL_X1], last_op = hdr[PL_LAST];
+  const float lc = c->logit_clip, wt = c->logit_weight_thr;
+  const RowGeom g = make_geom<VEC>(hdr[PL_Y0], hdr[PL_Y1]);
+  const int rows = X1 - X0;
+  const int rows_per_wg = (rows + split - 1) / split;
+  const int r0 = part * rows_per_wg, r1 = min(rows, r0 + rows_per_wg);
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int sub = lane >> g.shift, gl = lane & (g.lpr - 1);
+  float* map = maps + (size_t)m * gx * gy;
+  const uint8_t* code_e = code + (size_t)e * n * S * S;
+  bool exceed = false;
+  float a1 = 0.f, aD = 0.f, aT = 0.f;
+  unsigned cells = 0, opcells = 0;
+  for (int row = r0 + wv * g.rpw + sub; row < r1; row += 4 * g.rpw) {
+    const int x = X0 + row;
+    for (int gi = gl; gi < g.groups; gi += g.lpr) {
+      const int y = g.y0 + gi * VEC;
+      bool need = false;
+      for (int o = 0; o < nops; ++o) {
+        const int32_t* op = s_ops + o * OP_WORDS;
+        need |= (x >= op[OP_XL] && x < op[OP_XR] && y + VEC > op[OP_YU] && y < op[OP_YD]);
+      }
+      if (!need) continue;
+      const size_t cell = (size_t)x * gy + y;
+      CellVec<VEC> mv = load_cells<VEC>(map + cell);
+      float L[VEC];
+      int lastt[VEC];
+      bool fused[VEC];
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) { L[q] = mv.v[q]; lastt[q] = -1; fused[q] = false; }
+      for (int o = 0; o < nops; ++o) {
+        const int32_t* op = s_ops + o * OP_WORDS;
+        if (!(x >= op[OP_XL] && x < op[OP_XR] && y + VEC > op[OP_YU] && y < op[OP_YD])) continue;
+        uint32_t cw = 0;
+        float lm0 = 0.f, lm1 = 0.f;
+        if (op[OP_TYPE]) {
+          cw = load_bytes<VEC>(code_e + (size_t)op[OP_SRC] * S * S + (size_t)(x - op[OP_XL]) * S + (y - (op[OP_YU] & ~3)));
+          lm0 = c->logit_meas[op[OP_ALT]][0];
+          lm1 = c->logit_meas[op[OP_ALT]][1];
+        }
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+          const int yy = y + q;
+          if (yy >= op[OP_YU] && yy < op[OP_YD]) {
+            L[q] = ippm_clampl(L[q], lc);
+            if (op[OP_TYPE]) { L[q] += ((cw >> (8 * q)) & 1u) ? lm1 : lm0; fused[q] = true; }
+            lastt[q] = o;
+            ++opcells;
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) {
+        if (lastt[q] < 0) continue;
+        ++cells;
+        const float b = mv.v[q];
+        float a = L[q];
+        if (lastt[q] != last_op) a = ippm_clampl(a, lc);
+        exceed |= fabsf(a) > lc;
+        mv.v[q] = a;
+        if (REWARD && fused[q]) {
+          const float wa = ippm_weight_l(a, wt), wb = ippm_weight_l(b, wt);
+          const float hb = ippm_entropy_l(b, lc), ha = ippm_entropy_l(a, lc);
+          a1 += wa * (hb - ha);
+          aD += (wa - wb) * hb;
+          aT += wa * ha - wb * hb;
+        }
+      }
+      store_cells<VEC>(map + cell, mv);
+    }
+  }
+  if (__any(exceed) && lane == 0) w[WS_FLAG_A] = 1;
   {
     const float fc = ippm_wave_sum((float)cells), fo = ippm_wave_sum((float)opcells);
     if (REWARD) { a1 = ippm_wave_sum(a1); aD = ippm_wave_sum(aD); aT = ippm_wave_sum(aT); }
@@ -749,18 +898,39 @@ extern "C" int ippm_comm_matrix(ippm_ctx* ctx, const int64_t* episode, const int
   return 0;
 }
 
+// The three instantiations share one plan: <= 6 ops and 7..10 ops take the register paths (workgroup column per
+// op), larger plans the generic path.  Each launch returns immediately for plans it does not own.
+template <bool REWARD>
+static void launch_apply(ippm_ctx* ctx, float* maps, const uint8_t* code, int32_t* ws, double* sums, int n_maps, int split,
+                         hipStream_t st) {
+  const int max_ops = ctx->cfg.n_agents + 1;
+  dim3 block(256);
+#define IPPM_APPLY(V, NK, MINOPS)                                                                                      \
+  hipLaunchKernelGGL((k_apply_ops<V, REWARD, NK>), dim3((unsigned)n_maps* split, std::min(max_ops, NK)), block, 0, st, \
+                     ctx->dcfg, maps, code, ws, ws, sums, ctx->dcounters, split, MINOPS)
+  if (ctx->vec == 4) {
+    IPPM_APPLY(4, 6, 1);
+    if (max_ops > 6) IPPM_APPLY(4, 10, 7);
+    if (max_ops > 10)
+      hipLaunchKernelGGL((k_apply_ops_generic<4, REWARD>), dim3((unsigned)n_maps * 8), block, 0, st, ctx->dcfg, maps, code, ws,
+                         sums, ctx->dcounters, 8, 11);
+  } else {
+    IPPM_APPLY(1, 6, 1);
+    if (max_ops > 6) IPPM_APPLY(1, 10, 7);
+    if (max_ops > 10)
+      hipLaunchKernelGGL((k_apply_ops_generic<1, REWARD>), dim3((unsigned)n_maps * 8), block, 0, st, ctx->dcfg, maps, code, ws,
+                         sums, ctx->dcounters, 8, 11);
+  }
+#undef IPPM_APPLY
+}
+
 extern "C" int ippm_fuse_local(ippm_ctx* ctx, float* local, const uint8_t* code, const int32_t* rect, const int32_t* pos,
                                const uint8_t* comm, int32_t* ws, int32_t n_envs, void* stream) {
   if (!ctx || !local || !code || !rect || !pos || !comm || !ws) { ippm_set_error("ippm_fuse_local: null argument"); return -1; }
   const int maps = n_envs * ctx->cfg.n_agents;
   hipLaunchKernelGGL(k_plan, dim3(grid1(maps, 64)), dim3(64), 0, S_(stream), ctx->dcfg, rect, pos, comm, ws, 0, n_envs);
   IPPM_LAUNCH_CHECK("plan_local");
-  const int split = std::max(1, env_int("IPPM_SPLIT_K4", 2));
-  dim3 grid((unsigned)maps * split, ctx->cfg.n_agents + 1), block(256);
-  if (ctx->vec == 4)
-    hipLaunchKernelGGL((k_apply_ops<4, false>), grid, block, 0, S_(stream), ctx->dcfg, local, code, ws, ws, nullptr, ctx->dcounters, split);
-  else
-    hipLaunchKernelGGL((k_apply_ops<1, false>), grid, block, 0, S_(stream), ctx->dcfg, local, code, ws, ws, nullptr, ctx->dcounters, split);
+  launch_apply<false>(ctx, local, code, ws, nullptr, maps, std::max(1, env_int("IPPM_SPLIT_K4", 2)), S_(stream));
   IPPM_LAUNCH_CHECK("fuse_local");
   return 0;
 }
@@ -774,12 +944,7 @@ extern "C" int ippm_fuse_global_reward(ippm_ctx* ctx, float* global, const uint8
   }
   hipLaunchKernelGGL(k_plan, dim3(grid1(n_envs, 64)), dim3(64), 0, S_(stream), ctx->dcfg, rect, pos, nullptr, ws, 1, n_envs);
   IPPM_LAUNCH_CHECK("plan_global");
-  const int split = std::max(1, env_int("IPPM_SPLIT_K5", 2));
-  dim3 grid((unsigned)n_envs * split, ctx->cfg.n_agents + 1), block(256);
-  if (ctx->vec == 4)
-    hipLaunchKernelGGL((k_apply_ops<4, true>), grid, block, 0, S_(stream), ctx->dcfg, global, code, ws, ws, sums, ctx->dcounters, split);
-  else
-    hipLaunchKernelGGL((k_apply_ops<1, true>), grid, block, 0, S_(stream), ctx->dcfg, global, code, ws, ws, sums, ctx->dcounters, split);
+  launch_apply<true>(ctx, global, code, ws, sums, n_envs, std::max(1, env_int("IPPM_SPLIT_K5", 2)), S_(stream));
   IPPM_LAUNCH_CHECK("fuse_global");
   hipLaunchKernelGGL(k_reward_finalize, dim3(grid1(n_envs)), dim3(256), 0, S_(stream), ctx->dcfg, sums, reward, n_envs);
   IPPM_LAUNCH_CHECK("reward_finalize");
