@@ -91,11 +91,11 @@ __device__ __forceinline__ float ippm_logit(float x) { return __logf(x * __built
 // Shannon entropy in bits of p = sigmoid(clamp(L)) (utils/state.py:118-121), symmetric in the sign of L;
 // the small side q = e/(1+e) keeps full relative precision
 __device__ __forceinline__ float ippm_entropy_l(float l, float lc) {
+  // with a = min(|L|, lc), e = exp(-a), q = e/(1+e):  H = log2(1+e) + a*log2(e_)*q   (3 transcendentals)
   const float a = fminf(fabsf(l), lc);
   const float e = __expf(-a);
-  const float big = __builtin_amdgcn_rcpf(1.0f + e);
-  const float small = e * big;
-  return -big * __log2f(big) - small * __log2f(small);
+  const float d = 1.0f + e;
+  return __log2f(d) + (a * 1.44269504f) * (e * __builtin_amdgcn_rcpf(d));
 }
 // entropy of a probability (used on the 11x11 resized planes)
 __device__ __forceinline__ float ippm_entropy(float p, float lo, float hi) {
