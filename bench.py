@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--agents", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-events", type=int, default=1, help="time every K3 launch with HIP events (roofline)")
+    ap.add_argument("--calib", action="store_true", help="PMC calibration: 3 device-to-device clones of the local maps (known "
+                    "bytes read and written by a 16 B/lane streaming kernel) before the timed loop")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -130,6 +132,10 @@ def main():
         env.steps(t, policy=POLICY_UNIFORM, features=False)
 
     reset()
+    if args.calib:
+        for _ in range(3):
+            env.local.clone()
+        torch.cuda.synchronize()
     t_in_ep = 0
     for _ in range(args.warmup):
         one_step(t_in_ep, False)
@@ -164,11 +170,19 @@ def main():
     k3_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) if ev_pairs else None
     sense_cells_step = counters["sense_cells"]
     roofline = None
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    if os.path.isfile(pmc_file):  # produced by tools/pmc_summary.py from separate rocprofv3 --pmc passes of this command
+        with open(pmc_file) as f:
+            pmc = json.load(f)
+        if pmc.get("envs_per_gpu") == E and pmc.get("n_agents") == N:
+            traffic = pmc.get("k_sense_update", {}).get("hbm_bytes_per_launch")
     if k3_ms:
         achieved = K3_BYTES_PER_CELL * sense_cells_step / (k3_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": "k_sense_update (K3: sense + Bayes update of the footprint tile)",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": None, "algorithmic_bytes_per_cell": K3_BYTES_PER_CELL,
+                    "traffic": traffic, "algorithmic_bytes_per_launch": K3_BYTES_PER_CELL * sense_cells_step / max(len(ev_pairs), 1),
+                    "algorithmic_bytes_per_cell": K3_BYTES_PER_CELL,
                     "cells_per_launch": sense_cells_step / max(len(ev_pairs), 1),
                     "avg_launch_us": 1e3 * k3_ms / len(ev_pairs), "launches": len(ev_pairs)}
 

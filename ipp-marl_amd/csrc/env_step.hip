@@ -930,7 +930,7 @@ extern "C" int ippm_fuse_local(ippm_ctx* ctx, float* local, const uint8_t* code,
   const int maps = n_envs * ctx->cfg.n_agents;
   hipLaunchKernelGGL(k_plan, dim3(grid1(maps, 64)), dim3(64), 0, S_(stream), ctx->dcfg, rect, pos, comm, ws, 0, n_envs);
   IPPM_LAUNCH_CHECK("plan_local");
-  launch_apply<false>(ctx, local, code, ws, nullptr, maps, std::max(1, env_int("IPPM_SPLIT_K4", 2)), S_(stream));
+  launch_apply<false>(ctx, local, code, ws, nullptr, maps, std::max(1, env_int("IPPM_SPLIT_K4", 1)), S_(stream));
   IPPM_LAUNCH_CHECK("fuse_local");
   return 0;
 }
@@ -944,7 +944,7 @@ extern "C" int ippm_fuse_global_reward(ippm_ctx* ctx, float* global, const uint8
   }
   hipLaunchKernelGGL(k_plan, dim3(grid1(n_envs, 64)), dim3(64), 0, S_(stream), ctx->dcfg, rect, pos, nullptr, ws, 1, n_envs);
   IPPM_LAUNCH_CHECK("plan_global");
-  launch_apply<true>(ctx, global, code, ws, sums, n_envs, std::max(1, env_int("IPPM_SPLIT_K5", 2)), S_(stream));
+  launch_apply<true>(ctx, global, code, ws, sums, n_envs, std::max(1, env_int("IPPM_SPLIT_K5", 1)), S_(stream));
   IPPM_LAUNCH_CHECK("fuse_global");
   hipLaunchKernelGGL(k_reward_finalize, dim3(grid1(n_envs)), dim3(256), 0, S_(stream), ctx->dcfg, sums, reward, n_envs);
   IPPM_LAUNCH_CHECK("reward_finalize");

@@ -1,0 +1,64 @@
+#!/usr/bin/env python
+"""Turns rocprofv3 output (kernel-trace --stats CSV + separate --pmc passes for FETCH_SIZE and WRITE_SIZE) of
+`bench.py --calib` into profiles/pmc_summary.json and a short text table.
+
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE are reported in KiB-units
+of 64-B requests; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x.  Instead of assuming the factor, both
+counters are calibrated on a kernel with known traffic captured in the same run: the device-to-device clone of the
+local-map tensor (reads and writes exactly its size with 16 B/lane accesses).
+
+    python tools/pmc_summary.py <fetch_dir> <write_dir> <stats_dir> <n_envs> <n_agents> <grid> [out.json]
+"""
+import json
+import sys
+
+import pandas as pd
+
+
+def per_kernel(directory, counter):
+    c = pd.read_csv(f"{directory}/p_counter_collection.csv")
+    c = c[c["Counter_Name"] == counter]
+    g = c.groupby("Kernel_Name")["Counter_Value"].agg(["mean", "count"])
+    return g
+
+
+def main():
+    fetch_dir, write_dir, stats_dir, n_envs, n_agents, grid = sys.argv[1:7]
+    out_path = sys.argv[7] if len(sys.argv) > 7 else "profiles/pmc_summary.json"
+    n_envs, n_agents, grid = int(n_envs), int(n_agents), int(grid)
+    clone_bytes = n_envs * n_agents * grid * grid * 4
+    fetch = per_kernel(fetch_dir, "FETCH_SIZE")
+    write = per_kernel(write_dir, "WRITE_SIZE")
+
+    def pick(df, pat):
+        rows = df[df.index.str.contains(pat, regex=False)]
+        return rows.sort_values("count", ascending=False).iloc[0] if len(rows) else None
+
+    # calibration kernel: torch's copy of a float tensor (largest elementwise copy in the trace)
+    cal_f = fetch[fetch.index.str.contains("copy", case=False)].sort_values("mean", ascending=False).iloc[0]
+    cal_w = write[write.index.str.contains("copy", case=False)].sort_values("mean", ascending=False).iloc[0]
+    f_scale = clone_bytes / (cal_f["mean"] * 1024.0)  # bytes per reported KiB-unit
+    w_scale = clone_bytes / (cal_w["mean"] * 1024.0)
+    summary = {"envs_per_gpu": n_envs, "n_agents": n_agents, "grid": grid, "calibration": {
+        "kernel": "torch clone of the local maps", "bytes": clone_bytes, "FETCH_SIZE_reported_KiB": float(cal_f["mean"]),
+        "WRITE_SIZE_reported_KiB": float(cal_w["mean"]), "fetch_correction": f_scale, "write_correction": w_scale}}
+    trace = pd.read_csv(f"{stats_dir}/p_kernel_trace.csv")
+    trace["dur_us"] = (trace["End_Timestamp"] - trace["Start_Timestamp"]) / 1e3
+    for key, pat in (("k_sense_update", "k_sense_update"), ("k_apply_ops_local", "k_apply_ops<4, false, 6>"),
+                     ("k_apply_ops_global", "k_apply_ops<4, true, 6>")):
+        f, w = pick(fetch, pat), pick(write, pat)
+        t = trace[trace["Kernel_Name"].str.contains(pat, regex=False)]["dur_us"]
+        if f is None or w is None:
+            continue
+        rd = float(f["mean"]) * 1024.0 * f_scale
+        wr = float(w["mean"]) * 1024.0 * w_scale
+        summary[key] = {"launches": int(f["count"]), "avg_us": float(t.mean()), "hbm_read_bytes_per_launch": rd,
+                        "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
+                        "hbm_GBps": (rd + wr) / (float(t.mean()) * 1e-6) / 1e9}
+    with open(out_path, "w") as fh:
+        json.dump(summary, fh, indent=1)
+    print(json.dumps(summary, indent=1))
+
+
+if __name__ == "__main__":
+    main()
