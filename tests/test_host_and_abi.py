@@ -1,0 +1,142 @@
+"""CPU-only checks of the product's host side: derived constants against the reference's golden vectors, the
+C-ABI library (loads, exports every symbol of include/ippmarl.h, struct mirror), and the host-callable mirrors
+of the device's integer streams (MT19937 start states / truth parameters, Philox, area-resize weights)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import ipp_oracle as O
+from configs import make_params
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _derived(name, **over):
+    from ippmarl.derived import DerivedConstants
+    return DerivedConstants(make_params(name, **over))
+
+
+@pytest.mark.parametrize("name", ["default", "small", "c2", "c4", "c5"])
+def test_derived_constants_match_reference(golden, name):
+    fx = golden("derived_footprints")
+    d = _derived(name)
+    assert [d.res_x, d.res_y] == list(fx[f"{name}_res"])
+    assert [d.grid_x, d.grid_y] == list(fx[f"{name}_dims"])
+    assert [d.space_x, d.space_y, d.space_z] == list(fx[f"{name}_space"])
+    full, clip = [], []
+    for x in range(d.space_x):
+        for y in range(d.space_y):
+            for z in range(d.space_z):
+                f, c = d.footprint(d.index_to_position([x, y, z]))
+                full.append(f), clip.append(c)
+    assert np.array_equal(np.array(full), fx[f"{name}_fp_full"])  # integer tables reproduce the float64 knife edges
+    assert np.array_equal(np.array(clip), fx[f"{name}_fp_clip"])
+    assert d.tile_stride % 4 == 0 and d.tile_stride >= 2 * max(d.radius_y) + 3
+
+
+def test_measurement_tables_match_reference_arithmetic(golden):
+    d = _derived("c2")
+    fx = golden("bayes_measurement")
+    for k, alt in enumerate((5, 10, 15)):
+        vals = np.unique(fx[f"meas_out_{alt}"])
+        assert list(vals) == sorted(d.meas_value[k])          # float32 values the reference produces
+        y = np.float32(vals)
+        np.testing.assert_array_equal(np.sort(d.logit_meas[k]), np.log(y / (1 - y)))  # float32 logits, same ops
+        assert int(d.flip_threshold[k]) == O.philox_flip_threshold(O.noise_of_altitude(alt))
+    assert abs(d.logit_clip - np.log(0.9999 / 0.0001)) < 1e-9
+
+
+def test_config_validation():
+    from ippmarl.derived import DerivedConstants
+    p = make_params("default")
+    del p["environment"]["x_dim"]
+    with pytest.raises((ValueError, KeyError)):
+        DerivedConstants(p)
+    with pytest.raises(ValueError):
+        DerivedConstants(make_params("default", experiment__missions__n_agents=17))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from ippmarl import _ffi
+    lib = _ffi.load_library()
+    header = open(os.path.join(ROOT, "include", "ippmarl.h")).read()
+    declared = set(re.findall(r"\b(ippm_[a-z0-9_]+)\s*\(", header))
+    declared -= {"ippm_ctx"}
+    assert len(declared) >= 25
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/ippmarl.h but not exported"
+    bound = set(_ffi.PROTOTYPES) | {"ippm_last_error", "ippm_version", "ippm_config_size"}
+    assert declared == bound, f"binding and header disagree: {declared ^ bound}"
+    assert lib.ippm_version() == 100
+    import ctypes
+    assert lib.ippm_config_size() == ctypes.sizeof(_ffi.IppmConfig)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from ippmarl import _ffi
+    monkeypatch.setattr(_ffi, "_lib", None)
+    monkeypatch.setattr(_ffi, "LIB_PATH", "/nonexistent/libippmarl.so")
+    with pytest.raises(_ffi.IppmError, match="no CPU fallback"):
+        _ffi.load_library()
+
+
+def test_no_gpu_means_no_env():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from ippmarl import _ffi
+    from ippmarl.vec_env import VecEnv
+    with pytest.raises(_ffi.IppmError):
+        VecEnv(make_params("small"), 2)
+
+
+def test_device_mt19937_mirror_matches_numpy(golden):
+    from ippmarl import _ffi
+    fx = golden("start_states")
+    got = np.array([[_ffi.host_start_state(3, e, a, 5, 11, 11) for a in range(16)] for e in range(1, 65)])
+    assert np.array_equal(got, fx["seed3"])
+    got7 = np.array([[_ffi.host_start_state(7, e, a, 5, 11, 11) for a in range(4)] for e in range(1, 17)])
+    assert np.array_equal(got7, fx["seed7"])
+    tp = golden("truth")["split_pct"]
+    assert np.array_equal(np.array([_ffi.host_truth_params(e) for e in range(1, 4097)]), tp)
+    # large episode numbers (later reset waves)
+    d = O.Derived(make_params("default"))
+    for e in (10 ** 6 + 7, 123456789):
+        assert _ffi.host_truth_params(e) == O.truth_split_params(e)
+        assert _ffi.host_start_state(3, e, 3, 5, 11, 11) == list(O.start_state(d, 3, e))
+
+
+def test_philox_mirror_matches_oracle_and_known_answers():
+    from ippmarl import _ffi
+    assert _ffi.host_philox(0, 0, 0, 0, 0, 0) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert _ffi.host_philox(0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344, 0xA4093822, 0x299F31D0) == \
+        [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+    rng = np.random.RandomState(0)
+    for _ in range(50):
+        args = [int(v) for v in rng.randint(0, 2 ** 32, size=6, dtype=np.uint64)]
+        assert _ffi.host_philox(*args) == [int(v) for v in O.philox4x32(*args)]
+
+
+@pytest.mark.parametrize("n_src", [30, 60, 90, 128, 256, 493, 512, 1024])
+def test_area_weights_match_oracle(n_src):
+    from ippmarl import _ffi
+    b, w0, w1 = _ffi.host_area_weights(n_src)
+    dense = O.area_weights(n_src, 11)
+    mine = np.zeros_like(dense)
+    for i in range(n_src):
+        mine[b[i], i] += w0[i]
+        if b[i] + 1 < 11:
+            mine[b[i] + 1, i] += w1[i]
+    np.testing.assert_allclose(mine, dense, rtol=0, atol=6e-8)  # weights are handed over as float32
+    np.testing.assert_allclose(mine.sum(axis=1), 1.0, atol=1e-6)
+
+
+def test_params_schema_loads_and_matches_reference_defaults():
+    from ippmarl.params import load_params, grid256_params
+    p = load_params()
+    assert p["experiment"]["constraints"]["budget"] == 14 and p["networks"]["lambda"] == 0.8
+    assert p["experiment"]["uav"]["communication_range"] == 25 and p["mapping"]["prior"] == 0.5
+    from ippmarl.derived import DerivedConstants
+    assert DerivedConstants(grid256_params()).grid_x == 256

@@ -18,7 +18,8 @@ import pandas as pd
 def per_kernel(directory, counter):
     c = pd.read_csv(f"{directory}/p_counter_collection.csv")
     c = c[c["Counter_Name"] == counter]
-    g = c.groupby("Kernel_Name")["Counter_Value"].agg(["mean", "count"])
+    per_dispatch = c.groupby(["Dispatch_Id", "Kernel_Name"])["Counter_Value"].sum().reset_index()
+    g = per_dispatch.groupby("Kernel_Name")["Counter_Value"].agg(["mean", "count", "max"])
     return g
 
 
@@ -35,13 +36,14 @@ def main():
         return rows.sort_values("count", ascending=False).iloc[0] if len(rows) else None
 
     # calibration kernel: torch's copy of a float tensor (largest elementwise copy in the trace)
-    cal_f = fetch[fetch.index.str.contains("copy", case=False)].sort_values("mean", ascending=False).iloc[0]
-    cal_w = write[write.index.str.contains("copy", case=False)].sort_values("mean", ascending=False).iloc[0]
-    f_scale = clone_bytes / (cal_f["mean"] * 1024.0)  # bytes per reported KiB-unit
-    w_scale = clone_bytes / (cal_w["mean"] * 1024.0)
+    # (the largest copy dispatch of the run is the clone; smaller copies share the kernel name)
+    cal_f = fetch[fetch.index.str.contains("copy", case=False)].sort_values("max", ascending=False).iloc[0]
+    cal_w = write[write.index.str.contains("copy", case=False)].sort_values("max", ascending=False).iloc[0]
+    f_scale = clone_bytes / (cal_f["max"] * 1024.0)  # true bytes per reported KiB
+    w_scale = clone_bytes / (cal_w["max"] * 1024.0)
     summary = {"envs_per_gpu": n_envs, "n_agents": n_agents, "grid": grid, "calibration": {
-        "kernel": "torch clone of the local maps", "bytes": clone_bytes, "FETCH_SIZE_reported_KiB": float(cal_f["mean"]),
-        "WRITE_SIZE_reported_KiB": float(cal_w["mean"]), "fetch_correction": f_scale, "write_correction": w_scale}}
+        "kernel": "torch clone of the local maps", "bytes": clone_bytes, "FETCH_SIZE_reported_KiB": float(cal_f["max"]),
+        "WRITE_SIZE_reported_KiB": float(cal_w["max"]), "fetch_correction": f_scale, "write_correction": w_scale}}
     trace = pd.read_csv(f"{stats_dir}/p_kernel_trace.csv")
     trace["dur_us"] = (trace["End_Timestamp"] - trace["Start_Timestamp"]) / 1e3
     for key, pat in (("k_sense_update", "k_sense_update"), ("k_apply_ops_local", "k_apply_ops<4, false, 6>"),
