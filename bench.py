@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--agents", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-events", type=int, default=1, help="time every K3 launch with HIP events (roofline)")
+    ap.add_argument("--train-rounds", type=int, default=2, help="COMA rounds (rollout with the actor + full update) timed after "
+                    "the env-only region for the COMA updates/s figure; 0 disables")
     ap.add_argument("--calib", action="store_true", help="PMC calibration: 3 device-to-device clones of the local maps (known "
                     "bytes read and written by a 16 B/lane streaming kernel) before the timed loop")
     args = ap.parse_args()
@@ -186,6 +188,35 @@ def main():
                     "cells_per_launch": sense_cells_step / max(len(ev_pairs), 1),
                     "avg_launch_us": 1e3 * k3_ms / len(ev_pairs), "launches": len(ev_pairs)}
 
+    coma = None
+    if args.train_rounds > 0:
+        # BASELINE configs[2]: full COMA actor + counterfactual critic training on the same env config
+        from ippmarl.trainer import COMATrainer
+        del env
+        torch.cuda.empty_cache()
+        tr = COMATrainer(params, args.envs, device=device, philox_seed=3, rank=rank, world=world)
+        tr.rollout("train")
+        tr.update()  # warm-up round (MIOpen kernel selection, allocator)
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        c0 = time.perf_counter()
+        roll_s = 0.0
+        for _ in range(args.train_rounds):
+            r0 = time.perf_counter()
+            tr.rollout("train")
+            torch.cuda.synchronize()
+            roll_s += time.perf_counter() - r0
+            stats = tr.update()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        cdt = time.perf_counter() - c0
+        coma = {"updates_per_s": args.train_rounds / cdt, "s_per_update": cdt / args.train_rounds,
+                "transitions_per_update": stats["transitions"], "adam_steps_per_update": stats["adam_steps"],
+                "rollout_agent_env_steps_per_s": tr.E * tr.N * tr.T * world * args.train_rounds / roll_s,
+                "note": "one update = TD(lambda) targets + data_passes x batch_number minibatch steps of critic and actor "
+                        "(reference round: 25+25 Adam steps on 300 transitions); nets float32 in PyTorch-ROCm"}
     if rank == 0:
         total_steps = E * N * args.steps * world
         out = {
@@ -199,6 +230,7 @@ def main():
             "faults": faults,
             "cells": counters,
             "roofline": roofline,
+            "coma_training": coma,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(params)

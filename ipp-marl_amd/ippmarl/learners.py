@@ -1,0 +1,95 @@
+"""COMA learners on tensors: critic TD regression (critic/learner.py:58-198) and actor policy gradient with the
+counterfactual baseline (actor/learner.py:36-168).  The baseline/advantage arithmetic runs in the HIP kernel K7
+(ippm_coma_advantage); autograd, Adam and the convnets are PyTorch.  Metric-only work of the reference (KL via an
+extra forward pass, gradient-norm dumps, explained variance) is not reproduced."""
+from __future__ import annotations
+
+import copy
+from typing import Dict, Optional
+
+import torch
+
+from . import _ffi
+
+
+class CriticLearner:
+    def __init__(self, params: Dict, critic, device):
+        self.params = params
+        self.critic = critic.to(device)
+        self.device = device
+        self.target_critic = copy.deepcopy(critic).to(device)
+        self.target_critic.eval()
+        net = params["networks"]
+        self.copy_rate = net["copy_rate"]
+        self.lr = net["critic"]["learning_rate"]
+        self.target_update_mode = net["critic"]["target_update_mode"]
+        self.tau = net["critic"]["tau"]
+        self.optimizer = torch.optim.Adam(self.critic.parameters(), lr=self.lr)
+        self.optimizer.zero_grad()
+
+    def update_target_network(self, num_train_step: int, data_pass: int):
+        """Hard copy every copy_rate train steps on data pass 0, or Polyak (critic/learner.py:192-198)."""
+        if self.target_update_mode == "hard":
+            if num_train_step % self.copy_rate == 0 and data_pass == 0:
+                self.target_critic.load_state_dict(self.critic.state_dict())
+        elif self.target_update_mode == "soft":
+            with torch.no_grad():
+                for t, s in zip(self.target_critic.parameters(), self.critic.parameters()):
+                    t.mul_(1 - self.tau).add_(s, alpha=self.tau)
+
+    def step(self, states: torch.Tensor, actions: torch.Tensor, td_targets: torch.Tensor, grad_hook=None):
+        """One minibatch: MSE on the chosen Q, Adam step, then the POST-step Q handed to the actor
+        (critic/learner.py:76-105).  Returns (loss, q_new [B,A])."""
+        q, _ = self.critic(states)
+        q_chosen = q.gather(1, actions.long().view(-1, 1))
+        loss = torch.square(q_chosen - td_targets.view(-1, 1).detach()).squeeze().mean()
+        self.optimizer.zero_grad()
+        loss.backward()
+        if grad_hook is not None:
+            grad_hook(self.critic)
+        self.optimizer.step()
+        with torch.no_grad():
+            q_new, _ = self.critic(states)
+        return loss.detach(), q_new
+
+
+class ActorLearner:
+    def __init__(self, params: Dict, actor, device, ctx: Optional[_ffi.Context] = None):
+        self.params = params
+        self.actor = actor.to(device)
+        self.device = device
+        self.ctx = ctx
+        self.n_actions = params["experiment"]["constraints"]["num_actions"]
+        self.lr = params["networks"]["actor"]["learning_rate"]
+        self.optimizer = torch.optim.Adam(self.actor.parameters(), lr=self.lr)
+        self.optimizer.zero_grad()
+
+    def advantage(self, probs: torch.Tensor, q_values: torch.Tensor, masks: torch.Tensor, actions: torch.Tensor):
+        """A = Q(a) - sum_a' pi~(a') Q(a') mask(a') with pi~ the mask-renormalised, floored policy
+        (actor/learner.py:55-83) -- HIP kernel K7."""
+        if self.ctx is None:
+            raise _ffi.IppmError("ActorLearner needs an ippmarl context: the counterfactual baseline runs in libippmarl (K7)")
+        b = probs.shape[0]
+        adv = torch.empty(b, dtype=torch.float32, device=probs.device)
+        stream = torch.cuda.current_stream(probs.device).cuda_stream
+        self.ctx.call("ippm_coma_advantage", _ffi.ptr(probs.detach().float().contiguous()), _ffi.ptr(q_values.float().contiguous()),
+                      _ffi.ptr(masks.to(torch.uint8).contiguous()), _ffi.ptr(actions.to(torch.int32).contiguous()),
+                      _ffi.ptr(adv), None, b, stream)
+        return adv
+
+    def step(self, observations: torch.Tensor, actions: torch.Tensor, masks: torch.Tensor, q_values: torch.Tensor, eps: float,
+             grad_hook=None):
+        """One minibatch (actor/learner.py:52-101).  The reference's loss broadcasts [B,1]*[B,1]*[B,A] before the
+        mean, i.e. every sample is weighted by (#valid actions)/A."""
+        probs, _ = self.actor(observations, eps)
+        log_probs = torch.log(probs)
+        adv = self.advantage(probs, q_values, masks, actions)
+        log_chosen = log_probs.gather(1, actions.long().view(-1, 1)).squeeze(1)
+        weight = masks.to(log_chosen.dtype).sum(-1) / self.n_actions
+        loss = -(adv.detach() * log_chosen * weight).mean()
+        self.optimizer.zero_grad()
+        loss.backward()
+        if grad_hook is not None:
+            grad_hook(self.actor)
+        self.optimizer.step()
+        return loss.detach(), adv

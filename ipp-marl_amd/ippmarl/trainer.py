@@ -1,0 +1,160 @@
+"""Batched COMA training loop: E device-resident environments roll out in lock step, the update runs on the whole
+buffer.  Mirrors the cadence of COMAMission.execute (missions/coma_mission.py:48-172): rollout -> TD(lambda) targets
+(K8) -> data_passes x batch_number minibatch steps of critic then actor (K7 inside the actor step).
+
+One "update" = TD-target build + data_passes * batch_number Adam steps of each net, exactly the reference's round; the
+number of transitions per round scales with the number of batched envs (reference: 300; here waves * T * E * N).
+"""
+from __future__ import annotations
+
+import copy
+from typing import Dict, Optional
+
+import torch
+
+from . import _ffi
+from .learners import ActorLearner, CriticLearner
+from .networks import ActorNetwork, CriticNetwork, epsilon_schedule
+from .parallel import GradAllReducer, broadcast_module, episode_ids
+from .vec_env import VecEnv, POLICY_ARGMAX, POLICY_SAMPLE
+
+
+class COMATrainer:
+    def __init__(self, params: Dict, n_envs: int, device: str = "cuda:0", philox_seed: int = 3, waves_per_update: int = 1,
+                 quirks: str = "reference", rank: int = 0, world: int = 1, first_episode: int = 1):
+        self.params = params
+        self.env = VecEnv(params, n_envs, device=device, philox_seed=philox_seed)
+        self.device = self.env.device
+        self.rank, self.world = rank, world
+        self.first_episode = first_episode
+        self.waves_per_update = waves_per_update
+        self.quirks = quirks
+        d = self.env.d
+        self.T, self.E, self.N, self.A = d.budget + 1, self.env.E, d.n_agents, d.n_actions
+        net = params["networks"]
+        self.data_passes, self.batch_number = net["data_passes"], net["batch_number"]
+        self.actor = ActorNetwork(params)
+        self.critic = CriticNetwork(params)
+        # the reference builds TD targets with a deepcopy of the critic taken at construction that is
+        # never synchronised; quirks="fixed" uses the learner's synchronised target network instead
+        self.frozen_target = copy.deepcopy(self.critic).to(self.device).eval()
+        self.actor_learner = ActorLearner(params, self.actor, self.device, ctx=self.env.ctx)
+        self.critic_learner = CriticLearner(params, self.critic, self.device)
+        for m in (self.actor, self.critic, self.critic_learner.target_critic, self.frozen_target):
+            broadcast_module(m)
+        self.reducer = GradAllReducer()
+        W, T, E, N = waves_per_update, self.T, self.E, self.N
+        dev = self.device
+        self.buf_obs = torch.empty(W, T, E, N, 11, 11, 7, device=dev)
+        self.buf_state = torch.empty(W, T, E, N, 11, 11, 12, device=dev)
+        self.buf_action = torch.empty(W, T, E, N, dtype=torch.int32, device=dev)
+        self.buf_mask = torch.empty(W, T, E, N, self.A, dtype=torch.uint8, device=dev)
+        self.buf_reward = torch.empty(W, T, E, device=dev)
+        self.wave = 0          # rollout waves done so far (defines the episode numbers)
+        self.filled = 0        # waves currently in the buffer
+        self.train_step = 0
+        self.eps = epsilon_schedule(params, 0)
+
+    # ------------------------------------------------------------------------------------------------
+    def rollout(self, mode: str = "train") -> Dict[str, float]:
+        """One wave: E episodes in lock step (EpisodeGenerator.execute for every env at once)."""
+        env = self.env
+        eps_ids = episode_ids(self.first_episode, self.wave, self.E, self.rank, self.world)
+        # the reference anneals epsilon with the episode index (actor/network.py:53-58); one wave = E episodes
+        self.eps = epsilon_schedule(self.params, int(eps_ids[0]))
+        env.reset(eps_ids)
+        w = self.filled
+        ret = torch.zeros(self.E, device=self.device)
+        abs_ret = torch.zeros(self.E, device=self.device)
+        policy = POLICY_ARGMAX if mode == "eval" else POLICY_SAMPLE
+        for t in range(self.T):
+            obs = env.build_observations(t)
+            with torch.no_grad():
+                probs, _ = self.actor(obs.view(self.E * self.N, 11, 11, 7), self.eps)
+            reward, done, state = env.steps(t, policy=policy, probs=probs.view(self.E, self.N, self.A))
+            if mode == "train":
+                self.buf_obs[w, t].copy_(obs)
+                self.buf_state[w, t].copy_(state)
+                self.buf_action[w, t].copy_(env.action)
+                self.buf_mask[w, t].copy_(env.mask)
+                self.buf_reward[w, t].copy_(reward[:, 0])
+            ret += reward[:, 0]
+            abs_ret += reward[:, 1]
+        self.wave += 1
+        if mode == "train":
+            self.filled += 1
+        return {"episode_return": float(ret.mean()), "absolute_return": float(abs_ret.mean()), "eps": self.eps,
+                "faults": int(env.fault.ne(0).sum())}
+
+    # ------------------------------------------------------------------------------------------------
+    def td_targets(self):
+        """K8 over one chain per (env, agent): the transitions of all buffered waves in time order
+        (BatchMemory.build_td_targets, batch_memory.py:120-162)."""
+        W, T, E, N = self.filled, self.T, self.E, self.N
+        target = self.frozen_target if self.quirks == "reference" else self.critic_learner.target_critic
+        states = self.buf_state[:W].reshape(W * T * E * N, 11, 11, 12)
+        actions = self.buf_action[:W].reshape(-1)
+        q_sel = torch.empty(W * T * E * N, device=self.device)
+        with torch.no_grad():
+            chunk = 16384
+            for lo in range(0, states.shape[0], chunk):
+                q, _ = target(states[lo:lo + chunk])
+                q_sel[lo:lo + chunk] = q.view(-1, self.A).gather(1, actions[lo:lo + chunk].long().view(-1, 1)).squeeze(1)
+        # chains: [E*N, W*T]
+        q_sel = q_sel.view(W, T, E, N).permute(2, 3, 0, 1).reshape(E * N, W * T).contiguous()
+        rew = self.buf_reward[:W].unsqueeze(-1).expand(W, T, E, N).permute(2, 3, 0, 1).reshape(E * N, W * T).contiguous()
+        done = torch.zeros(W, T, dtype=torch.uint8, device=self.device)
+        done[:, T - 1] = 1
+        done = done.view(1, W * T).expand(E * N, W * T).contiguous()
+        td = torch.empty_like(rew)
+        dr = torch.empty_like(rew)
+        self.env.ctx.call("ippm_td_lambda", _ffi.ptr(rew), _ffi.ptr(done), _ffi.ptr(q_sel), _ffi.ptr(td), _ffi.ptr(dr), E * N,
+                          W * T, self.env.stream)
+        # back to buffer order [W,T,E,N]
+        to_buf = lambda x: x.view(E, N, W, T).permute(2, 3, 0, 1).reshape(-1)  # noqa: E731
+        return to_buf(td), to_buf(dr)
+
+    def update(self) -> Dict[str, float]:
+        """One COMA round on everything in the buffer, then clear it (coma_mission.py:89-116)."""
+        W, T, E, N = self.filled, self.T, self.E, self.N
+        assert W > 0, "update() needs at least one rollout wave"
+        n = W * T * E * N
+        td, _ = self.td_targets()
+        obs = self.buf_obs[:W].reshape(n, 11, 11, 7)
+        states = self.buf_state[:W].reshape(n, 11, 11, 12)
+        actions = self.buf_action[:W].reshape(n)
+        masks = self.buf_mask[:W].reshape(n, self.A)
+        bs = n // self.batch_number
+        closs = aloss = torch.zeros((), device=self.device)
+        for data_pass in range(self.data_passes):
+            perm = torch.randperm(n, device=self.device)
+            self.critic_learner.update_target_network(self.train_step, data_pass)
+            q_new = []
+            for b in range(self.batch_number):  # critic first over all minibatches (critic/learner.py:58-105)
+                idx = perm[b * bs:(b + 1) * bs]
+                closs, q = self.critic_learner.step(states[idx], actions[idx], td[idx], grad_hook=self.reducer)
+                q_new.append(q)
+            for b in range(self.batch_number):  # then the actor with the post-step Q values (actor/learner.py:36-101)
+                idx = perm[b * bs:(b + 1) * bs]
+                aloss, _ = self.actor_learner.step(obs[idx], actions[idx], masks[idx], q_new[b], self.eps, grad_hook=self.reducer)
+            if data_pass == 0:
+                self.train_step += 1
+        self.filled = 0
+        return {"critic_loss": float(closs), "actor_loss": float(aloss), "transitions": n * self.world,
+                "adam_steps": 2 * self.data_passes * self.batch_number, "train_step": self.train_step}
+
+    def train(self, n_updates: int, log=None):
+        history = []
+        for _ in range(n_updates):
+            stats = {}
+            for _ in range(self.waves_per_update):
+                stats = self.rollout("train")
+            stats.update(self.update())
+            history.append(stats)
+            if log:
+                log(stats)
+        return history
+
+    def save_actor(self, path: str):
+        """Whole-module pickle of the actor, the reference's checkpoint format (coma_mission.py:425-451)."""
+        torch.save(self.actor, path)

@@ -1,0 +1,102 @@
+"""GPU checks of the learning path: the actor's minibatch step (K7 inside) against the reference's recorded numbers,
+TD(lambda) chains built from the trainer's buffers, and an end-to-end batched COMA round."""
+import numpy as np
+import pytest
+
+import ipp_oracle as O
+from configs import make_params, synthetic_minibatch
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def test_actor_and_critic_step_match_reference(golden):
+    from ippmarl import _ffi
+    from ippmarl.derived import DerivedConstants
+    from ippmarl.learners import ActorLearner, CriticLearner
+    from ippmarl.networks import ActorNetwork, CriticNetwork
+    fx = golden("coma_step")
+    params = make_params("c2")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(int(fx["net_seed"]))
+    actor, critic = ActorNetwork(params), CriticNetwork(params)
+    ctx = _ffi.Context(DerivedConstants(params))
+    obs, state, actions, masks, td = synthetic_minibatch(60, 6, int(fx["mb_seed"]))
+    t = lambda x, dt=None: torch.tensor(x, device=dev, dtype=dt)  # noqa: E731
+    cl = CriticLearner(params, critic, dev)
+    al = ActorLearner(params, actor, dev, ctx=ctx)
+    closs, q_new = cl.step(t(state), t(actions), t(td))
+    np.testing.assert_allclose(float(closs), float(fx["critic_loss"]), rtol=1e-4)
+    np.testing.assert_allclose(q_new.cpu().numpy(), fx["q_new"], rtol=2e-4, atol=2e-6)
+    aloss, adv = al.step(t(obs, torch.float32), t(actions), t(masks, torch.float32), q_new, float(fx["eps"]))
+    np.testing.assert_allclose(float(aloss), float(fx["actor_loss"]), rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(float(adv.mean()), float(fx["adv_mean"]), rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(float(adv.std()), float(fx["adv_std"]), rtol=2e-4)
+    with torch.no_grad():
+        pi1, _ = actor(t(obs, torch.float32), float(fx["eps"]))
+    np.testing.assert_allclose(pi1.cpu().numpy(), fx["pi1"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(actor.fc3.bias.detach().cpu().numpy(), fx["actor_fc3_b"], rtol=1e-4, atol=1e-6)
+
+
+def test_trainer_round_and_td_chains():
+    from ippmarl.trainer import COMATrainer
+    params = make_params("small")
+    torch.manual_seed(0)
+    tr = COMATrainer(params, n_envs=6, waves_per_update=2, first_episode=3)
+    s1 = tr.rollout("train")
+    s2 = tr.rollout("train")
+    assert s1["faults"] == 0 and np.isfinite(s1["episode_return"]) and np.isfinite(s2["episode_return"])
+    W, T, E, N = 2, tr.T, tr.E, tr.N
+    # TD(lambda) through the kernel == the oracle's literal restatement on each (env, agent) chain
+    td, dr = tr.td_targets()
+    td = td.view(W, T, E, N).cpu().numpy()
+    states = tr.buf_state[:W].reshape(-1, 11, 11, 12)
+    with torch.no_grad():
+        q, _ = tr.frozen_target(states)
+    q_sel = q.gather(1, tr.buf_action[:W].reshape(-1, 1).long()).view(W, T, E, N).cpu().numpy()
+    rew = tr.buf_reward[:W].cpu().numpy()
+    g, lam = params["networks"]["gamma"], params["networks"]["lambda"]
+    dones = [t == T - 1 for _ in range(W) for t in range(T)]
+    for e in (0, 3, 5):
+        for i in (0, N - 1):
+            want, _ = O.td_lambda_targets(rew[:, :, e].reshape(-1), dones, q_sel[:, :, e, i].reshape(-1), g, lam)
+            np.testing.assert_allclose(td[:, :, e, i].reshape(-1), want, rtol=2e-5, atol=2e-6)
+    assert td[1, 0].max() == 0.0 and td[1, 0].min() == 0.0  # first step of a later episode in the chain
+    before = [p.detach().clone() for p in tr.actor.parameters()]
+    stats = tr.update()
+    assert stats["transitions"] == W * T * E * N and stats["adam_steps"] == 50
+    assert np.isfinite(stats["critic_loss"]) and np.isfinite(stats["actor_loss"])
+    changed = [not torch.equal(a, b.detach()) for a, b in zip(before, tr.actor.parameters())]
+    names = [n for n, _ in tr.actor.named_parameters()]
+    assert all(c for c, n in zip(changed, names) if not n.startswith("fc2"))
+    assert not any(c for c, n in zip(changed, names) if n.startswith("fc2"))
+    # eval rollout (argmax policy) does not touch the buffer
+    tr.rollout("eval")
+    assert tr.filled == 0
+
+
+def test_sampling_policy_matches_oracle():
+    """POLICY_SAMPLE: the device's inverse-CDF draw over probs*mask == the oracle's float32 restatement."""
+    from ippmarl.vec_env import VecEnv, POLICY_SAMPLE, POLICY_ARGMAX
+    params = make_params("small")
+    seed = 77
+    env = VecEnv(params, 32, philox_seed=seed)
+    eps = np.arange(50, 82)
+    env.reset(eps)
+    d = env.d
+    rng = np.random.RandomState(1)
+    for t in range(3):
+        env.build_observations(t, features=False)
+        probs = rng.dirichlet(np.ones(d.n_actions), size=(env.E, d.n_agents)).astype(np.float32)
+        pre = env.pos.cpu().numpy().copy()
+        env.steps(t, policy=POLICY_SAMPLE, probs=torch.tensor(probs, device=env.device), features=False)
+        act, mask = env.action.cpu().numpy(), env.mask.cpu().numpy()
+        for e in range(env.E):
+            for i in range(d.n_agents):
+                want = O.sample_masked_action(O.philox_action_word(seed, int(eps[e]), i, t), probs[e, i] * mask[e, i])
+                assert act[e, i] == want, (t, e, i)
+    env.build_observations(3, features=False)
+    probs = rng.dirichlet(np.ones(d.n_actions), size=(env.E, d.n_agents)).astype(np.float32)
+    env.steps(3, policy=POLICY_ARGMAX, probs=torch.tensor(probs, device=env.device), features=False)
+    act, mask = env.action.cpu().numpy(), env.mask.cpu().numpy()
+    assert np.array_equal(act, np.argmax(probs * mask, axis=-1))

@@ -1,0 +1,136 @@
+"""CPU checks of the learning side: network architecture/initialisation parity with the reference (golden coma_step
+fixture), the critic's minibatch step, and the multi-process gradient averaging (gloo, world_size 2)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from configs import make_params, synthetic_minibatch
+
+
+def _nets(seed):
+    from ippmarl.networks import ActorNetwork, CriticNetwork
+    params = make_params("c2")
+    torch.manual_seed(seed)
+    actor = ActorNetwork(params)   # same construction order as COMAWrapper.__init__ (coma_wrapper.py:29-35)
+    critic = CriticNetwork(params)
+    return params, actor, critic
+
+
+def test_network_architecture_and_init_match_reference(golden):
+    fx = golden("coma_step")
+    params, actor, critic = _nets(int(fx["net_seed"]))
+    assert sum(p.numel() for p in actor.parameters()) == int(fx["n_actor_params"]) == 2275846
+    assert sum(p.numel() for p in critic.parameters()) == int(fx["n_critic_params"]) == 2307846
+    obs, state, actions, masks, td = synthetic_minibatch(60, 6, int(fx["mb_seed"]))
+    with torch.no_grad():
+        q0, _ = critic(torch.tensor(state))
+        pi0, _ = actor(torch.tensor(obs).float(), float(fx["eps"]))
+    np.testing.assert_allclose(q0.numpy(), fx["q0"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(pi0.numpy(), fx["pi0"], rtol=1e-5, atol=1e-7)
+    assert [n for n, _ in actor.named_parameters()] == ["conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias", "conv3.weight",
+                                                       "conv3.bias", "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias",
+                                                       "fc3.weight", "fc3.bias"]  # reference state_dict keys
+
+
+def test_critic_minibatch_step_matches_reference(golden):
+    from ippmarl.learners import CriticLearner
+    fx = golden("coma_step")
+    params, actor, critic = _nets(int(fx["net_seed"]))
+    obs, state, actions, masks, td = synthetic_minibatch(60, 6, int(fx["mb_seed"]))
+    learner = CriticLearner(params, critic, torch.device("cpu"))
+    loss, q_new = learner.step(torch.tensor(state), torch.tensor(actions), torch.tensor(td))
+    np.testing.assert_allclose(float(loss), float(fx["critic_loss"]), rtol=1e-5)
+    np.testing.assert_allclose(q_new.numpy(), fx["q_new"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(critic.fc3.bias.detach().numpy(), fx["critic_fc3_b"], rtol=1e-5, atol=1e-7)
+    assert critic.fc2.weight.grad is None  # the unused layer never gets a gradient (matters for the all-reduce)
+
+
+def test_epsilon_schedule():
+    from ippmarl.networks import epsilon_schedule
+    p = make_params("default")
+    assert epsilon_schedule(p, 0) == 0.5
+    assert abs(epsilon_schedule(p, 5000) - 0.26) < 1e-12
+    assert epsilon_schedule(p, 10001) == 0.02
+
+
+def test_shard_helpers():
+    from ippmarl.parallel import episode_ids, shard_range
+    spans = [shard_range(8192, r, 8) for r in range(8)]
+    assert spans[0] == (0, 1024) and spans[-1] == (7168, 8192)
+    spans = [shard_range(10, r, 4) for r in range(4)]
+    assert spans == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    a = episode_ids(1, 0, 4, 0, 2)
+    b = episode_ids(1, 0, 4, 1, 2)
+    c = episode_ids(1, 1, 4, 0, 2)
+    assert a.tolist() == [1, 2, 3, 4] and b.tolist() == [5, 6, 7, 8] and c.tolist() == [9, 10, 11, 12]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _dp_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ippmarl.learners import CriticLearner
+    from ippmarl.networks import CriticNetwork
+    from ippmarl.parallel import GradAllReducer, broadcast_module, shard_range
+    params = make_params("c2")
+    torch.manual_seed(100 + rank)          # different init per rank: broadcast must fix that
+    critic = CriticNetwork(params)
+    broadcast_module(critic)
+    _, state, actions, _, td = synthetic_minibatch(32, 6, 5)
+    lo, hi = shard_range(32, rank, world)
+    learner = CriticLearner(params, critic, torch.device("cpu"))
+    reducer = GradAllReducer()
+    grads = {}
+
+    def hook(module):
+        reducer(module)
+        grads.update({n: p.grad.clone() for n, p in module.named_parameters() if p.grad is not None})
+
+    learner.step(torch.tensor(state[lo:hi]), torch.tensor(actions[lo:hi]), torch.tensor(td[lo:hi]), grad_hook=hook)
+    if rank == 0:
+        torch.save({"grads": grads, "weights": {n: p.detach().clone() for n, p in critic.named_parameters()},
+                    "bytes": reducer.bytes_reduced}, out)
+    # weights must stay identical across ranks after the step
+    w = torch.cat([p.detach().reshape(-1) for p in critic.parameters()])
+    ws = [torch.empty_like(w) for _ in range(world)]
+    dist.all_gather(ws, w)
+    assert all(torch.equal(ws[0], x) for x in ws)
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_equals_single_process(tmp_path):
+    """world_size-2 gloo run: averaged shard gradients == gradient of the full batch in one process."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "rank0.pt")
+    mp.spawn(_dp_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    from ippmarl.learners import CriticLearner
+    from ippmarl.networks import CriticNetwork
+    params = make_params("c2")
+    torch.manual_seed(100)                  # rank 0's init is what broadcast distributes
+    critic = CriticNetwork(params)
+    _, state, actions, _, td = synthetic_minibatch(32, 6, 5)
+    learner = CriticLearner(params, critic, torch.device("cpu"))
+    ref = {}
+    learner.step(torch.tensor(state), torch.tensor(actions), torch.tensor(td),
+                 grad_hook=lambda m: ref.update({n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
+    assert set(ref) == set(got["grads"]) and "fc2.weight" not in ref
+    for n in ref:
+        torch.testing.assert_close(got["grads"][n], ref[n], rtol=1e-4, atol=1e-6)  # float32 summation order
+    for n, p in critic.named_parameters():
+        # the first Adam step moves every weight by lr * sign(g): a near-zero gradient may flip -> at most 2 lr apart
+        torch.testing.assert_close(got["weights"][n], p.detach(), rtol=0, atol=2.5e-4)
+    n_grad = sum(v.numel() for v in ref.values())
+    assert got["bytes"] == 4 * n_grad == 4 * (2307846 - 256 * 256 - 256)  # one flat bucket, fc2 skipped
