@@ -71,10 +71,13 @@ class ActorLearner:
             raise _ffi.IppmError("ActorLearner needs an ippmarl context: the counterfactual baseline runs in libippmarl (K7)")
         b = probs.shape[0]
         adv = torch.empty(b, dtype=torch.float32, device=probs.device)
+        # converted copies must stay referenced until the launch is queued (a dropped temporary's block can be reused)
+        p32 = probs.detach().float().contiguous()
+        q32 = q_values.float().contiguous()
+        m8 = masks.to(torch.uint8).contiguous()
+        a32 = actions.to(torch.int32).contiguous()
         stream = torch.cuda.current_stream(probs.device).cuda_stream
-        self.ctx.call("ippm_coma_advantage", _ffi.ptr(probs.detach().float().contiguous()), _ffi.ptr(q_values.float().contiguous()),
-                      _ffi.ptr(masks.to(torch.uint8).contiguous()), _ffi.ptr(actions.to(torch.int32).contiguous()),
-                      _ffi.ptr(adv), None, b, stream)
+        self.ctx.call("ippm_coma_advantage", _ffi.ptr(p32), _ffi.ptr(q32), _ffi.ptr(m8), _ffi.ptr(a32), _ffi.ptr(adv), None, b, stream)
         return adv
 
     def step(self, observations: torch.Tensor, actions: torch.Tensor, masks: torch.Tensor, q_values: torch.Tensor, eps: float,
