@@ -168,6 +168,7 @@ def main():
         dt = float(tt[0])
     counters = env.counters()
     faults = int(env.fault.abs().sum())
+    grid = [env.d.grid_x, env.d.grid_y]
 
     k3_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) if ev_pairs else None
     sense_cells_step = counters["sense_cells"]
@@ -192,7 +193,8 @@ def main():
     if args.train_rounds > 0:
         # BASELINE configs[2]: full COMA actor + counterfactual critic training on the same env config
         from ippmarl.trainer import COMATrainer
-        del env
+        env.sense = None
+        env = None  # release the env-only state before the trainer allocates its own
         torch.cuda.empty_cache()
         tr = COMATrainer(params, args.envs, device=device, philox_seed=3, rank=rank, world=world)
         tr.rollout("train")
@@ -225,7 +227,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (device-generated half-plane truth, Philox sensor noise)",
             "config": {"workload": "BASELINE.json configs[1]: 4 UAVs, 256x256 grid, 1024 batched envs per GPU, random policy, "
-                                   "env-step kernels only", "envs_per_gpu": E, "n_agents": N, "grid": [env.d.grid_x, env.d.grid_y],
+                                   "env-step kernels only", "envs_per_gpu": E, "n_agents": N, "grid": grid,
                        "episode_steps": T, "parallelism": f"env-sharded x{world} (no data-path collective)"},
             "faults": faults,
             "cells": counters,
