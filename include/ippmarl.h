@@ -126,6 +126,8 @@ int ippm_reset_episode(ippm_ctx* ctx, const int64_t* episode, int32_t* pos, uint
 /* Elementwise conversions between the stored log-odds and the reference's probabilities (n floats). */
 int ippm_logodds_to_prob(ippm_ctx* ctx, const float* src, float* dst, int64_t n, void* stream);
 int ippm_prob_to_logodds(ippm_ctx* ctx, const float* src, float* dst, int64_t n, void* stream);
+/* clip(p, 1e-4, 0.9999) of n stored log-odds in place: the full-grid input clip of one stand-alone fuse_map call. */
+int ippm_clamp_logodds(ippm_ctx* ctx, float* maps, int64_t n, void* stream);
 
 /* ---- K2: Camera.project_field_of_view (sensors/cameras.py:46-79) ------------------------------------ */
 int ippm_footprint(ippm_ctx* ctx, const int32_t* pos, int32_t* rect, int32_t* rect_unclipped, int32_t n_envs,
@@ -149,9 +151,10 @@ int ippm_comm_matrix(ippm_ctx* ctx, const int64_t* episode, const int32_t* pos, 
 /* ---- K4: Agent.receive_messages -> Mapping.fuse_map(..., "local") (agent/agent.py:62-71,
  * mappings.py:82-89).  For each agent i the measurements of the received agents j != i are fused into
  * local[e,i] in ascending j; every map cell is read and written at most once.  `ws` carries the deferred
- * full-grid input clip of the reference (DESIGN.md "deferred clamp"). */
+ * full-grid input clip of the reference (DESIGN.md "deferred clamp").  agent_sel >= 0 fuses only that agent's map
+ * (drop-in Agent.receive_messages). */
 int ippm_fuse_local(ippm_ctx* ctx, float* local, const uint8_t* code, const int32_t* rect, const int32_t* pos,
-                    const uint8_t* comm, int32_t* ws, int32_t n_envs, void* stream);
+                    const uint8_t* comm, int32_t* ws, int32_t agent_sel, int32_t n_envs, void* stream);
 
 /* ---- K5: Mapping.fuse_map(..., "global") + get_global_reward (mappings.py:91-102, utils/reward.py:11-82,
  * utils/state.py:53-121).  Fuses all N measurements into global[e] in place and returns
@@ -179,6 +182,13 @@ int ippm_reward_from_maps(ippm_ctx* ctx, const float* before, const float* after
  * policy: 0 = explicit `action_in`; 1 = uniform over the valid mask (Philox); 2 = sample from
  * probs*mask (Philox, "train"); 3 = argmax of probs*mask ("eval").  probs float [E,N,A] (policy 2/3).
  * fault[e] != 0 when an agent's mask became empty (the reference's torch.multinomial raises there). */
+/* AgentActionSpace.get_action_mask (mask_in == NULL) / apply_collision_mask (mask_in = the mask to refine) for a batch
+ * of single agents: pos int32 [B,3]; others int32 [B,max_others,3] = positions of already-moved agents, n_others
+ * int32 [B] (NULL: none); masks uint8 [B,A] (agent/action_space.py:25-196,309-589). */
+int ippm_action_mask(ippm_ctx* ctx, const int32_t* pos, const int32_t* others, const int32_t* n_others,
+                     int32_t max_others, const uint8_t* mask_in, uint8_t* mask_out, int32_t* next_pos, int32_t batch,
+                     void* stream); /* next_pos int32 [B,A,3] or NULL: action_to_position for every action */
+
 int ippm_mask_act_move(ippm_ctx* ctx, const int64_t* episode, int32_t* pos, const float* probs,
                        const int32_t* action_in, int32_t policy, int32_t t, uint8_t* mask, int32_t* action,
                        int32_t* fault, int32_t n_envs, void* stream);

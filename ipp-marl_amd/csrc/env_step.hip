@@ -90,6 +90,12 @@ __global__ void k_prob_to_logodds(const float* __restrict__ src, float* __restri
   }
 }
 
+// full-grid input clip of one map (stateless drop-in fuse_map: the deferred-clamp bookkeeping has no history there)
+__global__ void k_clamp_logodds(float* __restrict__ p, float lc, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = ippm_clampl(p[i], lc);
+}
+
 // ======================================================================================================
 // K2: footprint projection
 // ======================================================================================================
@@ -307,13 +313,13 @@ __device__ __forceinline__ void plan_push(int32_t* w, int& nops, int type, int s
 
 __global__ void k_plan(const ippm_config* __restrict__ c, const int32_t* __restrict__ rect,
                        const int32_t* __restrict__ pos, const uint8_t* __restrict__ comm, int32_t* __restrict__ ws,
-                       int global_maps, int n_envs) {
+                       int global_maps, int n_envs, int agent_sel) {
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = c->n_agents;
-  const int maps = global_maps ? n_envs : n_envs * n;
-  if (tid >= maps) return;
-  const int e = global_maps ? tid : tid / n;
-  const int i = global_maps ? n : tid % n;
+  const int per = (global_maps || agent_sel >= 0) ? 1 : n;
+  if (tid >= n_envs * per) return;
+  const int e = tid / per;
+  const int i = global_maps ? n : (agent_sel >= 0 ? agent_sel : tid % n);
   int32_t* w = ws + (size_t)(e * (n + 1) + i) * IPPM_WS_WORDS;
   int nops = 0, x0 = 1 << 30, x1 = -1, y0 = 1 << 30, y1 = -1;
   int last_src = -1;
@@ -379,9 +385,11 @@ template <int VEC, bool REWARD, int NK>
 __global__ void __launch_bounds__(256)
 k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const uint8_t* __restrict__ code,
             const int32_t* __restrict__ plan_ro, int32_t* __restrict__ ws, double* __restrict__ sums,
-            unsigned long long* __restrict__ counters, int split, int min_ops) {
+            unsigned long long* __restrict__ counters, int split, int min_ops, int agent_sel) {
   const int n = c->n_agents;
-  const int m = blockIdx.x / split, part = blockIdx.x % split;  // map index: (e,i) for local maps, e for global maps
+  const int part = blockIdx.x % split;
+  // map index: (e,i) for local maps (one agent per env when agent_sel >= 0), e for global maps
+  const int m = (!REWARD && agent_sel >= 0) ? (blockIdx.x / split) * n + agent_sel : blockIdx.x / split;
   const int k = blockIdx.y;  // op whose rectangle this workgroup walks
   const int e = REWARD ? m : m / n;
   const int slot = REWARD ? n : m % n;
@@ -529,9 +537,10 @@ template <int VEC, bool REWARD>
 __global__ void __launch_bounds__(256)
 k_apply_ops_generic(const ippm_config* __restrict__ c, float* __restrict__ maps, const uint8_t* __restrict__ code,
                     int32_t* __restrict__ ws, double* __restrict__ sums, unsigned long long* __restrict__ counters, int split,
-                    int min_ops) {
+                    int min_ops, int agent_sel) {
   const int n = c->n_agents;
-  const int m = blockIdx.x / split, part = blockIdx.x % split;
+  const int part = blockIdx.x % split;
+  const int m = (!REWARD && agent_sel >= 0) ? (blockIdx.x / split) * n + agent_sel : blockIdx.x / split;
   const int e = REWARD ? m : m / n;
   const int slot = REWARD ? n : m % n;
   int32_t* w = ws + (size_t)(e * (n + 1) + slot) * IPPM_WS_WORDS;
@@ -725,6 +734,42 @@ __device__ __forceinline__ uint32_t collision_bits(int A, int dx, int dy, int dz
   return (1u << c9) | (1u << (c9 + 9)) | (1u << (c9 + 18));
 }
 
+// stand-alone mask query of the drop-in AgentActionSpace (get_action_mask / apply_collision_mask)
+__global__ void k_action_mask(const ippm_config* __restrict__ c, const int32_t* __restrict__ pos,
+                              const int32_t* __restrict__ others, const int32_t* __restrict__ n_others, int max_others,
+                              const uint8_t* __restrict__ mask_in, uint8_t* __restrict__ mask_out,
+                              int32_t* __restrict__ next_pos, int batch) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  const int A = c->n_actions;
+  const int px = pos[b * 3], py = pos[b * 3 + 1], pz = pos[b * 3 + 2];
+  if (next_pos) {  // AgentActionSpace.action_to_position for every action (action_space.py:198-307)
+    for (int a = 0; a < A; ++a) {
+      int dx, dy, dz;
+      action_offset(A, a, c->spacing, dx, dy, dz);
+      int32_t* o = next_pos + ((size_t)b * A + a) * 3;
+      o[0] = px + dx; o[1] = py + dy; o[2] = pz + dz;
+    }
+  }
+  uint32_t m = 0;
+  if (mask_in) { for (int q = 0; q < A; ++q) m |= (mask_in[(size_t)b * A + q] ? 1u : 0u) << q; }
+  else m = boundary_mask(c, px, py, pz);
+  int ix, iy, iz;
+  ippm_pos_to_index(c, px, py, pz, ix, iy, iz);
+  const int no = n_others ? n_others[b] : 0;
+  for (int j = 0; j < no; ++j) {
+    const int32_t* o = others + ((size_t)b * max_others + j) * 3;
+    int jx, jy, jz;
+    ippm_pos_to_index(c, o[0], o[1], o[2], jx, jy, jz);
+    const uint32_t z = collision_bits(A, jx - ix, jy - iy, jz - iz);
+    if (!z) continue;
+    if (A == 6) { if (__popc(m) > 1) m &= ~z; }
+    else if (A == 9) { m &= ~z; if (m == 0) m |= z; }
+    else m &= ~z;
+  }
+  for (int q = 0; q < A; ++q) mask_out[(size_t)b * A + q] = (m >> q) & 1u;
+}
+
 __global__ void k_mask_act_move(const ippm_config* __restrict__ c, const int64_t* __restrict__ episode,
                                 int32_t* __restrict__ pos, const float* __restrict__ probs,
                                 const int32_t* __restrict__ action_in, int policy, int t, uint8_t* __restrict__ mask_out,
@@ -854,6 +899,13 @@ extern "C" int ippm_prob_to_logodds(ippm_ctx* ctx, const float* src, float* dst,
   return 0;
 }
 
+extern "C" int ippm_clamp_logodds(ippm_ctx* ctx, float* maps, int64_t n, void* stream) {
+  if (!ctx || !maps) { ippm_set_error("ippm_clamp_logodds: null argument"); return -1; }
+  hipLaunchKernelGGL(k_clamp_logodds, dim3(min(4096, grid1((size_t)n))), dim3(256), 0, S_(stream), maps, ctx->cfg.logit_clip, (size_t)n);
+  IPPM_LAUNCH_CHECK("clamp_logodds");
+  return 0;
+}
+
 extern "C" int ippm_footprint(ippm_ctx* ctx, const int32_t* pos, int32_t* rect, int32_t* rect_unclipped, int32_t n_envs,
                               void* stream) {
   if (!ctx || !pos || !rect) { ippm_set_error("ippm_footprint: null argument"); return -1; }
@@ -902,35 +954,36 @@ extern "C" int ippm_comm_matrix(ippm_ctx* ctx, const int64_t* episode, const int
 // op), larger plans the generic path.  Each launch returns immediately for plans it does not own.
 template <bool REWARD>
 static void launch_apply(ippm_ctx* ctx, float* maps, const uint8_t* code, int32_t* ws, double* sums, int n_maps, int split,
-                         hipStream_t st) {
+                         hipStream_t st, int agent_sel = -1) {
   const int max_ops = ctx->cfg.n_agents + 1;
   dim3 block(256);
 #define IPPM_APPLY(V, NK, MINOPS)                                                                                      \
   hipLaunchKernelGGL((k_apply_ops<V, REWARD, NK>), dim3((unsigned)n_maps* split, std::min(max_ops, NK)), block, 0, st, \
-                     ctx->dcfg, maps, code, ws, ws, sums, ctx->dcounters, split, MINOPS)
+                     ctx->dcfg, maps, code, ws, ws, sums, ctx->dcounters, split, MINOPS, agent_sel)
   if (ctx->vec == 4) {
     IPPM_APPLY(4, 6, 1);
     if (max_ops > 6) IPPM_APPLY(4, 10, 7);
     if (max_ops > 10)
       hipLaunchKernelGGL((k_apply_ops_generic<4, REWARD>), dim3((unsigned)n_maps * 8), block, 0, st, ctx->dcfg, maps, code, ws,
-                         sums, ctx->dcounters, 8, 11);
+                         sums, ctx->dcounters, 8, 11, agent_sel);
   } else {
     IPPM_APPLY(1, 6, 1);
     if (max_ops > 6) IPPM_APPLY(1, 10, 7);
     if (max_ops > 10)
       hipLaunchKernelGGL((k_apply_ops_generic<1, REWARD>), dim3((unsigned)n_maps * 8), block, 0, st, ctx->dcfg, maps, code, ws,
-                         sums, ctx->dcounters, 8, 11);
+                         sums, ctx->dcounters, 8, 11, agent_sel);
   }
 #undef IPPM_APPLY
 }
 
 extern "C" int ippm_fuse_local(ippm_ctx* ctx, float* local, const uint8_t* code, const int32_t* rect, const int32_t* pos,
-                               const uint8_t* comm, int32_t* ws, int32_t n_envs, void* stream) {
+                               const uint8_t* comm, int32_t* ws, int32_t agent_sel, int32_t n_envs, void* stream) {
   if (!ctx || !local || !code || !rect || !pos || !comm || !ws) { ippm_set_error("ippm_fuse_local: null argument"); return -1; }
-  const int maps = n_envs * ctx->cfg.n_agents;
-  hipLaunchKernelGGL(k_plan, dim3(grid1(maps, 64)), dim3(64), 0, S_(stream), ctx->dcfg, rect, pos, comm, ws, 0, n_envs);
+  if (agent_sel >= ctx->cfg.n_agents) { ippm_set_error("ippm_fuse_local: agent_sel out of range"); return -1; }
+  const int maps = agent_sel >= 0 ? n_envs : n_envs * ctx->cfg.n_agents;
+  hipLaunchKernelGGL(k_plan, dim3(grid1(maps, 64)), dim3(64), 0, S_(stream), ctx->dcfg, rect, pos, comm, ws, 0, n_envs, agent_sel);
   IPPM_LAUNCH_CHECK("plan_local");
-  launch_apply<false>(ctx, local, code, ws, nullptr, maps, std::max(1, env_int("IPPM_SPLIT_K4", 1)), S_(stream));
+  launch_apply<false>(ctx, local, code, ws, nullptr, maps, std::max(1, env_int("IPPM_SPLIT_K4", 1)), S_(stream), agent_sel);
   IPPM_LAUNCH_CHECK("fuse_local");
   return 0;
 }
@@ -942,7 +995,7 @@ extern "C" int ippm_fuse_global_reward(ippm_ctx* ctx, float* global, const uint8
     ippm_set_error("ippm_fuse_global_reward: null argument");
     return -1;
   }
-  hipLaunchKernelGGL(k_plan, dim3(grid1(n_envs, 64)), dim3(64), 0, S_(stream), ctx->dcfg, rect, pos, nullptr, ws, 1, n_envs);
+  hipLaunchKernelGGL(k_plan, dim3(grid1(n_envs, 64)), dim3(64), 0, S_(stream), ctx->dcfg, rect, pos, nullptr, ws, 1, n_envs, -1);
   IPPM_LAUNCH_CHECK("plan_global");
   launch_apply<true>(ctx, global, code, ws, sums, n_envs, std::max(1, env_int("IPPM_SPLIT_K5", 1)), S_(stream));
   IPPM_LAUNCH_CHECK("fuse_global");
@@ -959,6 +1012,17 @@ extern "C" int ippm_weighted_entropy(ippm_ctx* ctx, const float* maps, const uin
   hipLaunchKernelGGL(k_weighted_entropy, dim3(min(32, grid1(cells)), n_maps), dim3(256), 0, S_(stream), ctx->dcfg, maps, truth,
                      out, maps_per_truth > 0 ? maps_per_truth : 1);
   IPPM_LAUNCH_CHECK("weighted_entropy");
+  return 0;
+}
+
+extern "C" int ippm_action_mask(ippm_ctx* ctx, const int32_t* pos, const int32_t* others, const int32_t* n_others,
+                                int32_t max_others, const uint8_t* mask_in, uint8_t* mask_out, int32_t* next_pos, int32_t batch,
+                                void* stream) {
+  if (!ctx || !pos || !mask_out) { ippm_set_error("ippm_action_mask: null argument"); return -1; }
+  if (n_others && !others) { ippm_set_error("ippm_action_mask: n_others without others"); return -1; }
+  hipLaunchKernelGGL(k_action_mask, dim3(grid1(batch, 64)), dim3(64), 0, S_(stream), ctx->dcfg, pos, others, n_others, max_others,
+                     mask_in, mask_out, next_pos, batch);
+  IPPM_LAUNCH_CHECK("action_mask");
   return 0;
 }
 

@@ -1,0 +1,138 @@
+"""Per-episode device engine behind the drop-in classes (Mapping / Agent / COMAWrapper).
+
+One ``EpisodeEngine`` = a VecEnv with a single environment whose device tensors are the source of truth; the
+reference-shaped objects are views that upload/download NumPy arrays at the API boundary (probabilities outside,
+log-odds inside).  Throughput work uses VecEnv / COMATrainer directly; this layer exists so that code written against
+the reference's object surface runs unchanged on the HIP kernels.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _ffi
+from .vec_env import VecEnv
+
+_ENGINE_SEED = 3
+
+
+class Measurement(np.ndarray):
+    """A ``map2communicate`` array (0.5 outside the footprint, measurement inside) that remembers which footprint,
+    altitude level and observation codes it was built from, so it can go back to the device without re-deriving them."""
+
+    def __new__(cls, array, rect=None, alt_index=None, codes=None):
+        obj = np.asarray(array).view(cls)
+        obj.rect, obj.alt_index, obj.codes = rect, alt_index, codes
+        return obj
+
+    def __array_finalize__(self, obj):
+        if obj is None:
+            return
+        self.rect = getattr(obj, "rect", None)
+        self.alt_index = getattr(obj, "alt_index", None)
+        self.codes = getattr(obj, "codes", None)
+
+
+class EpisodeEngine:
+    def __init__(self, params: Dict, episode: int, device: str = "cuda:0", philox_seed: int = _ENGINE_SEED):
+        self.env = VecEnv(params, 1, device=device, philox_seed=philox_seed)
+        self.d = self.env.d
+        self.episode = int(episode)
+        env = self.env
+        env.episode.fill_(self.episode)
+        # truth, start cells, per-episode comm range, prior maps, workspace -- but no sensing yet (agents do that)
+        env.ctx.call("ippm_reset_episode", env._p(env.episode), env._p(env.pos), env._p(env.truth), env._p(env.local),
+                     env._p(env.glob), env._p(env.split_pct), env._p(env.comm_range), env._p(env.ws), env._p(env.sums), 1,
+                     env.stream)
+        self.start_positions = env.pos[0].cpu().numpy().astype(np.int64)
+        self.stage = [0] * self.d.n_agents  # per-agent sensing counter = Philox stage
+
+    # ---- maps -------------------------------------------------------------------------------------------
+    def _to_logodds(self, prob: np.ndarray) -> torch.Tensor:
+        src = torch.from_numpy(np.ascontiguousarray(prob, dtype=np.float32)).to(self.env.device)
+        dst = torch.empty_like(src)
+        self.env.ctx.call("ippm_prob_to_logodds", _ffi.ptr(src), _ffi.ptr(dst), src.numel(), self.env.stream)
+        return dst
+
+    def _to_prob(self, logodds: torch.Tensor) -> np.ndarray:
+        return self.env._to_prob(logodds.contiguous()).cpu().numpy()
+
+    def get_local(self, i: int) -> np.ndarray:
+        return self._to_prob(self.env.local[0, i])
+
+    def set_local(self, i: int, prob: np.ndarray):
+        self.env.local[0, i].copy_(self._to_logodds(prob))
+        # an externally supplied map may hold out-of-range values anywhere: make the next fusion clip it all
+        ws = self.env.ws[0, i]
+        ws[0] = 1
+        ws[1:5] = torch.tensor([0, self.d.grid_y, 0, self.d.grid_x], dtype=torch.int32, device=self.env.device)
+
+    def get_global(self) -> np.ndarray:
+        return self._to_prob(self.env.glob[0])
+
+    def set_global(self, prob: np.ndarray):
+        env = self.env
+        env.glob[0].copy_(self._to_logodds(prob))
+        ws = env.ws[0, self.d.n_agents]
+        ws[0] = 1
+        ws[1:5] = torch.tensor([0, self.d.grid_y, 0, self.d.grid_x], dtype=torch.int32, device=env.device)
+        out = torch.zeros(1, dtype=torch.float64, device=env.device)
+        env.ctx.call("ippm_weighted_entropy", env._p(env.glob), None, 1, _ffi.ptr(out), 1, env.stream)
+        env.sums[0, 2] = out[0]
+
+    # ---- measurements -----------------------------------------------------------------------------------
+    def measurement_views(self, i: int):
+        """(map2communicate [gx,gy] float32 Measurement, footprint_img [2r,2r] float64, clipped rect, cell_update view)."""
+        d, env = self.d, self.env
+        yu, yd, xl, xr = (int(v) for v in env.rect[0, i].cpu())
+        pos = env.pos[0, i].cpu().numpy()
+        k = min(max((int(pos[2]) - d.min_altitude) // d.spacing, 0), d.space_z - 1)
+        off = yu & 3
+        codes = env.code[0, i, : xr - xl, off: off + yd - yu].cpu().numpy()
+        meas = np.where(codes > 0, d.meas_value[k, 1], d.meas_value[k, 0]).astype(np.float32)
+        m2c = np.full((d.grid_x, d.grid_y), 0.5, dtype=np.float32)
+        m2c[xl:xr, yu:yd] = meas
+        full, _ = d.footprint(pos)
+        img = np.ones((full[1] - full[0], full[3] - full[2])) * 0.5
+        hx, wy = xr - xl, yd - yu
+        xo = (full[3] - full[2]) - hx if xl > full[2] else 0
+        yo = (full[1] - full[0]) - wy if yu > full[0] else 0
+        img[xo: xo + hx, yo: yo + wy] = meas
+        return Measurement(m2c, rect=[yu, yd, xl, xr], alt_index=k, codes=codes), img, [yu, yd, xl, xr]
+
+    def load_measurement(self, slot: int, m2c: np.ndarray):
+        """Puts a map2communicate array back into measurement slot ``slot`` (rect, altitude level, codes)."""
+        d, env = self.d, self.env
+        rect, k, codes = getattr(m2c, "rect", None), getattr(m2c, "alt_index", None), getattr(m2c, "codes", None)
+        if rect is None or codes is None or k is None:  # a plain array: recover footprint, level and codes from its values
+            arr = np.asarray(m2c)
+            hit = np.abs(arr - 0.5) > 0.01
+            if not hit.any():
+                rect, k, codes = [0, 0, 0, 0], 0, np.zeros((0, 0), dtype=np.uint8)
+            else:
+                xs, ys = np.where(hit.any(axis=1))[0], np.where(hit.any(axis=0))[0]
+                xl, xr, yu, yd = int(xs[0]), int(xs[-1]) + 1, int(ys[0]), int(ys[-1]) + 1
+                vals = arr[xl:xr, yu:yd]
+                hi = float(vals.max()) if (vals > 0.5).any() else 1.0 - float(vals.min())
+                k = int(np.argmin(np.abs(d.meas_value[:, 1] - hi)))
+                rect, codes = [yu, yd, xl, xr], (vals > 0.5).astype(np.uint8)
+        yu, yd, xl, xr = rect
+        tile = np.zeros((d.tile_stride, d.tile_stride), dtype=np.uint8)
+        tile[: xr - xl, (yu & 3): (yu & 3) + yd - yu] = codes
+        env.code[0, slot].copy_(torch.from_numpy(tile).to(env.device))
+        env.rect[0, slot].copy_(torch.tensor(rect, dtype=torch.int32))
+        # altitude level of the slot is read from pos[...,2] by the kernels
+        env.pos[0, slot, 2] = d.altitudes[k]
+
+
+_engines: Dict[int, EpisodeEngine] = {}
+
+
+def scratch_engine(params: Dict) -> EpisodeEngine:
+    """A shared engine for stateless calls (Camera, AgentActionSpace, get_global_reward, ...)."""
+    key = id(params)
+    if key not in _engines:
+        _engines[key] = EpisodeEngine(params, 1)
+    return _engines[key]

@@ -62,6 +62,19 @@ class ActorNetwork(_ConvTrunk):
     def eps(self, num_episode: int) -> float:
         return epsilon_schedule(self.params, num_episode)
 
+    def get_action_index(self, batch_memory, action_mask_1d, agent_id, t, num_episode: int, mode: str):
+        """Single-agent action choice of the drop-in Agent.step (actor/network.py:41-68,90-96): masked eps-softmax,
+        torch.multinomial in training, argmax in evaluation."""
+        device = next(self.parameters()).device
+        obs = batch_memory.get(-1, agent_id, "observation").unsqueeze(0).to(device).float()
+        mask = torch.as_tensor(action_mask_1d).to(device)
+        eps = epsilon_schedule(self.params, num_episode)
+        with torch.no_grad():
+            probs, _ = self.forward(obs, eps)
+        probs = probs.squeeze() * mask
+        chosen = torch.argmax(probs) if mode == "eval" else torch.multinomial(probs, 1, replacement=True)
+        return probs, chosen, mask, eps
+
 
 class CriticNetwork(_ConvTrunk):
     def __init__(self, params: Dict):

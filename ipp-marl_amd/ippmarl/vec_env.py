@@ -118,14 +118,29 @@ class VecEnv:
                       self._p(flips), self._p(self.code), self._p(self.rect), self._p(self.ws), stage, agent, self.E,
                       self.stream)
 
-    def build_observations(self, t: int, comm_draws: Optional[torch.Tensor] = None, features: bool = True):
-        """comm matrix -> local fusion (K4) -> actor observation [E,N,11,11,7] (K6)."""
+    def comm_matrix(self, t: int, comm_draws: Optional[torch.Tensor] = None):
         self.ctx.call("ippm_comm_matrix", self._p(self.episode), self._p(self.pos), self._p(self.comm_range),
                       self._p(comm_draws), self._p(self.comm), t, self.E, self.stream)
+
+    def fuse_local(self, agent: int = -1):
         self.ctx.call("ippm_fuse_local", self._p(self.local), self._p(self.code), self._p(self.rect), self._p(self.pos),
-                      self._p(self.comm), self._p(self.ws), self.E, self.stream)
+                      self._p(self.comm), self._p(self.ws), agent, self.E, self.stream)
+
+    def build_observations(self, t: int, comm_draws: Optional[torch.Tensor] = None, features: bool = True):
+        """comm matrix -> local fusion (K4) -> actor observation [E,N,11,11,7] (K6)."""
+        self.comm_matrix(t, comm_draws)
+        self.fuse_local()
         if not features:
             return None
+        if self.obs is None:
+            self.obs = torch.empty(self.E, self.d.n_agents, _ffi.FEAT, _ffi.FEAT, _ffi.ACTOR_PLANES, dtype=torch.float32,
+                                   device=self.device)
+        self.ctx.call("ippm_actor_features", self._p(self.local), self._p(self.code), self._p(self.rect), self._p(self.pos),
+                      self._p(self.comm), t, self._p(self.obs), self.E, self.stream)
+        return self.obs
+
+    def build_features_only(self, t: int):
+        """K6 actor features from the current device state (used by the drop-in transformations)."""
         if self.obs is None:
             self.obs = torch.empty(self.E, self.d.n_agents, _ffi.FEAT, _ffi.FEAT, _ffi.ACTOR_PLANES, dtype=torch.float32,
                                    device=self.device)

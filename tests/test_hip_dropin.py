@@ -1,0 +1,174 @@
+"""GPU tests of the drop-in object surface (COMAWrapper / Agent / Mapping / AgentActionSpace / ... with the reference's
+signatures), driven the way the reference's own scripts drive them and checked against the reference's recorded outputs."""
+import numpy as np
+import pytest
+
+import ipp_oracle as O
+from configs import make_params
+from conftest import assert_posteriors, unpack_correctness
+from test_oracle_golden import EPISODES
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+@pytest.mark.parametrize("tag", ["episode_c2_e1", "episode_small5_e3"])
+def test_episode_generator_replays_reference_episode(golden, tag, monkeypatch):
+    """EpisodeGenerator.execute(...) exactly as missions/coma_mission.py calls it, with the recorded randomness."""
+    from ippmarl.batch_memory import BatchMemory
+    from ippmarl.coma_wrapper import COMAWrapper, ReplayHooks
+    from ippmarl.mapping.grid_maps import GridMap
+    from ippmarl.missions.episode_generator import EpisodeGenerator
+    from ippmarl.sensors import Sensor
+    from ippmarl.sensors.models import SensorModel
+    fx = golden(tag)
+    params = make_params(EPISODES[tag]["name"], **EPISODES[tag]["over"])
+    n = params["experiment"]["missions"]["n_agents"]
+    T = params["experiment"]["constraints"]["budget"] + 1
+    corr = unpack_correctness(fx)
+    draws = iter(fx["comm_draws"])
+    monkeypatch.setattr(np.random, "random_sample", lambda *a, **k: next(draws))
+    wrapper = COMAWrapper(params, None)
+    wrapper.replay = ReplayHooks(correctness=lambda agent_id, stage: corr[stage * n + agent_id],
+                                 action=lambda agent_id, t: int(fx["actions"][t, agent_id]))
+    memory = BatchMemory(params, wrapper)
+    grid_map = GridMap(params)
+    generator = EpisodeGenerator(params, None, grid_map, Sensor(SensorModel(), grid_map))
+    mode = "eval" if tag == "episode_small5_e3" else "train"
+    (episode_return, episode_rewards, absolute_return, simulated_map, memory, agent_positions, t_last, eps, agent_actions,
+     agent_altitudes) = generator.execute(int(fx["episode"]), memory, wrapper, mode)
+    assert np.array_equal(simulated_map.astype(np.uint8), fx["truth"])
+    assert np.array_equal(np.array(agent_positions), fx["positions"])           # [T+1, n, 3], bit-exact
+    assert np.array_equal(np.array(agent_actions), fx["actions"])
+    np.testing.assert_allclose(episode_rewards, fx["episode_rewards"], rtol=RTOL, atol=1e-6)
+    np.testing.assert_allclose(episode_return, fx["episode_return"], rtol=RTOL)
+    np.testing.assert_allclose(absolute_return, fx["abs_return"], rtol=RTOL)
+    np.testing.assert_allclose(eps, fx["eps"], rtol=1e-12)
+    assert t_last == T - 1 and memory.size() == T * n
+    for t in range(T):
+        for a in range(n):
+            tr = memory.transitions[a][t]
+            assert np.array_equal(tr.mask.cpu().numpy(), fx["masks"][t, a])
+            np.testing.assert_allclose(tr.observation.cpu().numpy(), fx["obs"][t, a], rtol=RTOL, atol=2e-6)
+            np.testing.assert_allclose(tr.state.cpu().numpy(), fx["state"][t, a], rtol=RTOL, atol=2e-6)
+            assert tr.done == bool(fx["done"][t, a]) and abs(tr.reward - fx["rewards"][t, a]) <= 1e-5 * abs(fx["rewards"][t, a]) + 1e-6
+    assert_posteriors(np.array([ag.local_map for ag in generator.agents]), fx["final_local"], strict=False, msg="final local")
+
+
+def test_action_space_matches_reference_tables(golden):
+    from ippmarl.agent.action_space import AgentActionSpace
+    from ippmarl.agent.state_space import AgentStateSpace
+    fx = golden("masks")
+    for A in (6, 27):
+        params = make_params("default", experiment__constraints__num_actions=A)
+        asp, ss = AgentActionSpace(params), AgentStateSpace(params)
+        for pos, want in list(zip(fx[f"a{A}_pos"], fx[f"a{A}_mask"]))[::7]:
+            flat, _ = asp.get_action_mask(pos)
+            assert np.array_equal(flat, want), (A, pos)
+        base = np.array([25, 25, 10])
+        assert np.array_equal(np.array([asp.action_to_position(base, a) for a in range(A)]), fx[f"a{A}_moves"])
+        for pos, others, k, m_in, m_out in list(zip(fx[f"a{A}_col_pos"], fx[f"a{A}_col_others"], fx[f"a{A}_col_n"],
+                                                    fx[f"a{A}_col_in"], fx[f"a{A}_col_out"]))[:200]:
+            got = asp.apply_collision_mask(pos, m_in.copy(), [others[j] for j in range(k)], ss)
+            assert np.array_equal(got, m_out), (A, pos, others[:k])
+
+
+def test_camera_and_state_space(golden):
+    from ippmarl.agent.state_space import AgentStateSpace
+    from ippmarl.mapping.grid_maps import GridMap
+    from ippmarl.sensors.cameras import Camera
+    from ippmarl.sensors.models.sensor_models import AltitudeSensorModel
+    fx = golden("derived_footprints")
+    params = make_params("c2")
+    gm, ss = GridMap(params), AgentStateSpace(params)
+    cam = Camera(params, AltitudeSensorModel(params), gm)
+    k = 0
+    for x in range(11):
+        for y in range(11):
+            for z in range(3):
+                if k % 11 == 0:
+                    full, clip = cam.project_field_of_view(ss.index_to_position([x, y, z]), gm.resolution_x, gm.resolution_y)
+                    assert full == list(fx["c2_fp_full"][k]) and clip == list(fx["c2_fp_clip"][k])
+                k += 1
+    st = golden("start_states")["seed3"]
+    assert np.array_equal(np.array([[ss.get_random_agent_state(a, e) for a in range(4)] for e in range(1, 9)]), st[:8, :4])
+    assert AltitudeSensorModel(params).get_noise_variance(10) == 0.265
+
+
+def test_mapping_update_fuse_and_reward_standalone(golden):
+    """Mapping.update_grid_map / fuse_map / get_global_reward on plain NumPy arrays, against the oracle."""
+    from ippmarl.mapping.grid_maps import GridMap
+    from ippmarl.mapping.mappings import Mapping
+    from ippmarl.sensors import Sensor
+    from ippmarl.sensors.models import SensorModel
+    from ippmarl.utils.reward import get_global_reward
+    from ippmarl.agent.state_space import AgentStateSpace
+    params = make_params("small")
+    d = O.Derived(params)
+    d.exact = True
+    gm = GridMap(params)
+    mapping = Mapping(gm, Sensor(SensorModel(), gm), params, 4)
+    truth = O.make_truth(d, 4)
+    assert np.array_equal(mapping.simulated_map, truth)
+    rng = np.random.RandomState(2)
+    maps, infos = [], {}
+    for i, pos in enumerate([[10, 15, 15], [20, 15, 10], [15, 20, 5]]):
+        pos = np.array(pos)
+        _, fc = O.project_field_of_view(d, pos)
+        corr = (rng.random_sample(O.tile_shape(fc)) > 0.3).astype(np.int64)
+        mine = mapping.init_priors()
+        ref = O.init_prior_map(d)
+        out = mapping.update_grid_map(pos, mine, 0, "train", agent_id=i, correctness=corr)
+        want = O.update_grid_map(d, truth, pos, ref, corr)
+        assert out[0] is mine and out[2] == want[2]                           # in-place mutation, same rect
+        assert_posteriors(mine, ref, strict=True, msg="update_grid_map")
+        np.testing.assert_array_equal(np.asarray(out[3]), want[3].astype(np.float32))   # map2communicate
+        np.testing.assert_allclose(out[4], want[4], rtol=1e-7)                          # footprint_img
+        maps.append(mine)
+        infos[i] = {"map2communicate": out[3]}
+        infos_ref = infos
+    fused = mapping.fuse_map(maps[0], infos, 0, "local")
+    want = O.fuse_map(d, maps[0].astype(np.float64), {k: {"map2communicate": np.asarray(v["map2communicate"])} for k, v in infos.items()}, 0, "local")
+    assert_posteriors(fused, want, strict=True, msg="fuse_map local")
+    glob = mapping.fuse_map(mapping.init_priors(), [np.asarray(infos[k]["map2communicate"]) for k in (0, 1, 2)], None, "global")
+    want_g = O.fuse_map(d, O.init_prior_map(d), [np.asarray(infos[k]["map2communicate"]) for k in (0, 1, 2)], None, "global")
+    assert_posteriors(glob, want_g, strict=True, msg="fuse_map global (plain arrays)")
+    done, rel, ab = get_global_reward(mapping.init_priors(), glob, "COMA", None, truth, AgentStateSpace(params), None, None, 0, 14)
+    _, rel_w, ab_w = O.global_reward(d, O.init_prior_map(d), want_g, truth)
+    assert done is False
+    np.testing.assert_allclose([rel, ab], [rel_w, ab_w], rtol=RTOL, atol=1e-6)
+
+
+def test_batch_memory_td_targets(golden):
+    from ippmarl.batch_memory import BatchMemory
+    fx = golden("td_lambda")
+    params = make_params("default")
+    n, L = fx["rewards"].shape
+
+    class TableCritic(torch.nn.Module):
+        def __init__(self, table):
+            super().__init__()
+            self.table = torch.nn.Parameter(torch.tensor(table), requires_grad=False)
+
+        def forward(self, state):
+            return self.table[state.view(-1).long()], None
+
+    rng = np.random.RandomState(0)
+    actions = rng.randint(0, 6, size=(n, L))
+    table = rng.standard_normal((n * L, 6)).astype(np.float32)
+    for a in range(n):
+        for i in range(L):
+            table[a * L + i, actions[a, i]] = fx["qsel"][a, i]
+    bm = BatchMemory(params, None)
+    for a in range(n):
+        for i in range(L):
+            bm.add(a, state=torch.tensor([float(a * L + i)]), action=torch.tensor([actions[a, i]]), reward=float(fx["rewards"][a, i]),
+                   done=bool(fx["dones"][a, i]))
+    bm.build_td_targets(TableCritic(table))
+    td = np.array([[float(bm.transitions[a][i].td_target) for i in range(L)] for a in range(n)])
+    dr = np.array([[float(bm.transitions[a][i].discounted_return) for i in range(L)] for a in range(n)])
+    np.testing.assert_allclose(td, fx["td"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(dr, fx["dr"], rtol=2e-5, atol=2e-6)
+    batches = bm.build_batches()
+    assert len(batches) == (n * L) // 60 and all(len(b) == 60 for b in batches)

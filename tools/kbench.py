@@ -55,7 +55,7 @@ def main():
 
         def k4():
             env.ctx.call("ippm_fuse_local", env._p(env.local), env._p(env.code), env._p(env.rect), env._p(env.pos), env._p(env.comm),
-                         env._p(env.ws), E, env.stream)
+                         env._p(env.ws), -1, E, env.stream)
 
         def k5():
             env.ctx.call("ippm_fuse_global_reward", env._p(env.glob), env._p(env.code), env._p(env.rect), env._p(env.pos),
