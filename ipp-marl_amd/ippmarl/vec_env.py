@@ -61,6 +61,12 @@ class VecEnv:
         self.obs = None
         self.state = None
         self.t = 0
+        # K5 (global fusion + reward) only reads what K3 of the previous step wrote and touches no array K4 / K6 /
+        # the actor use, so it runs on a side stream concurrently with them (both are latency-bound kernels with
+        # spare occupancy); steps() joins before K1.
+        self.overlap = True
+        self.side = torch.cuda.Stream(device=self.device)
+        self._k5_done = None
 
     # ------------------------------------------------------------------------------------------------
     @property
@@ -126,8 +132,19 @@ class VecEnv:
         self.ctx.call("ippm_fuse_local", self._p(self.local), self._p(self.code), self._p(self.rect), self._p(self.pos),
                       self._p(self.comm), self._p(self.ws), agent, self.E, self.stream)
 
+    def _launch_k5(self, stream_ptr):
+        self.ctx.call("ippm_fuse_global_reward", self._p(self.glob), self._p(self.code), self._p(self.rect), self._p(self.pos),
+                      self._p(self.ws), self._p(self.sums), self._p(self.reward), self.E, stream_ptr)
+
     def build_observations(self, t: int, comm_draws: Optional[torch.Tensor] = None, features: bool = True):
-        """comm matrix -> local fusion (K4) -> actor observation [E,N,11,11,7] (K6)."""
+        """comm matrix -> local fusion (K4) -> actor observation [E,N,11,11,7] (K6).  With ``overlap`` the global
+        fusion of the same published measurements (K5, logically the first thing steps() does) is started on the side
+        stream here."""
+        if self.overlap:
+            main = torch.cuda.current_stream(self.device)
+            self.side.wait_stream(main)
+            self._launch_k5(self.side.cuda_stream)
+            self._k5_done = self.side.record_event()
         self.comm_matrix(t, comm_draws)
         self.fuse_local()
         if not features:
@@ -154,8 +171,11 @@ class VecEnv:
 
         Returns (reward [E,2] = (relative, absolute), done: bool, state [E,N,11,11,12] or None)."""
         d = self.d
-        self.ctx.call("ippm_fuse_global_reward", self._p(self.glob), self._p(self.code), self._p(self.rect), self._p(self.pos),
-                      self._p(self.ws), self._p(self.sums), self._p(self.reward), self.E, self.stream)
+        if self._k5_done is not None:   # started by build_observations on the side stream
+            torch.cuda.current_stream(self.device).wait_event(self._k5_done)
+            self._k5_done = None
+        else:
+            self._launch_k5(self.stream)
         if features:
             self.pos_pre.copy_(self.pos)
         if probs is not None:
