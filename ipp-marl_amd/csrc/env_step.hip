@@ -425,6 +425,58 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
   bool exceed = false;
   float a1 = 0.f, aD = 0.f, aT = 0.f;
   unsigned cells = 0, opcells = 0;
+  // Does any other op's rectangle intersect the rows/columns this workgroup walks?  If not (the common case) every
+  // group is covered by op k alone: a short branch-free loop does the job.
+  bool alone = true;
+#pragma unroll
+  for (int o = 0; o < NK; ++o) {
+    const bool hit = op[o].xl < kxl + r1 && op[o].xr > kxl + r0 && op[o].yu < kyd && op[o].yd > kyu;
+    alone &= (o == k) || !hit;
+  }
+  if (alone) {
+    int kinfo = 0;
+#pragma unroll
+    for (int o = 0; o < NK; ++o)
+      if (o == k) kinfo = op[o].info;
+    const bool isf = (kinfo & 0xFF) != 0;
+    const int alt = (kinfo >> 16) & 0xFF;
+    const float lm0 = isf ? c->logit_meas[alt][0] : 0.f, lm1 = isf ? c->logit_meas[alt][1] : 0.f;
+    const uint8_t* ctile = code_e + (size_t)((kinfo >> 8) & 0xFF) * S * S - (kyu & ~3);
+    const int wdt = kyd - kyu;
+    for (int gi = gl; gi < g.groups; gi += g.lpr) {
+      const int y = g.y0 + gi * VEC;
+      unsigned inm = 0;
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) inm |= ((unsigned)(y + q - kyu) < (unsigned)wdt) ? (1u << q) : 0u;
+      for (int row = r0 + wv * g.rpw + sub; row < r1; row += 4 * g.rpw) {
+        const size_t cell = (size_t)(kxl + row) * gy + y;
+        CellVec<VEC> mv = load_cells<VEC>(map + cell);
+        uint32_t cw = 0;
+        if (isf) cw = load_bytes<VEC>(ctile + (size_t)row * S + y);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+          const float b = mv.v[q];
+          float a = ippm_clampl(b, lc) + (((cw >> (8 * q)) & 1u) ? lm1 : lm0);
+          a = k_is_last ? a : ippm_clampl(a, lc);
+          const bool in = (inm >> q) & 1u;
+          a = in ? a : b;
+          exceed |= fabsf(a) > lc && in;
+          mv.v[q] = a;
+          if (REWARD) {
+            const float sel = (in && isf) ? 1.f : 0.f;
+            const float wa = ippm_weight_l(a, wt), wb = ippm_weight_l(b, wt);
+            const float hb = ippm_entropy_l(b, lc), ha = ippm_entropy_l(a, lc);
+            a1 += sel * (wa * (hb - ha));
+            aD += sel * ((wa - wb) * hb);
+            aT += sel * (wa * ha - wb * hb);
+          }
+        }
+        cells += __popc(inm);
+        store_cells<VEC>(map + cell, mv);
+      }
+    }
+    opcells = cells;
+  } else {
   using Mask = typename std::conditional<(NK * VEC > 32), unsigned long long, unsigned>::type;
   static_assert(NK * VEC <= 64, "op masks are at most 64 bits");
   constexpr unsigned QM = (1u << VEC) - 1u;
@@ -512,6 +564,7 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
       store_cells<VEC>(map + cell, mv);
     }
   }
+  }  // !alone
   if (__any(exceed) && lane == 0) ws[wbase + WS_FLAG_A] = 1;
   // block reduction of the reward terms and work counters: one atomic per workgroup and quantity
   {
