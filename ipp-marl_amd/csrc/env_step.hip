@@ -430,7 +430,10 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
   bool alone = true;
 #pragma unroll
   for (int o = 0; o < NK; ++o) {
-    const bool hit = op[o].xl < kxl + r1 && op[o].xr > kxl + r0 && op[o].yu < kyd && op[o].yd > kyu;
+    // column ranges widened to whole VEC-cell groups: ownership is decided per group, so two rectangles that merely
+    // share an edge group already interact
+    const bool hit = op[o].xl < kxl + r1 && op[o].xr > kxl + r0 && (op[o].yu & ~(VEC - 1)) < ((kyd + VEC - 1) & ~(VEC - 1)) &&
+                     ((op[o].yd + VEC - 1) & ~(VEC - 1)) > (kyu & ~(VEC - 1));
     alone &= (o == k) || !hit;
   }
   if (alone) {
