@@ -99,6 +99,9 @@ def _oracle_philox_episode(params, episode, seed, learned_probs=None):
     ("small", dict(experiment__uav__failure_rate=0.35, experiment__uav__fix_range=False, experiment__missions__n_agents=6), 4),
     ("c2", dict(), 3),
     ("default", dict(experiment__missions__n_agents=3), 2),  # 493 cells: grid_y % 4 != 0 -> scalar path
+    ("c4", dict(), 1),                                        # BASELINE config 4 shape: 8 UAVs, 512 x 512 (9-op plans)
+    ("c5", dict(experiment__missions__n_agents=3), 1),        # config 5 shape: 27 actions, 1024 x 1024, per-episode comm range
+    ("small", dict(experiment__missions__n_agents=12, experiment__uav__communication_range=100), 1),  # >10 ops: generic fusion path
 ])
 def test_production_randomness_matches_oracle(name, over, n_envs):
     """Philox mode (what bench/training use): device RNG streams, uniform random policy, every step vs the oracle."""
