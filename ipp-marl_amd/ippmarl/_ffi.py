@@ -6,6 +6,9 @@ import os
 from typing import Optional
 
 import numpy as np
+import torch  # noqa: F401  -- must be imported BEFORE libippmarl.so is dlopen'ed: both link libamdhip64.so.7 and the process
+#                            must end up with ONE HIP runtime (torch's), otherwise stream handles and device pointers
+#                            handed over by torch belong to a different runtime ("no ROCm-capable device is detected")
 
 from .derived import DerivedConstants, MAX_LATTICE, MAX_Z, CLIP_LO, CLIP_HI
 

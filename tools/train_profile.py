@@ -1,0 +1,20 @@
+#!/usr/bin/env python
+"""One warm-up round + one timed COMA round (rollout with the actor, TD targets, 25+25 Adam steps) for rocprofv3."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for sub in ("oracle", "ipp-marl_amd"):
+    sys.path.insert(0, os.path.join(ROOT, sub))
+import torch  # noqa: E402
+
+from ippmarl.params import grid256_params  # noqa: E402
+from ippmarl.trainer import COMATrainer  # noqa: E402
+
+tr = COMATrainer(grid256_params(), int(os.environ.get("ENVS", 1024)))
+tr.rollout("train"); tr.update()
+torch.cuda.synchronize()
+t0 = time.perf_counter(); tr.rollout("train"); torch.cuda.synchronize(); t1 = time.perf_counter()
+tr.update(); torch.cuda.synchronize(); t2 = time.perf_counter()
+print(f"rollout {t1 - t0:.3f}s update {t2 - t1:.3f}s")
