@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--profile-events", type=int, default=1, help="time every K3 launch with HIP events (roofline)")
     ap.add_argument("--train-rounds", type=int, default=2, help="COMA rounds (rollout with the actor + full update) timed after "
                     "the env-only region for the COMA updates/s figure; 0 disables")
+    ap.add_argument("--graphs", type=int, default=1, help="replay the launch-bound part of each step (comm, K4, K5, K1) from "
+                    "hipGraphs; K3 stays an ordinary launch bracketed by events")
     ap.add_argument("--calib", action="store_true", help="PMC calibration: 3 device-to-device clones of the local maps (known "
                     "bytes read and written by a 16 B/lane streaming kernel) before the timed loop")
     args = ap.parse_args()
@@ -130,10 +132,15 @@ def main():
 
     def one_step(t, timed):
         timing[0] = timed
-        env.build_observations(t, features=False)
-        env.steps(t, policy=POLICY_UNIFORM, features=False)
+        if args.graphs:
+            env.step_graphed(t)
+        else:
+            env.build_observations(t, features=False)
+            env.steps(t, policy=POLICY_UNIFORM, features=False)
 
     reset()
+    if args.graphs:
+        env.capture_step_graphs(POLICY_UNIFORM)
     if args.calib:
         for _ in range(3):
             env.local.clone()
@@ -228,7 +235,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (device-generated half-plane truth, Philox sensor noise)",
             "config": {"workload": "BASELINE.json configs[1]: 4 UAVs, 256x256 grid, 1024 batched envs per GPU, random policy, "
                                    "env-step kernels only", "envs_per_gpu": E, "n_agents": N, "grid": grid,
-                       "episode_steps": T, "parallelism": f"env-sharded x{world} (no data-path collective)"},
+                       "episode_steps": T, "parallelism": f"env-sharded x{world} (no data-path collective)", "hip_graphs": bool(args.graphs)},
             "faults": faults,
             "cells": counters,
             "roofline": roofline,

@@ -165,25 +165,29 @@ class VecEnv:
                       self._p(self.comm), t, self._p(self.obs), self.E, self.stream)
         return self.obs
 
+    def _fuse_act_move(self, t: int, policy: int, probs, actions):
+        """K5 (or its join) + K1: everything of steps() that precedes the critic features and the sensing."""
+        if self._k5_done is not None:   # started by build_observations on the side stream
+            torch.cuda.current_stream(self.device).wait_event(self._k5_done)
+            self._k5_done = None
+        else:
+            self._launch_k5(self.stream)
+        self.ctx.call("ippm_mask_act_move", self._p(self.episode), self._p(self.pos), self._p(probs), self._p(actions), policy, t,
+                      self._p(self.mask), self._p(self.action), self._p(self.fault), self.E, self.stream)
+
     def steps(self, t: int, policy: int = POLICY_UNIFORM, probs: Optional[torch.Tensor] = None,
               actions: Optional[torch.Tensor] = None, flips: Optional[torch.Tensor] = None, features: bool = True):
         """K5 (global fusion + reward of the measurements published this step), K1, critic features, K3.
 
         Returns (reward [E,2] = (relative, absolute), done: bool, state [E,N,11,11,12] or None)."""
         d = self.d
-        if self._k5_done is not None:   # started by build_observations on the side stream
-            torch.cuda.current_stream(self.device).wait_event(self._k5_done)
-            self._k5_done = None
-        else:
-            self._launch_k5(self.stream)
         if features:
             self.pos_pre.copy_(self.pos)
         if probs is not None:
             probs = probs.to(torch.float32).contiguous()
         if actions is not None:
             actions = actions.to(self.device, torch.int32).contiguous()
-        self.ctx.call("ippm_mask_act_move", self._p(self.episode), self._p(self.pos), self._p(probs), self._p(actions), policy, t,
-                      self._p(self.mask), self._p(self.action), self._p(self.fault), self.E, self.stream)
+        self._fuse_act_move(t, policy, probs, actions)
         state = None
         if features:
             if self.obs is None:
@@ -198,6 +202,34 @@ class VecEnv:
         self.sense(stage=t + 1, flips=flips)
         self.t = t + 1
         return self.reward, t == d.budget, state
+
+    # ---- hipGraph replay of the launch-bound part of a random-policy step ------------------------------------
+    def capture_step_graphs(self, policy: int = POLICY_UNIFORM):
+        """Captures, for every t of an episode, the fixed launch sequence {K5 on the side stream || comm + K4} -> K1
+        into a hipGraph (the per-step arguments t / stage are baked in, all arrays are fixed device buffers).  The
+        sensing kernel K3 stays an ordinary launch so that callers can bracket it with events."""
+        graphs = []
+        torch.cuda.synchronize(self.device)
+        saved = {k: getattr(self, k).clone() for k in ("local", "glob", "ws", "sums", "pos", "comm", "mask", "action", "fault", "reward")}
+        capture_stream = torch.cuda.Stream(device=self.device)
+        for t in range(self.d.budget + 1):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=capture_stream):
+                self.build_observations(t, features=False)
+                self._fuse_act_move(t, policy, None, None)
+            graphs.append(g)
+        torch.cuda.synchronize(self.device)
+        for k, v in saved.items():   # capture does not execute, but keep the state untouched in any case
+            getattr(self, k).copy_(v)
+        self._graphs = graphs
+        return graphs
+
+    def step_graphed(self, t: int):
+        """One random-policy env step: graph replay (comm, K4, K5, K1) + K3."""
+        self._graphs[t].replay()
+        self.sense(stage=t + 1)
+        self.t = t + 1
+        return self.reward, t == self.d.budget
 
     # ------------------------------------------------------------------------------------------------
     def counters(self, reset: bool = False) -> dict:
