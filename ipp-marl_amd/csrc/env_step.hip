@@ -385,7 +385,7 @@ template <int VEC, bool REWARD, int NK>
 __global__ void __launch_bounds__(256)
 k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const uint8_t* __restrict__ code,
             const int32_t* __restrict__ plan_ro, int32_t* __restrict__ ws, double* __restrict__ sums,
-            unsigned long long* __restrict__ counters, int split, int min_ops, int agent_sel) {
+            unsigned long long* __restrict__ counters, int split, int min_ops, int agent_sel, int dbg) {
   const int n = c->n_agents;
   const int part = blockIdx.x % split;
   // map index: (e,i) for local maps (one agent per env when agent_sel >= 0), e for global maps
@@ -428,6 +428,7 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
   // Does any other op's rectangle intersect the rows/columns this workgroup walks?  If not (the common case) every
   // group is covered by op k alone: a short branch-free loop does the job.
   bool alone = true;
+  unsigned hitmask = 0;  // ops (including k) that can touch a group this workgroup walks: all others are skipped wholesale
 #pragma unroll
   for (int o = 0; o < NK; ++o) {
     // column ranges widened to whole VEC-cell groups: ownership is decided per group, so two rectangles that merely
@@ -435,6 +436,7 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
     const bool hit = op[o].xl < kxl + r1 && op[o].xr > kxl + r0 && (op[o].yu & ~(VEC - 1)) < ((kyd + VEC - 1) & ~(VEC - 1)) &&
                      ((op[o].yd + VEC - 1) & ~(VEC - 1)) > (kyu & ~(VEC - 1));
     alone &= (o == k) || !hit;
+    hitmask |= (hit || o == k) ? (1u << o) : 0u;
   }
   if (alone) {
     int kinfo = 0;
@@ -465,7 +467,7 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
           a = in ? a : b;
           exceed |= fabsf(a) > lc && in;
           mv.v[q] = a;
-          if (REWARD) {
+          if (REWARD && !(dbg & 1)) {
             const float sel = (in && isf) ? 1.f : 0.f;
             const float wa = ippm_weight_l(a, wt), wb = ippm_weight_l(b, wt);
             const float hb = ippm_entropy_l(b, lc), ha = ippm_entropy_l(a, lc);
@@ -489,6 +491,7 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
     Mask cmask = 0;
 #pragma unroll
     for (int o = 0; o < NK; ++o) {
+      if (!((hitmask >> o) & 1u)) continue;
       unsigned mq = 0;
 #pragma unroll
       for (int q = 0; q < VEC; ++q) mq |= ((unsigned)(y + q - op[o].yu) < (unsigned)(op[o].yd - op[o].yu)) ? (1u << q) : 0u;
@@ -500,6 +503,7 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
       Mask act = 0;
 #pragma unroll
       for (int o = 0; o < NK; ++o) {
+        if (!((hitmask >> o) & 1u)) continue;
         const bool rowin = (unsigned)(x - op[o].xl) < (unsigned)(op[o].xr - op[o].xl);
         act |= rowin ? (cmask & ((Mask)QM << (o * VEC))) : (Mask)0;
       }
@@ -512,6 +516,7 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
 #pragma unroll
       for (int o = 0; o < NK; ++o) {
         cw[o] = 0;
+        if (!((hitmask >> o) & 1u)) continue;
         if (o <= k && (op[o].info & 0xFF) && ((unsigned)(act >> (o * VEC)) & QM))
           cw[o] = load_bytes<VEC>(code_e + (size_t)((op[o].info >> 8) & 0xFF) * S * S + (size_t)(x - op[o].xl) * S +
                                   (y - (op[o].yu & ~3)));
@@ -525,6 +530,7 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
 #pragma unroll
       for (int o = 0; o < NK; ++o) {
         if (o > k) break;
+        if (!((hitmask >> o) & 1u)) continue;
         const unsigned inm = (unsigned)(act >> (o * VEC)) & QM;
         if (!__any(inm != 0u)) continue;
         const bool isf = (op[o].info & 0xFF) != 0;
@@ -575,7 +581,7 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
     if (REWARD) { a1 = ippm_wave_sum(a1); aD = ippm_wave_sum(aD); aT = ippm_wave_sum(aT); }
     if (lane == 0) { s_red[wv][0] = a1; s_red[wv][1] = aD; s_red[wv][2] = aT; s_red[wv][3] = fc; s_red[wv][4] = fo; }
     __syncthreads();
-    if (threadIdx.x < 5) {
+    if (threadIdx.x < 5 && !(dbg & 2)) {
       const float t = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
       if (threadIdx.x < 3) {
         if (REWARD && t != 0.f) atomicAdd(&sums[(size_t)e * 8 + SUM_ACC1 + threadIdx.x], (double)t);
@@ -1015,7 +1021,7 @@ static void launch_apply(ippm_ctx* ctx, float* maps, const uint8_t* code, int32_
   dim3 block(256);
 #define IPPM_APPLY(V, NK, MINOPS)                                                                                      \
   hipLaunchKernelGGL((k_apply_ops<V, REWARD, NK>), dim3((unsigned)n_maps* split, std::min(max_ops, NK)), block, 0, st, \
-                     ctx->dcfg, maps, code, ws, ws, sums, ctx->dcounters, split, MINOPS, agent_sel)
+                     ctx->dcfg, maps, code, ws, ws, sums, ctx->dcounters, split, MINOPS, agent_sel, env_int("IPPM_DEBUG", 0))
   if (ctx->vec == 4) {
     IPPM_APPLY(4, 6, 1);
     if (max_ops > 6) IPPM_APPLY(4, 10, 7);
