@@ -17,20 +17,18 @@
  *   - batched over E independent environments ("envs"); N = agents per env; maps are gx rows x gy columns,
  *     row index = x-cell, contiguous index = y-cell (reference: map[xl:xr, yu:yd], mappings.py:46-49).
  *
- * Array layouts (E envs, N agents, A actions, TB = cfg.tile_patch_rows * cfg.tile_patch_cols * 32 tile bytes)
+ * Array layouts (E envs, N agents, A actions, S = cfg.tile_stride)
  *   episode   int64  [E]          episode number of each env (seeds truth, start states, Philox streams)
  *   pos       int32  [E,N,3]      UAV position in metres (x,y,z)
  *   rect      int32  [E,N,4]      clipped footprint [yu,yd,xl,xr], half-open when sliced (cameras.py:62-77)
- * Every per-cell plane is PATCH-TILED: [gxp/4][gyp/8][4][8] with gxp/gyp = gx/gy rounded up to 4/8, so one 4-row x
- * 8-column patch is 128 contiguous bytes of floats (32 bytes of a byte plane) and a wavefront touches 8 consecutive
- * patches = 1 KiB (256 B) with one instruction.
- *   truth     uint8  [E,gxp*gyp]  ground truth in {0,1}, patch-tiled (ippm_truth_from_rowmajor converts)
- *   local     float  [E,N,gxp*gyp] per-agent occupancy belief: LOG-ODDS ln(p/(1-p)) (0 = prior 0.5), patch-tiled
- *   global    float  [E,gxp*gyp]  fused team belief.  ippm_logodds_to_prob / ippm_prob_to_logodds convert to and
+ *   truth     uint8  [E,gx,gyp]   ground truth in {0,1}; rows padded to gyp = gy rounded up to 8 (padding ignored)
+ *   local     float  [E,N,gxp*gyp] per-agent occupancy belief: LOG-ODDS ln(p/(1-p)) (0 = prior 0.5), PATCH-TILED:
+ *   global    float  [E,gxp*gyp]  [gxp/4][gyp/8][4][8], i.e. each 128-byte line holds a 4-row x 8-column patch
+ *                                 (gxp = gx rounded up to 4).  ippm_logodds_to_prob / ippm_prob_to_logodds convert to and
  *                                 from row-major [gx,gy] probabilities at the boundary (DESIGN.md sections 2-3)
- *   code      uint8  [E,N,TB]     last measurement of each agent as 1-byte codes (1 = observed occupied), patch-tiled
- *                                 relative to the footprint: cell (x,y) of clipped rect [yu,yd,xl,xr] lives at
- *                                 (((x>>2)-(xl>>2))*tile_patch_cols + ((y>>3)-(yu>>3)))*32 + (x&3)*8 + (y&7)
+ *   code      uint8  [E,N,S,S]    last measurement of each agent as 1-byte codes (1 = observed occupied);
+ *                                 cell (x,y) of the footprint lives at [x-xl][y-(yu & ~7)] so that four
+ *                                 grid-aligned cells share one aligned 32-bit word
  *   flips     uint8  same layout as code; 1 = this cell's observation is flipped (parity mode)
  *   comm      uint8  [E,N,N]      comm[e,i,j] = 1 iff agent i receives agent j's message (diagonal = 1)
  *   mask      uint8  [E,N,A]      action mask after boundary + collision masking
@@ -70,9 +68,9 @@ typedef struct ippm_config {
   int32_t n_actions;                  /* 4 | 6 | 9 | 27 (action_space.py) */
   int32_t budget;                     /* episode has budget+1 steps */
   int32_t env_seed;                   /* params.environment.seed (start states: state_space.py:29) */
-  int32_t tile_patch_rows;            /* code/flips tile capacity in 4x8-cell patches: rows >= (2 r_max + 6)/4 + 1 ... */
+  int32_t tile_stride;                /* S: row stride (and row count) of code/flips tiles, multiple of 8, >= 2r+7 */
   int32_t fix_range;                  /* 0: per-episode range from {0,15,25,100} (communication_log.py:22-31) */
-  int32_t tile_patch_cols;            /* ... and columns >= (2 r_max + 14)/8 + 1; tile bytes = rows * cols * 32 */
+  int32_t reserved0;
   int32_t centre_x[IPPM_MAX_LATTICE]; /* floor(x_m / res_x) per lattice index (cameras.py:66) */
   int32_t centre_y[IPPM_MAX_LATTICE]; /* floor(y_m / res_x) -- the reference uses res_x for both axes */
   int32_t radius_x[IPPM_MAX_Z];       /* floor(0.5*floor(2 z tan(ax/2)/res_x)) per altitude index */
@@ -130,8 +128,6 @@ int ippm_reset_episode(ippm_ctx* ctx, const int64_t* episode, int32_t* pos, uint
  * probability maps ([n_maps, gx, gy] floats). */
 int ippm_logodds_to_prob(ippm_ctx* ctx, const float* src_tiled, float* dst_rowmajor, int64_t n_maps, void* stream);
 int ippm_prob_to_logodds(ippm_ctx* ctx, const float* src_rowmajor, float* dst_tiled, int64_t n_maps, void* stream);
-/* Row-major uint8 truth [n_envs, gx, gy] -> patch-tiled [n_envs, gxp*gyp] (caller-supplied terrain). */
-int ippm_truth_from_rowmajor(ippm_ctx* ctx, const uint8_t* src, uint8_t* dst, int32_t n_envs, void* stream);
 /* clip(p, 1e-4, 0.9999) of n stored log-odds (any layout) in place: the full-grid input clip of one stand-alone fuse_map call. */
 int ippm_clamp_logodds(ippm_ctx* ctx, float* maps, int64_t n, void* stream);
 

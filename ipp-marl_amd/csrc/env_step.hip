@@ -62,13 +62,13 @@ __global__ void k_fill_truth(const ippm_config* __restrict__ c, const int32_t* _
     int start = -((dim * (pct - 1)) / 100);
     lo = start == 0 ? 0 : max(dim + start, 0);
   }
-  const int npc = ippm_gyp(c) >> 3;
-  const size_t per = (size_t)ippm_gxp(c) * ippm_gyp(c);  // truth is patch-tiled like the maps
-  uint8_t* t = truth + (size_t)e * per;
-  for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < per; s += (size_t)gridDim.x * blockDim.x) {
-    const int patch = (int)(s >> 5), x = (patch / npc) * 4 + (int)((s >> 3) & 3), y = (patch % npc) * 8 + (int)(s & 7);
-    const int v = (split < 2) ? x : y;
-    t[s] = (x < gx && y < gy && v >= lo && v < hi) ? 1 : 0;
+  const int gys = ippm_gyp(c);  // truth rows are padded to the patch width like the maps
+  uint8_t* t = truth + (size_t)e * gx * gys;
+  int total = gx * gys;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int x = i / gys, y = i - x * gys;
+    int v = (split < 2) ? x : y;
+    t[i] = (y < gy && v >= lo && v < hi) ? 1 : 0;
   }
 }
 

@@ -78,10 +78,9 @@ k_actor_features(const ippm_config* __restrict__ c, const float* __restrict__ lo
   extern __shared__ float smem[];
   const int n = c->n_agents;
   const int e = blockIdx.x / n, i = blockIdx.x % n;
-  const int gx = c->grid_x, gy = c->grid_y, TPC = c->tile_patch_cols;
-  const size_t TB = (size_t)c->tile_patch_rows * TPC * 32;
+  const int gx = c->grid_x, gy = c->grid_y, S = c->tile_stride;
   float* colsum = smem;                               // [2][11][gy] (reused as [1][11][2r] for the footprint image)
-  float* red = smem + 2 * IPPM_FEAT * gy;             // [2][121]
+  float* red = smem + 2 * IPPM_FEAT * max(gy, S);     // [2][121]
   float* red_fp = red + 2 * IPPM_FEAT * IPPM_FEAT;    // [121]
   __shared__ int s_rect[IPPM_MAX_AGENTS][4];
   __shared__ int s_recv[IPPM_MAX_AGENTS];
@@ -118,7 +117,8 @@ k_actor_features(const ippm_config* __restrict__ c, const float* __restrict__ lo
   const int full_x = fu[3] - fu[2], full_y = fu[1] - fu[0];
   const int xoff = (cl[2] > fu[2]) ? full_x - hx : 0;
   const int yoff = (cl[0] > fu[0]) ? full_y - wy : 0;
-  const uint8_t* cd = code + (size_t)(e * n + i) * TB;
+  const uint8_t* cd = code + (size_t)(e * n + i) * S * S;
+  const int ycode0 = cl[0] - (cl[0] & ~7);
   const float mv0 = c->meas_value[k][0], mv1 = c->meas_value[k][1];
   TabView tfp;
   tfp.n = fp_n[k];
@@ -129,7 +129,7 @@ k_actor_features(const ippm_config* __restrict__ c, const float* __restrict__ lo
   auto src_fp = [&](int r, int col, float* v) {
     const int u = r - xoff, w = col - yoff;
     float val = 0.5f;
-    if (u >= 0 && u < hx && w >= 0 && w < wy) val = cd[ippm_tile_off(cl[2] + u, cl[0] + w, cl[2], cl[0], TPC)] ? mv1 : mv0;
+    if (u >= 0 && u < hx && w >= 0 && w < wy) val = cd[(size_t)u * S + w + ycode0] ? mv1 : mv0;
     v[0] = val;
   };
   area_reduce<1>(src_fp, tfp, tfp, colsum, red_fp);
@@ -291,7 +291,7 @@ extern "C" int ippm_actor_features(ippm_ctx* ctx, const float* local, const uint
   if (!ctx || !local || !code || !rect || !pos || !comm || !obs) { ippm_set_error("ippm_actor_features: null argument"); return -1; }
   if (int rc = feature_checks(ctx, "ippm_actor_features")) return rc;
   const ippm_config& c = ctx->cfg;
-  const size_t lds = sizeof(float) * (2 * IPPM_FEAT * (size_t)c.grid_y + 3 * IPPM_FEAT * IPPM_FEAT);
+  const size_t lds = sizeof(float) * (2 * IPPM_FEAT * (size_t)std::max(c.grid_y, c.tile_stride) + 3 * IPPM_FEAT * IPPM_FEAT);
   IPPM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_actor_features), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k_actor_features, dim3(n_envs * c.n_agents), dim3(256), lds, S_(stream), ctx->dcfg, local, code, rect, pos,
                      comm, make_view(ctx, ctx->off_rows, c.grid_x), make_view(ctx, ctx->off_cols, c.grid_y), ctx->tab_bin0,

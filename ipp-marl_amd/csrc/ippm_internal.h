@@ -94,11 +94,6 @@ __device__ __forceinline__ size_t ippm_cell_off(int x, int y, int npc) {
   return ((size_t)(x >> 2) * npc + (y >> 3)) * 32 + ((x & 3) << 3) + (y & 7);
 }
 
-// byte offset of footprint cell (x, y) inside an agent's code/flips tile; (xl, yu) = the footprint's clipped origin
-__device__ __forceinline__ size_t ippm_tile_off(int x, int y, int xl, int yu, int tpc) {
-  return ((size_t)((x >> 2) - (xl >> 2)) * tpc + ((y >> 3) - (yu >> 3))) * 32 + ((x & 3) << 3) + (y & 7);
-}
-
 __device__ __forceinline__ float ippm_clipf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 
 // Maps are stored as float32 LOG-ODDS L = ln(p/(1-p)) (DESIGN.md "log-odds storage"): the reference's

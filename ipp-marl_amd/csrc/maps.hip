@@ -93,18 +93,6 @@ __global__ void k_prob_to_logodds(const ippm_config* __restrict__ c, const float
   }
 }
 
-__global__ void k_truth_from_rowmajor(const ippm_config* __restrict__ c, const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
-                                      int n_envs) {
-  const int gx = c->grid_x, gy = c->grid_y, npc = ippm_gyp(c) >> 3;
-  const size_t per = (size_t)ippm_gxp(c) * ippm_gyp(c);
-  const size_t total = per * n_envs;
-  for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < total; s += (size_t)gridDim.x * blockDim.x) {
-    const size_t m = s / per, w = s - m * per;
-    const int patch = (int)(w >> 5), x = (patch / npc) * 4 + (int)((w >> 3) & 3), y = (patch % npc) * 8 + (int)(w & 7);
-    dst[s] = (x < gx && y < gy) ? src[(m * gx + x) * gy + y] : 0;
-  }
-}
-
 // ======================================================================================================
 // K3: sense + Bayesian update of the agent's own footprint tile
 // ======================================================================================================
@@ -119,8 +107,7 @@ k_sense_update(const ippm_config* __restrict__ c, const int64_t* __restrict__ ep
   int e, i;
   if (agent_sel >= 0) { e = tile; i = agent_sel; }
   else { e = tile / n; i = tile % n; }
-  const int gy = c->grid_y, TPC = c->tile_patch_cols;
-  const size_t TB = (size_t)c->tile_patch_rows * TPC * 32;
+  const int gx = c->grid_x, gy = c->grid_y, S = c->tile_stride;
   const int gyp = ippm_gyp(c), npcT = gyp >> 3;
   const size_t map_stride = (size_t)ippm_gxp(c) * gyp;
   const int32_t* p = pos + (size_t)(e * n + i) * 3;
@@ -140,12 +127,13 @@ k_sense_update(const ippm_config* __restrict__ c, const int64_t* __restrict__ ep
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const LanePos lp = lane_pos(lane, st);
   float* map = local + (size_t)(e * n + i) * map_stride;
-  const uint8_t* tr = truth + (size_t)e * map_stride;  // truth is tiled like the maps, one byte per cell
-  uint8_t* cd = code + (size_t)(e * n + i) * TB;
-  const uint8_t* fl = flips ? flips + (size_t)(e * n + i) * TB : nullptr;
+  const uint8_t* tr = truth + (size_t)e * gx * gyp;
+  uint8_t* cd = code + (size_t)(e * n + i) * S * S;
+  const uint8_t* fl = flips ? flips + (size_t)(e * n + i) * S * S : nullptr;
   const int64_t ep = episode ? episode[e] : 0;
   const uint32_t sw = ippm_stream_word((uint32_t)i, (uint32_t)stage, IPPM_DOMAIN_FLIP);
   const uint32_t k0 = (uint32_t)c->philox_seed, k1 = (uint32_t)(c->philox_seed >> 32);
+  const int tile_y0 = yu & ~7;
   const int stride = 4 * st.spw;  // patch rows advanced per iteration of the workgroup
   bool exceed = false;
   for (int pcc = lp.pcl; pcc < st.npc; pcc += st.ppr) {
@@ -165,10 +153,9 @@ k_sense_update(const ippm_config* __restrict__ c, const int64_t* __restrict__ ep
         on[u] = (prr + u * stride) < a1 && (unsigned)(x - xl) < (unsigned)h;
         tw[u] = 0; fw[u] = 0;
         if (on[u]) {
-          const size_t off = ippm_cell_off(x, y, npcT);
-          m[u] = load_cells(map + off);
-          tw[u] = load_word(tr + off);
-          if (fl) fw[u] = load_word(fl + ippm_tile_off(x, y, xl, yu, TPC));
+          m[u] = load_cells(map + ippm_cell_off(x, y, npcT));
+          tw[u] = load_word(tr + (size_t)x * gyp + y);
+          if (fl) fw[u] = load_word(fl + (size_t)(x - xl) * S + (y - tile_y0));
         }
       }
 #pragma unroll
@@ -205,7 +192,7 @@ k_sense_update(const ippm_config* __restrict__ c, const int64_t* __restrict__ ep
           cw |= (in ? obs : 0u) << (8 * q);
         }
         store_cells(map + ippm_cell_off(x, y, npcT), m[u]);
-        store_word(cd + ippm_tile_off(x, y, xl, yu, TPC), cw);
+        store_word(cd + (size_t)(x - xl) * S + (y - tile_y0), cw);
       }
     }
   }
@@ -259,8 +246,7 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
 #pragma unroll
   for (int o = 0; o < NK; ++o)
     if (o == k) { kyu = op[o].yu; kyd = op[o].yd; kxl = op[o].xl; kxr = op[o].xr; kinfo = op[o].info; }
-  const int TPC = c->tile_patch_cols;
-  const size_t TB = (size_t)c->tile_patch_rows * TPC * 32;
+  const int S = c->tile_stride;
   const int gyp = ippm_gyp(c), npcT = gyp >> 3;
   const size_t map_stride = (size_t)ippm_gxp(c) * gyp;
   const bool k_is_last = hdr[PL_LAST] == k;
@@ -272,7 +258,7 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const LanePos lp = lane_pos(lane, st);
   float* map = maps + (size_t)m * map_stride;
-  const uint8_t* code_e = code + (size_t)e * n * TB;
+  const uint8_t* code_e = code + (size_t)e * n * S * S;
   bool exceed = false;
   float a1s = 0.f, aD = 0.f, aT = 0.f;
   unsigned cells = 0, opcells = 0;
@@ -294,7 +280,7 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
     const bool isf = (kinfo & 0xFF) != 0;
     const int alt = (kinfo >> 16) & 0xFF;
     const float lm0 = isf ? c->logit_meas[alt][0] : 0.f, lm1 = isf ? c->logit_meas[alt][1] : 0.f;
-    const uint8_t* ctile = code_e + (size_t)((kinfo >> 8) & 0xFF) * TB;
+    const uint8_t* ctile = code_e + (size_t)((kinfo >> 8) & 0xFF) * S * S - (kyu & ~7);
     for (int pcc = lp.pcl; pcc < st.npc; pcc += st.ppr) {
       const int y = (st.pc0 + pcc) * 8 + lp.half * 4;
       unsigned inm = 0;
@@ -307,7 +293,7 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
         const size_t off = ippm_cell_off(x, y, npcT);
         Cells mv = load_cells(map + off);
         uint32_t cw = 0;
-        if (isf) cw = load_word(ctile + ippm_tile_off(x, y, kxl, kyu, TPC));
+        if (isf) cw = load_word(ctile + (size_t)(x - kxl) * S + y);
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
           const float b = mv.v[q];
@@ -370,7 +356,8 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
           cw[o] = 0;
           if (!((hitmask >> o) & 1u)) continue;
           if (o <= k && (op[o].info & 0xFF) && ((unsigned)(act >> (o * VEC)) & QM))
-            cw[o] = load_word(code_e + (size_t)((op[o].info >> 8) & 0xFF) * TB + ippm_tile_off(x, y, op[o].xl, op[o].yu, TPC));
+            cw[o] = load_word(code_e + (size_t)((op[o].info >> 8) & 0xFF) * S * S + (size_t)(x - op[o].xl) * S +
+                              (y - (op[o].yu & ~7)));
         }
         const Cells old = mv;
         float L[VEC];
@@ -464,8 +451,7 @@ k_apply_ops_generic(const ippm_config* __restrict__ c, float* __restrict__ maps,
   __shared__ float s_red[4][6];
   for (int q = threadIdx.x; q < nops * OP_WORDS; q += blockDim.x) s_ops[q] = w[WS_OPS + q];
   __syncthreads();
-  const int TPC = c->tile_patch_cols;
-  const size_t TB = (size_t)c->tile_patch_rows * TPC * 32;
+  const int S = c->tile_stride;
   const int gyp = ippm_gyp(c), npcT = gyp >> 3;
   const size_t map_stride = (size_t)ippm_gxp(c) * gyp;
   const int X0 = hdr[PL_X0], X1 = hdr[PL_X1], last_op = hdr[PL_LAST];
@@ -476,7 +462,7 @@ k_apply_ops_generic(const ippm_config* __restrict__ c, float* __restrict__ maps,
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const LanePos lp = lane_pos(lane, st);
   float* map = maps + (size_t)m * map_stride;
-  const uint8_t* code_e = code + (size_t)e * n * TB;
+  const uint8_t* code_e = code + (size_t)e * n * S * S;
   bool exceed = false;
   float a1s = 0.f, aD = 0.f, aT = 0.f;
   unsigned cells = 0, opcells = 0;
@@ -503,7 +489,7 @@ k_apply_ops_generic(const ippm_config* __restrict__ c, float* __restrict__ maps,
         uint32_t cw = 0;
         float lm0 = 0.f, lm1 = 0.f;
         if (op[OP_TYPE]) {
-          cw = load_word(code_e + (size_t)op[OP_SRC] * TB + ippm_tile_off(x, y, op[OP_XL], op[OP_YU], TPC));
+          cw = load_word(code_e + (size_t)op[OP_SRC] * S * S + (size_t)(x - op[OP_XL]) * S + (y - (op[OP_YU] & ~7)));
           lm0 = c->logit_meas[op[OP_ALT]][0];
           lm1 = c->logit_meas[op[OP_ALT]][1];
         }
@@ -564,14 +550,14 @@ k_weighted_entropy(const ippm_config* __restrict__ c, const float* __restrict__ 
   const int gx = c->grid_x, gy = c->grid_y, gyp = ippm_gyp(c), npc = gyp >> 3;
   const size_t per = (size_t)ippm_gxp(c) * gyp;
   const float* p = maps + (size_t)m * per;
-  const uint8_t* t = truth ? truth + (size_t)(m / maps_per_truth) * per : nullptr;
+  const uint8_t* t = truth ? truth + (size_t)(m / maps_per_truth) * gx * gyp : nullptr;
   const float lc = c->logit_clip, wt = c->logit_weight_thr;
   float acc = 0.f;
   for (size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x; s < per; s += (size_t)gridDim.x * blockDim.x) {
     const int patch = (int)(s >> 5), x = (patch / npc) * 4 + (int)((s >> 3) & 3), y = (patch % npc) * 8 + (int)(s & 7);
     if (x >= gx || y >= gy) continue;
     const float v = p[s];
-    const float wgt = t ? (float)t[s] : ippm_weight_l(v, wt);
+    const float wgt = t ? (float)t[(size_t)x * gyp + y] : ippm_weight_l(v, wt);
     acc += wgt * ippm_entropy_l(v, lc);
   }
   acc = ippm_wave_sum(acc);
@@ -600,14 +586,6 @@ extern "C" int ippm_prob_to_logodds(ippm_ctx* ctx, const float* src, float* dst,
   const size_t total = (size_t)ippm_host_gxp(ctx->cfg) * ippm_host_gyp(ctx->cfg) * n_maps;
   hipLaunchKernelGGL(k_prob_to_logodds, dim3(std::min(8192, grid1(total))), dim3(256), 0, S_(stream), ctx->dcfg, src, dst, (int)n_maps);
   IPPM_LAUNCH_CHECK("prob_to_logodds");
-  return 0;
-}
-
-extern "C" int ippm_truth_from_rowmajor(ippm_ctx* ctx, const uint8_t* src, uint8_t* dst, int32_t n_envs, void* stream) {
-  if (!ctx || !src || !dst) { ippm_set_error("ippm_truth_from_rowmajor: null argument"); return -1; }
-  const size_t total = (size_t)ippm_host_gxp(ctx->cfg) * ippm_host_gyp(ctx->cfg) * n_envs;
-  hipLaunchKernelGGL(k_truth_from_rowmajor, dim3(std::min(8192, grid1(total))), dim3(256), 0, S_(stream), ctx->dcfg, src, dst, n_envs);
-  IPPM_LAUNCH_CHECK("truth_from_rowmajor");
   return 0;
 }
 

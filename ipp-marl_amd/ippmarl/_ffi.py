@@ -25,7 +25,7 @@ class IppmConfig(C.Structure):
         ("spacing", C.c_int32), ("min_altitude", C.c_int32),
         ("x_dim_m", C.c_int32), ("y_dim_m", C.c_int32),
         ("n_actions", C.c_int32), ("budget", C.c_int32), ("env_seed", C.c_int32),
-        ("tile_patch_rows", C.c_int32), ("fix_range", C.c_int32), ("tile_patch_cols", C.c_int32),
+        ("tile_stride", C.c_int32), ("fix_range", C.c_int32), ("reserved0", C.c_int32),
         ("centre_x", C.c_int32 * MAX_LATTICE), ("centre_y", C.c_int32 * MAX_LATTICE),
         ("radius_x", C.c_int32 * MAX_Z), ("radius_y", C.c_int32 * MAX_Z),
         ("logit_meas", (C.c_float * 2) * MAX_Z), ("meas_value", (C.c_float * 2) * MAX_Z),
@@ -61,7 +61,6 @@ PROTOTYPES = {
     "ippm_fuse_local": [P, P, P, P, P, P, P, I32, I32, P],
     "ippm_action_mask": [P, P, P, P, I32, P, P, P, I32, P],
     "ippm_clamp_logodds": [P, P, I64, P],
-    "ippm_truth_from_rowmajor": [P, P, P, I32, P],
     "ippm_fuse_global_reward": [P, P, P, P, P, P, P, P, I32, P],
     "ippm_weighted_entropy": [P, P, P, I32, P, I32, P],
     "ippm_reward_from_maps": [P, P, P, P, P, I32, P],
@@ -122,7 +121,7 @@ def make_config(d: DerivedConstants) -> IppmConfig:
     c.spacing, c.min_altitude = d.spacing, d.min_altitude
     c.x_dim_m, c.y_dim_m = d.x_dim_m, d.y_dim_m
     c.n_actions, c.budget, c.env_seed = d.n_actions, d.budget, d.env_seed
-    c.tile_patch_rows, c.tile_patch_cols, c.fix_range = d.tile_patch_rows, d.tile_patch_cols, 1 if d.fix_range else 0
+    c.tile_stride, c.fix_range = d.tile_stride, 1 if d.fix_range else 0
     for i in range(d.space_x):
         c.centre_x[i] = int(d.centre_x[i])
     for i in range(d.space_y):

@@ -90,11 +90,9 @@ class DerivedConstants:
         self.logit_prior = float(np.log(self.prior / (1 - self.prior))) if 0 < self.prior < 1 else 0.0
         self.logit_clip = float(np.log(CLIP_HI / (1 - CLIP_HI)))
         self.logit_weight_thr = float(np.log(0.501 / 0.499))
-        # code/flip tiles are patch-tiled like the maps: capacity in 4x8-cell patches for the widest footprint at any
-        # alignment, and bytes per tile
-        self.tile_patch_rows = (2 * max(rx) + 6) // 4 + 1
-        self.tile_patch_cols = (2 * max(ry) + 14) // 8 + 1
-        self.tile_bytes = self.tile_patch_rows * self.tile_patch_cols * 32
+        # code/flip tile stride: widest footprint + 7 cells of patch-alignment slack, multiple of 8
+        need = max(max(2 * r for r in rx), max(2 * r for r in ry) + 7, 8)
+        self.tile_stride = (need + 7) // 8 * 8
         # storage dims of the patch-tiled maps (4-row x 8-column patches) and of the padded truth rows
         self.grid_xp = (self.grid_x + 3) // 4 * 4
         self.grid_yp = (self.grid_y + 7) // 8 * 8
@@ -117,13 +115,6 @@ class DerivedConstants:
         cy = lambda v: min(max(v, 0), self.grid_y - 1)  # noqa: E731
         cx = lambda v: min(max(v, 0), self.grid_x - 1)  # noqa: E731
         return full, [cy(yu), cy(yd), cx(xl), cx(xr)]
-
-    def tile_index(self, rect) -> np.ndarray:
-        """Byte offsets [h, w] of the cells of clipped rect [yu,yd,xl,xr] inside an agent's code/flips tile."""
-        yu, yd, xl, xr = (int(v) for v in rect)
-        xs = np.arange(xl, xr)[:, None]
-        ys = np.arange(yu, yd)[None, :]
-        return (((xs >> 2) - (xl >> 2)) * self.tile_patch_cols + ((ys >> 3) - (yu >> 3))) * 32 + ((xs & 3) << 3) + (ys & 7)
 
     def max_start_seed(self, episode: int) -> int:
         return self.env_seed * int(episode) * max(self.n_agents - 1, 0)

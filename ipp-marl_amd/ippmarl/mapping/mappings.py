@@ -59,9 +59,9 @@ class Mapping:
 
     def _pack_one(self, i, fc, flips_tile):
         env, d = self.engine.env, self.engine.d
-        out = np.zeros((1, d.n_agents, d.tile_bytes), dtype=np.uint8)
+        out = np.zeros((1, d.n_agents, d.tile_stride, d.tile_stride), dtype=np.uint8)
         yu, yd, xl, xr = fc
-        out[0, i][d.tile_index(fc)] = np.asarray(flips_tile, dtype=np.uint8).reshape(xr - xl, yd - yu)
+        out[0, i, : xr - xl, (yu & 7): (yu & 7) + yd - yu] = np.asarray(flips_tile, dtype=np.uint8).reshape(xr - xl, yd - yu)
         return torch.from_numpy(out).to(env.device)
 
     # ------------------------------------------------------------------------------------------------

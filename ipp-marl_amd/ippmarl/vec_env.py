@@ -38,18 +38,18 @@ class VecEnv:
         torch.cuda.set_device(self.device)
         self.ctx = _ffi.Context(self.d)
         d, E, dev = self.d, self.E, self.device
-        N, A = d.n_agents, d.n_actions
+        N, A, S = d.n_agents, d.n_actions, d.tile_stride
         z = lambda *shape, dtype: torch.zeros(*shape, dtype=dtype, device=dev)  # noqa: E731
         self.episode = z(E, dtype=torch.int64)
         self.pos = z(E, N, 3, dtype=torch.int32)
         self.pos_pre = z(E, N, 3, dtype=torch.int32)
         self.rect = z(E, N, 4, dtype=torch.int32)
-        self.truth = z(E, d.map_floats, dtype=torch.uint8)          # patch-tiled like the maps, one byte per cell
+        self.truth = z(E, d.grid_x, d.grid_yp, dtype=torch.uint8)   # rows padded to the patch width
         # beliefs: float32 log-odds (0 = prior 0.5) in patch-tiled storage; posterior_local()/posterior_global()
         # export row-major probabilities
         self.local = z(E, N, d.map_floats, dtype=torch.float32)
         self.glob = z(E, d.map_floats, dtype=torch.float32)
-        self.code = z(E, N, d.tile_bytes, dtype=torch.uint8)          # patch-tiled measurement codes per footprint
+        self.code = z(E, N, S, S, dtype=torch.uint8)
         self.comm = z(E, N, N, dtype=torch.uint8)
         self.comm_range = z(E, dtype=torch.float32)
         self.mask = z(E, N, A, dtype=torch.uint8)
@@ -96,16 +96,10 @@ class VecEnv:
         self.ctx.call("ippm_prob_to_logodds", self._p(src), self._p(out), n_maps, self.stream)
         return out
 
-    def _untile(self, t: torch.Tensor) -> torch.Tensor:
-        """[..., gxp*gyp] patch-tiled -> [..., gx, gy] row-major (pure view/permute: used for inspection only)."""
-        d = self.d
-        v = t.reshape(*t.shape[:-1], d.grid_xp // 4, d.grid_yp // 8, 4, 8).transpose(-3, -2)
-        return v.reshape(*t.shape[:-1], d.grid_xp, d.grid_yp)[..., : d.grid_x, : d.grid_y]
-
     @property
     def truth_map(self) -> torch.Tensor:
-        """Ground truth as row-major uint8 [E, gx, gy]."""
-        return self._untile(self.truth)
+        """Ground truth without the row padding, uint8 [E, gx, gy]."""
+        return self.truth[:, :, : self.d.grid_y]
 
     def posterior_local(self) -> torch.Tensor:
         """Occupancy probabilities of the agents' local maps, float32 [E,N,gx,gy] (the reference's local_map)."""
@@ -135,8 +129,8 @@ class VecEnv:
                       self._p(self.split_pct), self._p(self.comm_range), self._p(self.ws), self._p(self.sums), self.E,
                       self.stream)
         if truth is not None:
-            src = torch.as_tensor(truth).to(self.device, torch.uint8).reshape(self.E, d.grid_x, d.grid_y).contiguous()
-            self.ctx.call("ippm_truth_from_rowmajor", self._p(src), self._p(self.truth), self.E, self.stream)
+            self.truth.zero_()
+            self.truth[:, :, : d.grid_y].copy_(torch.as_tensor(truth).to(self.device, torch.uint8))
         if start_positions is not None:
             self.pos.copy_(torch.as_tensor(start_positions).to(self.device, torch.int32))
         self.t = 0
@@ -260,13 +254,12 @@ class VecEnv:
         return self.ctx.counters(self.stream, reset)
 
     def pack_flips(self, tiles, rects: np.ndarray) -> torch.Tensor:
-        """tiles[e][i]: uint8 [h,w] (1 = flipped) for clipped rect rects[e,i] = [yu,yd,xl,xr] -> device tile layout."""
-        N = self.d.n_agents
-        out = np.zeros((self.E, N, self.d.tile_bytes), dtype=np.uint8)
+        """tiles[e][i]: uint8 [h,w] (1 = flipped) for clipped rect rects[e,i] = [yu,yd,xl,xr] -> device layout."""
+        S, N = self.d.tile_stride, self.d.n_agents
+        out = np.zeros((self.E, N, S, S), dtype=np.uint8)
         for e in range(self.E):
             for i in range(N):
-                if tiles[e][i] is None:
-                    continue
                 yu, yd, xl, xr = (int(v) for v in rects[e, i])
-                out[e, i][self.d.tile_index(rects[e, i])] = np.asarray(tiles[e][i], dtype=np.uint8).reshape(xr - xl, yd - yu)
+                off = yu & 7
+                out[e, i, : xr - xl, off: off + yd - yu] = np.asarray(tiles[e][i], dtype=np.uint8).reshape(xr - xl, yd - yu)
         return torch.from_numpy(out).to(self.device)
