@@ -21,13 +21,12 @@
  *   episode   int64  [E]          episode number of each env (seeds truth, start states, Philox streams)
  *   pos       int32  [E,N,3]      UAV position in metres (x,y,z)
  *   rect      int32  [E,N,4]      clipped footprint [yu,yd,xl,xr], half-open when sliced (cameras.py:62-77)
- *   truth     uint8  [E,gx,gyp]   ground truth in {0,1}; rows padded to gyp = gy rounded up to 8 (padding ignored)
- *   local     float  [E,N,gxp*gyp] per-agent occupancy belief: LOG-ODDS ln(p/(1-p)) (0 = prior 0.5), PATCH-TILED:
- *   global    float  [E,gxp*gyp]  [gxp/4][gyp/8][4][8], i.e. each 128-byte line holds a 4-row x 8-column patch
- *                                 (gxp = gx rounded up to 4).  ippm_logodds_to_prob / ippm_prob_to_logodds convert to and
- *                                 from row-major [gx,gy] probabilities at the boundary (DESIGN.md sections 2-3)
+ *   truth     uint8  [E,gx,gy]    ground truth in {0,1}
+ *   local     float  [E,N,gx,gy]  per-agent occupancy belief, stored as LOG-ODDS ln(p/(1-p)) (0 = prior 0.5);
+ *   global    float  [E,gx,gy]    fused team belief, log-odds.  ippm_logodds_to_prob / ippm_prob_to_logodds
+ *                                 convert at the boundary (DESIGN.md "log-odds storage")
  *   code      uint8  [E,N,S,S]    last measurement of each agent as 1-byte codes (1 = observed occupied);
- *                                 cell (x,y) of the footprint lives at [x-xl][y-(yu & ~7)] so that four
+ *                                 cell (x,y) of the footprint lives at [x-xl][y-(yu & ~3)] so that four
  *                                 grid-aligned cells share one aligned 32-bit word
  *   flips     uint8  same layout as code; 1 = this cell's observation is flipped (parity mode)
  *   comm      uint8  [E,N,N]      comm[e,i,j] = 1 iff agent i receives agent j's message (diagonal = 1)
@@ -68,7 +67,7 @@ typedef struct ippm_config {
   int32_t n_actions;                  /* 4 | 6 | 9 | 27 (action_space.py) */
   int32_t budget;                     /* episode has budget+1 steps */
   int32_t env_seed;                   /* params.environment.seed (start states: state_space.py:29) */
-  int32_t tile_stride;                /* S: row stride (and row count) of code/flips tiles, multiple of 8, >= 2r+7 */
+  int32_t tile_stride;                /* S: row stride (and row count) of code/flips tiles, multiple of 4 */
   int32_t fix_range;                  /* 0: per-episode range from {0,15,25,100} (communication_log.py:22-31) */
   int32_t reserved0;
   int32_t centre_x[IPPM_MAX_LATTICE]; /* floor(x_m / res_x) per lattice index (cameras.py:66) */
@@ -124,11 +123,10 @@ int ippm_reset_episode(ippm_ctx* ctx, const int64_t* episode, int32_t* pos, uint
                        float* global, int32_t* split_pct, float* comm_range_out, int32_t* ws, double* sums,
                        int32_t n_envs, void* stream);
 
-/* Conversions between the stored maps (patch-tiled log-odds, gxp*gyp floats each) and the reference's row-major
- * probability maps ([n_maps, gx, gy] floats). */
-int ippm_logodds_to_prob(ippm_ctx* ctx, const float* src_tiled, float* dst_rowmajor, int64_t n_maps, void* stream);
-int ippm_prob_to_logodds(ippm_ctx* ctx, const float* src_rowmajor, float* dst_tiled, int64_t n_maps, void* stream);
-/* clip(p, 1e-4, 0.9999) of n stored log-odds (any layout) in place: the full-grid input clip of one stand-alone fuse_map call. */
+/* Elementwise conversions between the stored log-odds and the reference's probabilities (n floats). */
+int ippm_logodds_to_prob(ippm_ctx* ctx, const float* src, float* dst, int64_t n, void* stream);
+int ippm_prob_to_logodds(ippm_ctx* ctx, const float* src, float* dst, int64_t n, void* stream);
+/* clip(p, 1e-4, 0.9999) of n stored log-odds in place: the full-grid input clip of one stand-alone fuse_map call. */
 int ippm_clamp_logodds(ippm_ctx* ctx, float* maps, int64_t n, void* stream);
 
 /* ---- K2: Camera.project_field_of_view (sensors/cameras.py:46-79) ------------------------------------ */

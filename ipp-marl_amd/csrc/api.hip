@@ -118,14 +118,14 @@ extern "C" int ippm_ctx_create(const ippm_config* cfg, ippm_ctx** out) {
   if (!(c.logit_clip > 0.f) || !(c.logit_weight_thr > 0.f)) return bad("logit_clip / logit_weight_thr not set");
   if (c.prior != 0.5f) return bad("mapping.prior != 0.5 is not supported on the HIP path (the reference shifts every cell of a map by "
                                   "-logit(prior) per fused message; see DESIGN.md)");
-  if (c.tile_stride % 8 != 0) return bad("tile_stride must be a multiple of 8");
+  if (c.tile_stride % 4 != 0) return bad("tile_stride must be a multiple of 4");
   for (int k = 0; k < c.space_z; ++k)
-    if (2 * c.radius_x[k] > c.tile_stride || 2 * c.radius_y[k] + 7 > c.tile_stride) return bad("tile_stride too small for the footprint");
+    if (2 * c.radius_x[k] > c.tile_stride || 2 * c.radius_y[k] + 3 > c.tile_stride) return bad("tile_stride too small for the footprint");
   if (c.spacing <= 0 || c.budget <= 0) return bad("spacing and budget must be positive");
   ippm_ctx* ctx = new ippm_ctx();
   std::memset(ctx, 0, sizeof(*ctx));
   ctx->cfg = c;
-  ctx->vec = 4;
+  ctx->vec = (c.grid_y % 4 == 0) ? 4 : 1;
   int rc = ippm_check_hip(hipMalloc(&ctx->dcfg, sizeof(ippm_config)), "hipMalloc(cfg)");
   if (!rc) rc = ippm_check_hip(hipMemcpy(ctx->dcfg, cfg, sizeof(ippm_config), hipMemcpyHostToDevice), "hipMemcpy(cfg)");
   if (!rc) rc = ippm_check_hip(hipMalloc(&ctx->dcounters, IPPM_COUNTER_SLOTS * 8 * sizeof(unsigned long long)), "hipMalloc(counters)");

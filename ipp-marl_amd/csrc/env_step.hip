@@ -62,13 +62,12 @@ __global__ void k_fill_truth(const ippm_config* __restrict__ c, const int32_t* _
     int start = -((dim * (pct - 1)) / 100);
     lo = start == 0 ? 0 : max(dim + start, 0);
   }
-  const int gys = ippm_gyp(c);  // truth rows are padded to the patch width like the maps
-  uint8_t* t = truth + (size_t)e * gx * gys;
-  int total = gx * gys;
+  uint8_t* t = truth + (size_t)e * gx * gy;
+  int total = gx * gy;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    int x = i / gys, y = i - x * gys;
+    int x = i / gy, y = i - x * gy;
     int v = (split < 2) ? x : y;
-    t[i] = (y < gy && v >= lo && v < hi) ? 1 : 0;
+    t[i] = (v >= lo && v < hi) ? 1 : 0;
   }
 }
 
@@ -76,6 +75,19 @@ __global__ void k_fill_f32(float* __restrict__ p, float v, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t stride = (size_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) p[i] = v;
+}
+
+// posterior <-> log-odds conversion at the API boundary (drop-in classes exchange probabilities)
+__global__ void k_logodds_to_prob(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = ippm_sigmoid(src[i]);
+}
+__global__ void k_prob_to_logodds(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float p = src[i];
+    dst[i] = __logf(p) - __logf(1.0f - p);  // p in {0,1} gives -inf/+inf: clamped on first use like the reference's clip
+  }
 }
 
 // full-grid input clip of one map (stateless drop-in fuse_map: the deferred-clamp bookkeeping has no history there)
@@ -97,6 +109,158 @@ __global__ void k_footprint(const ippm_config* __restrict__ c, const int32_t* __
     rect[i * 4 + k] = cl[k];
     if (rect_full) rect_full[i * 4 + k] = fu[k];
   }
+}
+
+// ======================================================================================================
+// row/lane geometry shared by K3 and the fusion kernel
+// ======================================================================================================
+struct RowGeom {
+  int y0;      // grid-aligned first column
+  int groups;  // VEC-wide groups per row
+  int lpr;     // lanes per row (power of two <= 64)
+  int rpw;     // rows per wavefront
+  int shift;   // log2(lpr)
+};
+template <int VEC>
+__device__ __forceinline__ RowGeom make_geom(int ya, int yb) {
+  RowGeom g;
+  g.y0 = ya & ~(VEC - 1);
+  g.groups = (yb - g.y0 + VEC - 1) / VEC;
+  const int gm1 = max(g.groups - 1, 0);
+  g.shift = gm1 == 0 ? 0 : min(32 - __clz(gm1), 6);
+  g.lpr = 1 << g.shift;
+  g.rpw = 64 >> g.shift;
+  return g;
+}
+
+template <int VEC>
+struct CellVec {
+  float v[VEC];
+};
+template <int VEC>
+__device__ __forceinline__ CellVec<VEC> load_cells(const float* p) {
+  CellVec<VEC> r;
+  if (VEC == 4) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    r.v[0] = t.x; r.v[1 % VEC] = t.y; r.v[2 % VEC] = t.z; r.v[3 % VEC] = t.w;
+  } else {
+    r.v[0] = p[0];
+  }
+  return r;
+}
+template <int VEC>
+__device__ __forceinline__ void store_cells(float* p, const CellVec<VEC>& r) {
+  if (VEC == 4) {
+    *reinterpret_cast<float4*>(p) = make_float4(r.v[0], r.v[1 % VEC], r.v[2 % VEC], r.v[3 % VEC]);
+  } else {
+    p[0] = r.v[0];
+  }
+}
+// VEC consecutive bytes as one word (aligned by construction when VEC == 4)
+template <int VEC>
+__device__ __forceinline__ uint32_t load_bytes(const uint8_t* p) {
+  if (VEC == 4) return *reinterpret_cast<const uint32_t*>(p);
+  return p[0];
+}
+template <int VEC>
+__device__ __forceinline__ void store_bytes(uint8_t* p, uint32_t w) {
+  if (VEC == 4) *reinterpret_cast<uint32_t*>(p) = w;
+  else p[0] = (uint8_t)w;
+}
+
+// ======================================================================================================
+// K3: sense + Bayesian update of the agent's own footprint tile
+// ======================================================================================================
+template <int VEC, int UNR>
+__global__ void __launch_bounds__(256)
+k_sense_update(const ippm_config* __restrict__ c, const int64_t* __restrict__ episode,
+               const int32_t* __restrict__ pos, const uint8_t* __restrict__ truth, float* __restrict__ local,
+               const uint8_t* __restrict__ flips, uint8_t* __restrict__ code, int32_t* __restrict__ rect_out,
+               int32_t* __restrict__ ws, unsigned long long* __restrict__ counters, int stage, int agent_sel,
+               int split) {
+  const int n = c->n_agents;
+  const int tile = blockIdx.x / split, part = blockIdx.x % split;  // (tile, row part) flattened: grid.x has no 65535 limit
+  int e, i;
+  if (agent_sel >= 0) { e = tile; i = agent_sel; }
+  else { e = tile / n; i = tile % n; }
+  const int gx = c->grid_x, gy = c->grid_y, S = c->tile_stride;
+  const int32_t* p = pos + (size_t)(e * n + i) * 3;
+  int r[4];
+  ippm_footprint_rect(c, p[0], p[1], p[2], r, nullptr);
+  const int yu = r[0], yd = r[1], xl = r[2], xr = r[3];
+  if (part == 0 && threadIdx.x < 4) rect_out[(size_t)(e * n + i) * 4 + threadIdx.x] = r[threadIdx.x];
+  const int h = xr - xl, w = yd - yu;
+  if (h <= 0 || w <= 0) return;
+  const int k = ippm_alt_index(c, p[2]);
+  const float lm0 = c->logit_meas[k][0], lm1 = c->logit_meas[k][1];
+  const uint32_t thr = c->flip_threshold[k];
+  const float lc = c->logit_clip;
+  const RowGeom g = make_geom<VEC>(yu, yd);
+  const int tile_y0 = yu & ~3;
+  const int rows_per_wg = (h + split - 1) / split;
+  const int r0 = part * rows_per_wg, r1 = min(h, r0 + rows_per_wg);
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int sub = lane >> g.shift, gl = lane & (g.lpr - 1);
+  float* map = local + (size_t)(e * n + i) * gx * gy;
+  const uint8_t* tr = truth + (size_t)e * gx * gy;
+  uint8_t* cd = code + (size_t)(e * n + i) * S * S;
+  const uint8_t* fl = flips ? flips + (size_t)(e * n + i) * S * S : nullptr;
+  const int64_t ep = episode ? episode[e] : 0;
+  const uint32_t sw = ippm_stream_word((uint32_t)i, (uint32_t)stage, IPPM_DOMAIN_FLIP);
+  const uint32_t k0 = (uint32_t)c->philox_seed, k1 = (uint32_t)(c->philox_seed >> 32);
+  const int stride = 4 * g.rpw;
+  bool exceed = false;
+  for (int gi = gl; gi < g.groups; gi += g.lpr) {
+    const int y = g.y0 + gi * VEC;
+    for (int row = r0 + wv * g.rpw + sub; row < r1; row += stride * UNR) {
+      // UNR independent rows per lane: all their loads are in flight before the first use
+      CellVec<VEC> m[UNR];
+      uint32_t tw[UNR], fw[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int rr = row + u * stride;
+        tw[u] = 0; fw[u] = 0;
+        if (rr < r1) {
+          const size_t cell = (size_t)(xl + rr) * gy + y;
+          m[u] = load_cells<VEC>(map + cell);
+          tw[u] = load_bytes<VEC>(tr + cell);
+          if (fl) fw[u] = load_bytes<VEC>(fl + (size_t)rr * S + (y - tile_y0));
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int rr = row + u * stride;
+        if (rr >= r1) continue;
+        const size_t cell = (size_t)(xl + rr) * gy + y;
+        Philox4 ph;
+        if (!fl && VEC == 4) ph = ippm_philox((uint32_t)(cell >> 2), (uint32_t)ep, sw, (uint32_t)(ep >> 32), k0, k1);
+        uint32_t cw = 0;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+          // branch-free: cells of an edge group that lie outside the footprint keep their value
+          const bool in = (unsigned)(y + q - yu) < (unsigned)w;
+          uint32_t flip;
+          if (fl) flip = (fw[u] >> (8 * q)) & 1u;
+          else if (VEC == 4) flip = ph.v[q] < thr ? 1u : 0u;
+          else {
+            Philox4 p1 = ippm_philox((uint32_t)((cell + q) >> 2), (uint32_t)ep, sw, (uint32_t)(ep >> 32), k0, k1);
+            flip = p1.v[(cell + q) & 3] < thr ? 1u : 0u;
+          }
+          const uint32_t obs = ((tw[u] >> (8 * q)) & 1u) ^ flip;
+          // mappings.py:109-124 in log-odds: clip the prior belief, add the measurement's log-odds
+          const float l = ippm_clampl(m[u].v[q], lc) + (obs ? lm1 : lm0);
+          exceed |= in & (fabsf(l) > lc);
+          m[u].v[q] = in ? l : m[u].v[q];
+          cw |= (in ? obs : 0u) << (8 * q);
+        }
+        store_cells<VEC>(map + cell, m[u]);
+        store_bytes<VEC>(cd + (size_t)rr * S + (y - tile_y0), cw);
+      }
+    }
+  }
+  if (ws && __any(exceed) && lane == 0) ws[(size_t)(e * (n + 1) + i) * IPPM_WS_WORDS + WS_FLAG_S] = 1;
+  if (counters && part == 0 && threadIdx.x == 0)
+    atomicAdd(&counters[(tile & (IPPM_COUNTER_SLOTS - 1)) * 8 + 0], (unsigned long long)h * w);
 }
 
 // ======================================================================================================
@@ -204,6 +368,341 @@ __global__ void k_plan(const ippm_config* __restrict__ c, const int32_t* __restr
 // K4 / K5: apply the planned ops to a map, each touched cell read once and written once.
 // REWARD: also accumulate the information-gain reward terms of K5 (utils/reward.py:68-82).
 // ======================================================================================================
+// Work decomposition: one workgroup column per (map, op).  The workgroups of op k walk the rows of ITS
+// rectangle (dense lanes, like K3) and own every 4-cell group that no later op touches; an owned group gets the
+// complete ordered chain of all ops covering each of its cells.  Every group of the union is therefore read
+// and written exactly once, by exactly one workgroup, whatever the overlap pattern.
+//
+// A lane keeps its column group while it walks down the rows, so everything that depends on columns only (which
+// cells of the group each op covers) is folded into a few bit masks once per column chunk; per row only the
+// row-range tests remain.  NK = ops held in registers (scalar loads, fully unrolled).
+struct OpRec {
+  int info;  // type | src << 8 | alt << 16
+  int yu, yd, xl, xr;
+};
+
+template <int VEC, bool REWARD, int NK>
+__global__ void __launch_bounds__(256)
+k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const uint8_t* __restrict__ code,
+            const int32_t* __restrict__ plan_ro, int32_t* __restrict__ ws, double* __restrict__ sums,
+            unsigned long long* __restrict__ counters, int split, int min_ops, int agent_sel, int dbg) {
+  const int n = c->n_agents;
+  const int part = blockIdx.x % split;
+  // map index: (e,i) for local maps (one agent per env when agent_sel >= 0), e for global maps
+  const int m = (!REWARD && agent_sel >= 0) ? (blockIdx.x / split) * n + agent_sel : blockIdx.x / split;
+  const int k = blockIdx.y;  // op whose rectangle this workgroup walks
+  const int e = REWARD ? m : m / n;
+  const int slot = REWARD ? n : m % n;
+  const size_t wbase = (size_t)(e * (n + 1) + slot) * IPPM_WS_WORDS;
+  const int32_t* __restrict__ hdr = plan_ro + wbase + WS_PLAN;
+  const int nops = hdr[PL_NOPS];
+  if (k >= nops || nops > NK || nops < min_ops) return;  // (another instantiation handles other plan sizes)
+  __shared__ float s_red[4][6];
+  OpRec op[NK];
+#pragma unroll
+  for (int o = 0; o < NK; ++o) {
+    const int32_t* p = plan_ro + wbase + WS_OPS + o * OP_WORDS;  // uniform address: scalar loads
+    const bool on = o < nops;
+    op[o].info = on ? (p[OP_TYPE] | (p[OP_SRC] << 8) | (p[OP_ALT] << 16)) : 0;
+    op[o].yu = on ? p[OP_YU] : 0; op[o].yd = on ? p[OP_YD] : 0;
+    op[o].xl = on ? p[OP_XL] : 0; op[o].xr = on ? p[OP_XR] : 0;  // empty rect: never covers
+  }
+  int kyu = 0, kyd = 0, kxl = 0, kxr = 0;
+#pragma unroll
+  for (int o = 0; o < NK; ++o)
+    if (o == k) { kyu = op[o].yu; kyd = op[o].yd; kxl = op[o].xl; kxr = op[o].xr; }
+  const int gx = c->grid_x, gy = c->grid_y, S = c->tile_stride;
+  const bool k_is_last = hdr[PL_LAST] == k;
+  const float lc = c->logit_clip, wt = c->logit_weight_thr;
+  const RowGeom g = make_geom<VEC>(kyu, kyd);
+  const int rows = kxr - kxl;
+  const int rows_per_wg = (rows + split - 1) / split;
+  const int r0 = part * rows_per_wg, r1 = min(rows, r0 + rows_per_wg);
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int sub = lane >> g.shift, gl = lane & (g.lpr - 1);
+  float* map = maps + (size_t)m * gx * gy;
+  const uint8_t* code_e = code + (size_t)e * n * S * S;
+  bool exceed = false;
+  float a1 = 0.f, aD = 0.f, aT = 0.f;
+  unsigned cells = 0, opcells = 0;
+  // Does any other op's rectangle intersect the rows/columns this workgroup walks?  If not (the common case) every
+  // group is covered by op k alone: a short branch-free loop does the job.
+  bool alone = true;
+  unsigned hitmask = 0;  // ops (including k) that can touch a group this workgroup walks: all others are skipped wholesale
+#pragma unroll
+  for (int o = 0; o < NK; ++o) {
+    // column ranges widened to whole VEC-cell groups: ownership is decided per group, so two rectangles that merely
+    // share an edge group already interact
+    const bool hit = op[o].xl < kxl + r1 && op[o].xr > kxl + r0 && (op[o].yu & ~(VEC - 1)) < ((kyd + VEC - 1) & ~(VEC - 1)) &&
+                     ((op[o].yd + VEC - 1) & ~(VEC - 1)) > (kyu & ~(VEC - 1));
+    alone &= (o == k) || !hit;
+    hitmask |= (hit || o == k) ? (1u << o) : 0u;
+  }
+  if (alone) {
+    int kinfo = 0;
+#pragma unroll
+    for (int o = 0; o < NK; ++o)
+      if (o == k) kinfo = op[o].info;
+    const bool isf = (kinfo & 0xFF) != 0;
+    const int alt = (kinfo >> 16) & 0xFF;
+    const float lm0 = isf ? c->logit_meas[alt][0] : 0.f, lm1 = isf ? c->logit_meas[alt][1] : 0.f;
+    const uint8_t* ctile = code_e + (size_t)((kinfo >> 8) & 0xFF) * S * S - (kyu & ~3);
+    const int wdt = kyd - kyu;
+    for (int gi = gl; gi < g.groups; gi += g.lpr) {
+      const int y = g.y0 + gi * VEC;
+      unsigned inm = 0;
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) inm |= ((unsigned)(y + q - kyu) < (unsigned)wdt) ? (1u << q) : 0u;
+      for (int row = r0 + wv * g.rpw + sub; row < r1; row += 4 * g.rpw) {
+        const size_t cell = (size_t)(kxl + row) * gy + y;
+        CellVec<VEC> mv = load_cells<VEC>(map + cell);
+        uint32_t cw = 0;
+        if (isf) cw = load_bytes<VEC>(ctile + (size_t)row * S + y);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+          const float b = mv.v[q];
+          float a = ippm_clampl(b, lc) + (((cw >> (8 * q)) & 1u) ? lm1 : lm0);
+          a = k_is_last ? a : ippm_clampl(a, lc);
+          const bool in = (inm >> q) & 1u;
+          a = in ? a : b;
+          exceed |= fabsf(a) > lc && in;
+          mv.v[q] = a;
+          if (REWARD && !(dbg & 1)) {
+            const float sel = (in && isf) ? 1.f : 0.f;
+            const float wa = ippm_weight_l(a, wt), wb = ippm_weight_l(b, wt);
+            const float hb = ippm_entropy_l(b, lc), ha = ippm_entropy_l(a, lc);
+            a1 += sel * (wa * (hb - ha));
+            aD += sel * ((wa - wb) * hb);
+            aT += sel * (wa * ha - wb * hb);
+          }
+        }
+        cells += __popc(inm);
+        store_cells<VEC>(map + cell, mv);
+      }
+    }
+    opcells = cells;
+  } else {
+  using Mask = typename std::conditional<(NK * VEC > 32), unsigned long long, unsigned>::type;
+  static_assert(NK * VEC <= 64, "op masks are at most 64 bits");
+  constexpr unsigned QM = (1u << VEC) - 1u;
+  for (int gi = gl; gi < g.groups; gi += g.lpr) {
+    const int y = g.y0 + gi * VEC;
+    // column-only part: cmask holds, VEC bits per op, which cells of my group lie inside the op's column range
+    Mask cmask = 0;
+#pragma unroll
+    for (int o = 0; o < NK; ++o) {
+      if (!((hitmask >> o) & 1u)) continue;
+      unsigned mq = 0;
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) mq |= ((unsigned)(y + q - op[o].yu) < (unsigned)(op[o].yd - op[o].yu)) ? (1u << q) : 0u;
+      cmask |= (Mask)mq << (o * VEC);
+    }
+    for (int row = r0 + wv * g.rpw + sub; row < r1; row += 4 * g.rpw) {
+      const int x = kxl + row;
+      // row part: act = cells covered by op o in this row, for all ops
+      Mask act = 0;
+#pragma unroll
+      for (int o = 0; o < NK; ++o) {
+        if (!((hitmask >> o) & 1u)) continue;
+        const bool rowin = (unsigned)(x - op[o].xl) < (unsigned)(op[o].xr - op[o].xl);
+        act |= rowin ? (cmask & ((Mask)QM << (o * VEC))) : (Mask)0;
+      }
+      // ownership: a later op touching any cell of this group takes it over
+      if (k + 1 < NK && (act >> ((k + 1) * VEC)) != 0) continue;
+      const size_t cell = (size_t)x * gy + y;
+      // issue every load of this group (map cells + the measurement codes of all covering ops) before any use
+      CellVec<VEC> mv = load_cells<VEC>(map + cell);
+      uint32_t cw[NK];
+#pragma unroll
+      for (int o = 0; o < NK; ++o) {
+        cw[o] = 0;
+        if (!((hitmask >> o) & 1u)) continue;
+        if (o <= k && (op[o].info & 0xFF) && ((unsigned)(act >> (o * VEC)) & QM))
+          cw[o] = load_bytes<VEC>(code_e + (size_t)((op[o].info >> 8) & 0xFF) * S * S + (size_t)(x - op[o].xl) * S +
+                                  (y - (op[o].yu & ~3)));
+      }
+      const CellVec<VEC> old = mv;
+      float L[VEC];
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) L[q] = mv.v[q];
+      unsigned touched = 0, fusedm = 0;
+      // ordered clamp/add chain (mappings.py:80-124 in log-odds); ops that cover no lane of the wavefront are skipped
+#pragma unroll
+      for (int o = 0; o < NK; ++o) {
+        if (o > k) break;
+        if (!((hitmask >> o) & 1u)) continue;
+        const unsigned inm = (unsigned)(act >> (o * VEC)) & QM;
+        if (!__any(inm != 0u)) continue;
+        const bool isf = (op[o].info & 0xFF) != 0;
+        const int alt = (op[o].info >> 16) & 0xFF;
+        const float lm0 = isf ? c->logit_meas[alt][0] : 0.f, lm1 = isf ? c->logit_meas[alt][1] : 0.f;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+          // every op of the reference clips its input over the whole grid (mappings.py:110-111)
+          const float l = ippm_clampl(L[q], lc) + (((cw[o] >> (8 * q)) & 1u) ? lm1 : lm0);
+          L[q] = ((inm >> q) & 1u) ? l : L[q];
+        }
+        touched |= inm;
+        fusedm |= isf ? inm : 0u;
+        opcells += __popc(inm);
+      }
+      cells += __popc(touched);
+      // outputs of the plan's last op stay unclamped; every other cell was clipped again by a later full-grid op
+      const unsigned keep = k_is_last ? ((unsigned)(act >> (k * VEC)) & QM) : 0u;
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) {
+        const float b = mv.v[q];
+        float a = ((keep >> q) & 1u) ? L[q] : ippm_clampl(L[q], lc);
+        a = ((touched >> q) & 1u) ? a : b;
+        exceed |= fabsf(a) > lc && ((touched >> q) & 1u);
+        mv.v[q] = a;
+      }
+      if (REWARD && __any(fusedm != 0)) {
+        // information-gain terms of the cells that received a measurement (utils/reward.py:68-82)
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+          const float sel = ((fusedm >> q) & 1u) ? 1.f : 0.f;
+          const float b = old.v[q], a = mv.v[q];
+          const float wa = ippm_weight_l(a, wt), wb = ippm_weight_l(b, wt);
+          const float hb = ippm_entropy_l(b, lc), ha = ippm_entropy_l(a, lc);
+          a1 += sel * (wa * (hb - ha));
+          aD += sel * ((wa - wb) * hb);
+          aT += sel * (wa * ha - wb * hb);
+        }
+      }
+      store_cells<VEC>(map + cell, mv);
+    }
+  }
+  }  // !alone
+  if (__any(exceed) && lane == 0) ws[wbase + WS_FLAG_A] = 1;
+  // block reduction of the reward terms and work counters: one atomic per workgroup and quantity
+  {
+    const float fc = ippm_wave_sum((float)cells), fo = ippm_wave_sum((float)opcells);
+    if (REWARD) { a1 = ippm_wave_sum(a1); aD = ippm_wave_sum(aD); aT = ippm_wave_sum(aT); }
+    if (lane == 0) { s_red[wv][0] = a1; s_red[wv][1] = aD; s_red[wv][2] = aT; s_red[wv][3] = fc; s_red[wv][4] = fo; }
+    __syncthreads();
+    if (threadIdx.x < 5 && !(dbg & 2)) {
+      const float t = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
+      if (threadIdx.x < 3) {
+        if (REWARD && t != 0.f) atomicAdd(&sums[(size_t)e * 8 + SUM_ACC1 + threadIdx.x], (double)t);
+      } else if (counters && t > 0.f) {
+        const int cslot = blockIdx.x & (IPPM_COUNTER_SLOTS - 1);
+        atomicAdd(&counters[cslot * 8 + (REWARD ? 3 : 1) + (threadIdx.x - 3)], (unsigned long long)t);
+      }
+    }
+  }
+}
+
+// Fallback for plans with more than 10 ops (more than 8 agents): walks the bounding hull of the plan with the op
+// table in LDS.  Same per-cell semantics, no attempt at speed.
+template <int VEC, bool REWARD>
+__global__ void __launch_bounds__(256)
+k_apply_ops_generic(const ippm_config* __restrict__ c, float* __restrict__ maps, const uint8_t* __restrict__ code,
+                    int32_t* __restrict__ ws, double* __restrict__ sums, unsigned long long* __restrict__ counters, int split,
+                    int min_ops, int agent_sel) {
+  const int n = c->n_agents;
+  const int part = blockIdx.x % split;
+  const int m = (!REWARD && agent_sel >= 0) ? (blockIdx.x / split) * n + agent_sel : blockIdx.x / split;
+  const int e = REWARD ? m : m / n;
+  const int slot = REWARD ? n : m % n;
+  int32_t* w = ws + (size_t)(e * (n + 1) + slot) * IPPM_WS_WORDS;
+  const int32_t* hdr = w + WS_PLAN;
+  const int nops = hdr[PL_NOPS];
+  if (nops < min_ops) return;
+  __shared__ int32_t s_ops[IPPM_MAX_OPS * OP_WORDS];
+  __shared__ float s_red[4][6];
+  for (int q = threadIdx.x; q < nops * OP_WORDS; q += blockDim.x) s_ops[q] = w[WS_OPS + q];
+  __syncthreads();
+  const int gx = c->grid_x, gy = c->grid_y, S = c->tile_stride;
+  const int X0 = hdr[PL_X0], X1 = hdr[PL_X1], last_op = hdr[PL_LAST];
+  const float lc = c->logit_clip, wt = c->logit_weight_thr;
+  const RowGeom g = make_geom<VEC>(hdr[PL_Y0], hdr[PL_Y1]);
+  const int rows = X1 - X0;
+  const int rows_per_wg = (rows + split - 1) / split;
+  const int r0 = part * rows_per_wg, r1 = min(rows, r0 + rows_per_wg);
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int sub = lane >> g.shift, gl = lane & (g.lpr - 1);
+  float* map = maps + (size_t)m * gx * gy;
+  const uint8_t* code_e = code + (size_t)e * n * S * S;
+  bool exceed = false;
+  float a1 = 0.f, aD = 0.f, aT = 0.f;
+  unsigned cells = 0, opcells = 0;
+  for (int row = r0 + wv * g.rpw + sub; row < r1; row += 4 * g.rpw) {
+    const int x = X0 + row;
+    for (int gi = gl; gi < g.groups; gi += g.lpr) {
+      const int y = g.y0 + gi * VEC;
+      bool need = false;
+      for (int o = 0; o < nops; ++o) {
+        const int32_t* op = s_ops + o * OP_WORDS;
+        need |= (x >= op[OP_XL] && x < op[OP_XR] && y + VEC > op[OP_YU] && y < op[OP_YD]);
+      }
+      if (!need) continue;
+      const size_t cell = (size_t)x * gy + y;
+      CellVec<VEC> mv = load_cells<VEC>(map + cell);
+      float L[VEC];
+      int lastt[VEC];
+      bool fused[VEC];
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) { L[q] = mv.v[q]; lastt[q] = -1; fused[q] = false; }
+      for (int o = 0; o < nops; ++o) {
+        const int32_t* op = s_ops + o * OP_WORDS;
+        if (!(x >= op[OP_XL] && x < op[OP_XR] && y + VEC > op[OP_YU] && y < op[OP_YD])) continue;
+        uint32_t cw = 0;
+        float lm0 = 0.f, lm1 = 0.f;
+        if (op[OP_TYPE]) {
+          cw = load_bytes<VEC>(code_e + (size_t)op[OP_SRC] * S * S + (size_t)(x - op[OP_XL]) * S + (y - (op[OP_YU] & ~3)));
+          lm0 = c->logit_meas[op[OP_ALT]][0];
+          lm1 = c->logit_meas[op[OP_ALT]][1];
+        }
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+          const int yy = y + q;
+          if (yy >= op[OP_YU] && yy < op[OP_YD]) {
+            L[q] = ippm_clampl(L[q], lc);
+            if (op[OP_TYPE]) { L[q] += ((cw >> (8 * q)) & 1u) ? lm1 : lm0; fused[q] = true; }
+            lastt[q] = o;
+            ++opcells;
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < VEC; ++q) {
+        if (lastt[q] < 0) continue;
+        ++cells;
+        const float b = mv.v[q];
+        float a = L[q];
+        if (lastt[q] != last_op) a = ippm_clampl(a, lc);
+        exceed |= fabsf(a) > lc;
+        mv.v[q] = a;
+        if (REWARD && fused[q]) {
+          const float wa = ippm_weight_l(a, wt), wb = ippm_weight_l(b, wt);
+          const float hb = ippm_entropy_l(b, lc), ha = ippm_entropy_l(a, lc);
+          a1 += wa * (hb - ha);
+          aD += (wa - wb) * hb;
+          aT += wa * ha - wb * hb;
+        }
+      }
+      store_cells<VEC>(map + cell, mv);
+    }
+  }
+  if (__any(exceed) && lane == 0) w[WS_FLAG_A] = 1;
+  {
+    const float fc = ippm_wave_sum((float)cells), fo = ippm_wave_sum((float)opcells);
+    if (REWARD) { a1 = ippm_wave_sum(a1); aD = ippm_wave_sum(aD); aT = ippm_wave_sum(aT); }
+    if (lane == 0) { s_red[wv][0] = a1; s_red[wv][1] = aD; s_red[wv][2] = aT; s_red[wv][3] = fc; s_red[wv][4] = fo; }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+      const float t = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
+      if (threadIdx.x < 3) {
+        if (REWARD && t != 0.f) atomicAdd(&sums[(size_t)e * 8 + SUM_ACC1 + threadIdx.x], (double)t);
+      } else if (counters && t > 0.f) {
+        const int cslot = blockIdx.x & (IPPM_COUNTER_SLOTS - 1);
+        atomicAdd(&counters[cslot * 8 + (REWARD ? 3 : 1) + (threadIdx.x - 3)], (unsigned long long)t);
+      }
+    }
+  }
+}
+
 __global__ void k_reward_finalize(const ippm_config* __restrict__ c, double* __restrict__ sums,
                                   float* __restrict__ reward, int n_envs) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -218,6 +717,28 @@ __global__ void k_reward_finalize(const ippm_config* __restrict__ c, double* __r
   const double cells = (double)c->grid_x * (double)c->grid_y;
   reward[e * 2] = (float)(22.0 * (s1 / s2) - 0.5);        // utils/reward.py:38-40
   reward[e * 2 + 1] = (float)(10.0 * (s1 / cells) - 0.17);  // utils/reward.py:37
+}
+
+// full-grid weighted entropy per map (initialisation of T, evaluation metrics)
+__global__ void __launch_bounds__(256)
+k_weighted_entropy(const ippm_config* __restrict__ c, const float* __restrict__ maps, const uint8_t* __restrict__ truth,
+                   double* __restrict__ out, int maps_per_truth) {
+  const int m = blockIdx.y;
+  const size_t total = (size_t)c->grid_x * c->grid_y;
+  const float* p = maps + (size_t)m * total;
+  const uint8_t* t = truth ? truth + (size_t)(m / maps_per_truth) * total : nullptr;
+  const float lc = c->logit_clip, wt = c->logit_weight_thr;
+  float acc = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = p[i];
+    const float wgt = t ? (float)t[i] : ippm_weight_l(v, wt);
+    acc += wgt * ippm_entropy_l(v, lc);
+  }
+  acc = ippm_wave_sum(acc);
+  __shared__ float s[4];
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&out[m], (double)(s[0] + s[1] + s[2] + s[3]));
 }
 
 // ======================================================================================================
@@ -391,7 +912,8 @@ __global__ void k_mask_act_move(const ippm_config* __restrict__ c, const int64_t
 // ======================================================================================================
 static inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int grid1(size_t n, int b = 256) { return (int)((n + b - 1) / b); }
-int ippm_env_int(const char* name, int dflt) {
+// tuning knob (row splits per tile/map); the defaults are the measured best on MI355X
+static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v && *v ? atoi(v) : dflt;
 }
@@ -406,7 +928,7 @@ extern "C" int ippm_reset_episode(ippm_ctx* ctx, const int64_t* episode, int32_t
   hipLaunchKernelGGL(k_reset_scalars, dim3(grid1((size_t)n_envs * per, 64)), dim3(64), 0, S_(stream), ctx->dcfg, episode, pos,
                      split_pct, comm_range_out, ws, sums, n_envs);
   IPPM_LAUNCH_CHECK("reset_scalars");
-  const size_t cells = (size_t)ippm_host_gxp(c) * ippm_host_gyp(c);  // padded, patch-tiled map storage
+  const size_t cells = (size_t)c.grid_x * c.grid_y;
   if (truth) {
     hipLaunchKernelGGL(k_fill_truth, dim3(min(64, grid1(cells)), n_envs), dim3(256), 0, S_(stream), ctx->dcfg, split_pct,
                        truth, n_envs);
@@ -422,6 +944,20 @@ extern "C" int ippm_reset_episode(ippm_ctx* ctx, const int64_t* episode, int32_t
                        cells * n_envs);
     IPPM_LAUNCH_CHECK("fill_global");
   }
+  return 0;
+}
+
+extern "C" int ippm_logodds_to_prob(ippm_ctx* ctx, const float* src, float* dst, int64_t n, void* stream) {
+  if (!ctx || !src || !dst) { ippm_set_error("ippm_logodds_to_prob: null argument"); return -1; }
+  hipLaunchKernelGGL(k_logodds_to_prob, dim3(min(4096, grid1((size_t)n))), dim3(256), 0, S_(stream), src, dst, (size_t)n);
+  IPPM_LAUNCH_CHECK("logodds_to_prob");
+  return 0;
+}
+
+extern "C" int ippm_prob_to_logodds(ippm_ctx* ctx, const float* src, float* dst, int64_t n, void* stream) {
+  if (!ctx || !src || !dst) { ippm_set_error("ippm_prob_to_logodds: null argument"); return -1; }
+  hipLaunchKernelGGL(k_prob_to_logodds, dim3(min(4096, grid1((size_t)n))), dim3(256), 0, S_(stream), src, dst, (size_t)n);
+  IPPM_LAUNCH_CHECK("prob_to_logodds");
   return 0;
 }
 
@@ -441,6 +977,31 @@ extern "C" int ippm_footprint(ippm_ctx* ctx, const int32_t* pos, int32_t* rect, 
   return 0;
 }
 
+extern "C" int ippm_sense_update(ippm_ctx* ctx, const int64_t* episode, const int32_t* pos, const uint8_t* truth,
+                                 float* local, const uint8_t* flips, uint8_t* code, int32_t* rect, int32_t* ws,
+                                 int32_t stage, int32_t agent_sel, int32_t n_envs, void* stream) {
+  if (!ctx || !pos || !truth || !local || !code || !rect) { ippm_set_error("ippm_sense_update: null argument"); return -1; }
+  if (!flips && !episode) { ippm_set_error("ippm_sense_update: Philox flips need the episode ids"); return -1; }
+  if (agent_sel >= ctx->cfg.n_agents) { ippm_set_error("ippm_sense_update: agent_sel out of range"); return -1; }
+  const int maps = agent_sel >= 0 ? n_envs : n_envs * ctx->cfg.n_agents;
+  const int split = std::max(1, env_int("IPPM_SPLIT_K3", 2));
+  dim3 grid((unsigned)maps * split), block(256);
+  const int unr = env_int("IPPM_UNROLL_K3", 2);
+#define IPPM_K3_LAUNCH(V, U)                                                                                              \
+  hipLaunchKernelGGL((k_sense_update<V, U>), grid, block, 0, S_(stream), ctx->dcfg, episode, pos, truth, local, flips, code, \
+                     rect, ws, ctx->dcounters, stage, agent_sel, split)
+  if (ctx->vec == 4) {
+    if (unr >= 4) IPPM_K3_LAUNCH(4, 4);
+    else if (unr >= 2) IPPM_K3_LAUNCH(4, 2);
+    else IPPM_K3_LAUNCH(4, 1);
+  } else {
+    IPPM_K3_LAUNCH(1, 1);
+  }
+#undef IPPM_K3_LAUNCH
+  IPPM_LAUNCH_CHECK("sense_update");
+  return 0;
+}
+
 extern "C" int ippm_comm_matrix(ippm_ctx* ctx, const int64_t* episode, const int32_t* pos, const float* comm_range,
                                 const double* draws, uint8_t* comm, int32_t t, int32_t n_envs, void* stream) {
   if (!ctx || !pos || !comm) { ippm_set_error("ippm_comm_matrix: null argument"); return -1; }
@@ -451,6 +1012,32 @@ extern "C" int ippm_comm_matrix(ippm_ctx* ctx, const int64_t* episode, const int
   return 0;
 }
 
+// The three instantiations share one plan: <= 6 ops and 7..10 ops take the register paths (workgroup column per
+// op), larger plans the generic path.  Each launch returns immediately for plans it does not own.
+template <bool REWARD>
+static void launch_apply(ippm_ctx* ctx, float* maps, const uint8_t* code, int32_t* ws, double* sums, int n_maps, int split,
+                         hipStream_t st, int agent_sel = -1) {
+  const int max_ops = ctx->cfg.n_agents + 1;
+  dim3 block(256);
+#define IPPM_APPLY(V, NK, MINOPS)                                                                                      \
+  hipLaunchKernelGGL((k_apply_ops<V, REWARD, NK>), dim3((unsigned)n_maps* split, std::min(max_ops, NK)), block, 0, st, \
+                     ctx->dcfg, maps, code, ws, ws, sums, ctx->dcounters, split, MINOPS, agent_sel, env_int("IPPM_DEBUG", 0))
+  if (ctx->vec == 4) {
+    IPPM_APPLY(4, 6, 1);
+    if (max_ops > 6) IPPM_APPLY(4, 10, 7);
+    if (max_ops > 10)
+      hipLaunchKernelGGL((k_apply_ops_generic<4, REWARD>), dim3((unsigned)n_maps * 8), block, 0, st, ctx->dcfg, maps, code, ws,
+                         sums, ctx->dcounters, 8, 11, agent_sel);
+  } else {
+    IPPM_APPLY(1, 6, 1);
+    if (max_ops > 6) IPPM_APPLY(1, 10, 7);
+    if (max_ops > 10)
+      hipLaunchKernelGGL((k_apply_ops_generic<1, REWARD>), dim3((unsigned)n_maps * 8), block, 0, st, ctx->dcfg, maps, code, ws,
+                         sums, ctx->dcounters, 8, 11, agent_sel);
+  }
+#undef IPPM_APPLY
+}
+
 extern "C" int ippm_fuse_local(ippm_ctx* ctx, float* local, const uint8_t* code, const int32_t* rect, const int32_t* pos,
                                const uint8_t* comm, int32_t* ws, int32_t agent_sel, int32_t n_envs, void* stream) {
   if (!ctx || !local || !code || !rect || !pos || !comm || !ws) { ippm_set_error("ippm_fuse_local: null argument"); return -1; }
@@ -458,7 +1045,7 @@ extern "C" int ippm_fuse_local(ippm_ctx* ctx, float* local, const uint8_t* code,
   const int maps = agent_sel >= 0 ? n_envs : n_envs * ctx->cfg.n_agents;
   hipLaunchKernelGGL(k_plan, dim3(grid1(maps, 64)), dim3(64), 0, S_(stream), ctx->dcfg, rect, pos, comm, ws, 0, n_envs, agent_sel);
   IPPM_LAUNCH_CHECK("plan_local");
-  ippm_launch_apply(false, ctx, local, code, ws, nullptr, maps, std::max(1, ippm_env_int("IPPM_SPLIT_K4", 1)), S_(stream), agent_sel);
+  launch_apply<false>(ctx, local, code, ws, nullptr, maps, std::max(1, env_int("IPPM_SPLIT_K4", 1)), S_(stream), agent_sel);
   IPPM_LAUNCH_CHECK("fuse_local");
   return 0;
 }
@@ -472,10 +1059,21 @@ extern "C" int ippm_fuse_global_reward(ippm_ctx* ctx, float* global, const uint8
   }
   hipLaunchKernelGGL(k_plan, dim3(grid1(n_envs, 64)), dim3(64), 0, S_(stream), ctx->dcfg, rect, pos, nullptr, ws, 1, n_envs, -1);
   IPPM_LAUNCH_CHECK("plan_global");
-  ippm_launch_apply(true, ctx, global, code, ws, sums, n_envs, std::max(1, ippm_env_int("IPPM_SPLIT_K5", 1)), S_(stream), -1);
+  launch_apply<true>(ctx, global, code, ws, sums, n_envs, std::max(1, env_int("IPPM_SPLIT_K5", 1)), S_(stream));
   IPPM_LAUNCH_CHECK("fuse_global");
   hipLaunchKernelGGL(k_reward_finalize, dim3(grid1(n_envs)), dim3(256), 0, S_(stream), ctx->dcfg, sums, reward, n_envs);
   IPPM_LAUNCH_CHECK("reward_finalize");
+  return 0;
+}
+
+extern "C" int ippm_weighted_entropy(ippm_ctx* ctx, const float* maps, const uint8_t* truth, int32_t maps_per_truth,
+                                     double* out, int32_t n_maps, void* stream) {
+  if (!ctx || !maps || !out) { ippm_set_error("ippm_weighted_entropy: null argument"); return -1; }
+  IPPM_HIP(hipMemsetAsync(out, 0, sizeof(double) * n_maps, S_(stream)));
+  const size_t cells = (size_t)ctx->cfg.grid_x * ctx->cfg.grid_y;
+  hipLaunchKernelGGL(k_weighted_entropy, dim3(min(32, grid1(cells)), n_maps), dim3(256), 0, S_(stream), ctx->dcfg, maps, truth,
+                     out, maps_per_truth > 0 ? maps_per_truth : 1);
+  IPPM_LAUNCH_CHECK("weighted_entropy");
   return 0;
 }
 

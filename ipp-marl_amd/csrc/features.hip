@@ -93,11 +93,10 @@ k_actor_features(const ippm_config* __restrict__ c, const float* __restrict__ lo
     ippm_pos_to_index(c, pj[0], pj[1], pj[2], s_idx[j][0], s_idx[j][1], s_idx[j][2]);
   }
   __syncthreads();
-  const int npcT = ippm_gyp(c) >> 3;
-  const float* map = local + (size_t)(e * n + i) * ((size_t)ippm_gxp(c) * ippm_gyp(c));  // patch-tiled storage
+  const float* map = local + (size_t)(e * n + i) * gx * gy;
   // pass 1: plane q = R(local map), plane F = R(footprint indicator)
   auto src_map = [&](int r, int col, float* v) {
-    v[0] = ippm_sigmoid(map[ippm_cell_off(r, col, npcT)]);  // maps hold log-odds; the resize averages probabilities
+    v[0] = ippm_sigmoid(map[(size_t)r * gy + col]);  // maps hold log-odds; the resize averages probabilities
     float f = 0.5f;
     for (int j = 0; j < n; ++j) {
       if (j == i || !s_recv[j]) continue;
@@ -118,7 +117,7 @@ k_actor_features(const ippm_config* __restrict__ c, const float* __restrict__ lo
   const int xoff = (cl[2] > fu[2]) ? full_x - hx : 0;
   const int yoff = (cl[0] > fu[0]) ? full_y - wy : 0;
   const uint8_t* cd = code + (size_t)(e * n + i) * S * S;
-  const int ycode0 = cl[0] - (cl[0] & ~7);
+  const int ycode0 = cl[0] - (cl[0] & ~3);
   const float mv0 = c->meas_value[k][0], mv1 = c->meas_value[k][1];
   TabView tfp;
   tfp.n = fp_n[k];
@@ -188,10 +187,9 @@ k_critic_features(const ippm_config* __restrict__ c, const float* __restrict__ g
     s_act[j] = action[e * n + j];
   }
   __syncthreads();
-  const int npcT = ippm_gyp(c) >> 3;
-  const float* map = global + (size_t)e * ((size_t)ippm_gxp(c) * ippm_gyp(c));
+  const float* map = global + (size_t)e * gx * gy;
   auto src_map = [&](int r, int col, float* v) {
-    v[0] = ippm_sigmoid(map[ippm_cell_off(r, col, npcT)]);
+    v[0] = ippm_sigmoid(map[(size_t)r * gy + col]);
     float f = 0.5f;
     for (int j = 0; j < n; ++j)
       if (r >= s_rect[j][2] && r < s_rect[j][3] && col >= s_rect[j][0] && col < s_rect[j][1]) f = 1.f;
@@ -234,15 +232,12 @@ __global__ void __launch_bounds__(256)
 k_reward_pair(const ippm_config* __restrict__ c, const float* __restrict__ before, const float* __restrict__ after,
               double* __restrict__ out /* [n,2] S1,S2 */) {
   const int m = blockIdx.y;
-  const int gx = c->grid_x, gy = c->grid_y, npc = ippm_gyp(c) >> 3;
-  const size_t total = (size_t)ippm_gxp(c) * ippm_gyp(c);  // walk the tiled storage, skip the padding cells
+  const size_t total = (size_t)c->grid_x * c->grid_y;
   const float* b = before + (size_t)m * total;
   const float* a = after + (size_t)m * total;
   const float lc = c->logit_clip, wt = c->logit_weight_thr;
   float s1 = 0.f, s2 = 0.f;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int patch = (int)(i >> 5), x = (patch / npc) * 4 + (int)((i >> 3) & 3), y = (patch % npc) * 8 + (int)(i & 7);
-    if (x >= gx || y >= gy) continue;
     const float wa = ippm_weight_l(a[i], wt);
     const float hb = ippm_entropy_l(b[i], lc), ha = ippm_entropy_l(a[i], lc);
     s1 += wa * (hb - ha);
@@ -317,7 +312,7 @@ extern "C" int ippm_reward_from_maps(ippm_ctx* ctx, const float* before, const f
                                      int32_t n_maps, void* stream) {
   if (!ctx || !before || !after || !sums) { ippm_set_error("ippm_reward_from_maps: null argument"); return -1; }
   IPPM_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * n_maps, S_(stream)));
-  const size_t cells = (size_t)ippm_host_gxp(ctx->cfg) * ippm_host_gyp(ctx->cfg);
+  const size_t cells = (size_t)ctx->cfg.grid_x * ctx->cfg.grid_y;
   const int gxb = (int)std::min<size_t>(32, (cells + 255) / 256);
   hipLaunchKernelGGL(k_reward_pair, dim3(gxb, n_maps), dim3(256), 0, S_(stream), ctx->dcfg, before, after, sums);
   IPPM_LAUNCH_CHECK("reward_pair");

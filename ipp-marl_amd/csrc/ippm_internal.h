@@ -65,17 +65,6 @@ struct ippm_ctx {
 };
 
 void ippm_set_error(const std::string& msg);
-int ippm_env_int(const char* name, int dflt);  // tuning knobs (IPPM_SPLIT_K3/K4/K5, ...); defaults = measured best
-void ippm_launch_apply(bool reward, ippm_ctx* ctx, float* maps, const uint8_t* code, int32_t* ws, double* sums, int n_maps,
-                       int split, hipStream_t st, int agent_sel);
-
-// ---- map storage: patch-tiled -----------------------------------------------------------------------------
-// A belief map is stored as 4-row x 8-column patches of 32 floats = one 128-byte line, patches row-major
-// ([gxp/4][gyp/8][4][8], gxp/gyp = grid rounded up to 4/8).  A footprint then touches whole lines (read over-fetch
-// 1.1x instead of 1.4-1.9x for row segments of 120-360 bytes) and a wavefront instruction covers eight
-// consecutive patches = 1 KiB contiguous (DESIGN.md "patch-tiled maps").
-static inline int ippm_host_gxp(const ippm_config& c) { return (c.grid_x + 3) & ~3; }
-static inline int ippm_host_gyp(const ippm_config& c) { return (c.grid_y + 7) & ~7; }
 int ippm_check_hip(hipError_t err, const char* what);
 #define IPPM_HIP(call)                                       \
   do {                                                       \
@@ -86,13 +75,6 @@ int ippm_check_hip(hipError_t err, const char* what);
 
 // ---- device helpers ------------------------------------------------------------------------------------
 #ifdef __HIPCC__
-
-__device__ __forceinline__ int ippm_gxp(const ippm_config* c) { return (c->grid_x + 3) & ~3; }
-__device__ __forceinline__ int ippm_gyp(const ippm_config* c) { return (c->grid_y + 7) & ~7; }
-// float offset of cell (x, y) inside one tiled map; npc = patches per patch-row = gyp / 8
-__device__ __forceinline__ size_t ippm_cell_off(int x, int y, int npc) {
-  return ((size_t)(x >> 2) * npc + (y >> 3)) * 32 + ((x & 3) << 3) + (y & 7);
-}
 
 __device__ __forceinline__ float ippm_clipf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 

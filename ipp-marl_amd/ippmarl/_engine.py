@@ -51,10 +51,13 @@ class EpisodeEngine:
 
     # ---- maps -------------------------------------------------------------------------------------------
     def _to_logodds(self, prob: np.ndarray) -> torch.Tensor:
-        return self.env._to_logodds(torch.from_numpy(np.ascontiguousarray(prob, dtype=np.float32)))
+        src = torch.from_numpy(np.ascontiguousarray(prob, dtype=np.float32)).to(self.env.device)
+        dst = torch.empty_like(src)
+        self.env.ctx.call("ippm_prob_to_logodds", _ffi.ptr(src), _ffi.ptr(dst), src.numel(), self.env.stream)
+        return dst
 
     def _to_prob(self, logodds: torch.Tensor) -> np.ndarray:
-        return self.env._to_prob(logodds).cpu().numpy()
+        return self.env._to_prob(logodds.contiguous()).cpu().numpy()
 
     def get_local(self, i: int) -> np.ndarray:
         return self._to_prob(self.env.local[0, i])
@@ -86,7 +89,7 @@ class EpisodeEngine:
         yu, yd, xl, xr = (int(v) for v in env.rect[0, i].cpu())
         pos = env.pos[0, i].cpu().numpy()
         k = min(max((int(pos[2]) - d.min_altitude) // d.spacing, 0), d.space_z - 1)
-        off = yu & 7
+        off = yu & 3
         codes = env.code[0, i, : xr - xl, off: off + yd - yu].cpu().numpy()
         meas = np.where(codes > 0, d.meas_value[k, 1], d.meas_value[k, 0]).astype(np.float32)
         m2c = np.full((d.grid_x, d.grid_y), 0.5, dtype=np.float32)
@@ -117,7 +120,7 @@ class EpisodeEngine:
                 rect, codes = [yu, yd, xl, xr], (vals > 0.5).astype(np.uint8)
         yu, yd, xl, xr = rect
         tile = np.zeros((d.tile_stride, d.tile_stride), dtype=np.uint8)
-        tile[: xr - xl, (yu & 7): (yu & 7) + yd - yu] = codes
+        tile[: xr - xl, (yu & 3): (yu & 3) + yd - yu] = codes
         env.code[0, slot].copy_(torch.from_numpy(tile).to(env.device))
         env.rect[0, slot].copy_(torch.tensor(rect, dtype=torch.int32))
         # altitude level of the slot is read from pos[...,2] by the kernels

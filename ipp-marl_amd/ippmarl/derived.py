@@ -90,13 +90,9 @@ class DerivedConstants:
         self.logit_prior = float(np.log(self.prior / (1 - self.prior))) if 0 < self.prior < 1 else 0.0
         self.logit_clip = float(np.log(CLIP_HI / (1 - CLIP_HI)))
         self.logit_weight_thr = float(np.log(0.501 / 0.499))
-        # code/flip tile stride: widest footprint + 7 cells of patch-alignment slack, multiple of 8
-        need = max(max(2 * r for r in rx), max(2 * r for r in ry) + 7, 8)
-        self.tile_stride = (need + 7) // 8 * 8
-        # storage dims of the patch-tiled maps (4-row x 8-column patches) and of the padded truth rows
-        self.grid_xp = (self.grid_x + 3) // 4 * 4
-        self.grid_yp = (self.grid_y + 7) // 8 * 8
-        self.map_floats = self.grid_xp * self.grid_yp
+        # code/flip tile stride: widest footprint + 3 cells of alignment slack, multiple of 4
+        need = max(max(2 * r for r in rx), max(2 * r for r in ry) + 3, 4)
+        self.tile_stride = (need + 3) // 4 * 4
 
     # -- helpers shared by the host-side mirrors ------------------------------------------------------
     def position_to_index(self, position):

@@ -28,7 +28,7 @@ class Mapping:
         self.sensor = sensor
         self.prior = params["mapping"]["prior"]
         self.engine = EpisodeEngine(params, episode, device=device)
-        self.simulated_map = self.engine.env.truth_map[0].cpu().numpy().astype(np.float64)
+        self.simulated_map = self.engine.env.truth[0].cpu().numpy().astype(np.float64)
         self.simulation = _SimulationView(self.simulated_map)
         self._scratch_calls = 0
 
@@ -61,7 +61,7 @@ class Mapping:
         env, d = self.engine.env, self.engine.d
         out = np.zeros((1, d.n_agents, d.tile_stride, d.tile_stride), dtype=np.uint8)
         yu, yd, xl, xr = fc
-        out[0, i, : xr - xl, (yu & 7): (yu & 7) + yd - yu] = np.asarray(flips_tile, dtype=np.uint8).reshape(xr - xl, yd - yu)
+        out[0, i, : xr - xl, (yu & 3): (yu & 3) + yd - yu] = np.asarray(flips_tile, dtype=np.uint8).reshape(xr - xl, yd - yu)
         return torch.from_numpy(out).to(env.device)
 
     # ------------------------------------------------------------------------------------------------
@@ -76,7 +76,9 @@ class Mapping:
         # save the engine state this call borrows
         keep = {k: getattr(env, k).clone() for k in ("local", "code", "rect", "pos", "comm", "ws")}
         try:
-            lo = env._to_logodds(torch.from_numpy(np.ascontiguousarray(own_map_state, dtype=np.float32)))
+            cur = torch.from_numpy(np.ascontiguousarray(own_map_state, dtype=np.float32)).to(env.device)
+            lo = torch.empty_like(cur)
+            env.ctx.call("ippm_prob_to_logodds", _ffi.ptr(cur), _ffi.ptr(lo), cur.numel(), env.stream)
             n = d.n_agents
             if n < 2:
                 raise _ffi.IppmError("stand-alone fuse_map needs n_agents >= 2 (one slot for the map, the others for measurements)")
@@ -92,7 +94,9 @@ class Mapping:
                     env.comm[0, 0, s] = 1
                 env.fuse_local(agent=0)
                 lo = env.local[0, 0].clone()
-            return env._to_prob(lo).cpu().numpy()
+            out = torch.empty_like(lo)
+            env.ctx.call("ippm_logodds_to_prob", _ffi.ptr(lo), _ffi.ptr(out), lo.numel(), env.stream)
+            return out.cpu().numpy()
         finally:
             for k, v in keep.items():
                 getattr(env, k).copy_(v)

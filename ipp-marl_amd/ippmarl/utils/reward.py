@@ -13,13 +13,16 @@ def get_utility_reward(state: np.array, state_: np.array, simulated_map, agent_s
     dev = env.device
 
     def up(m):
-        return env._to_logodds(torch.from_numpy(np.ascontiguousarray(m, dtype=np.float32)))
+        src = torch.from_numpy(np.ascontiguousarray(m, dtype=np.float32)).to(dev)
+        dst = torch.empty_like(src)
+        env.ctx.call("ippm_prob_to_logodds", _ffi.ptr(src), _ffi.ptr(dst), src.numel(), env.stream)
+        return dst
 
     before, after = up(state), up(state_)
     sums = torch.zeros(1, 2, dtype=torch.float64, device=dev)
     env.ctx.call("ippm_reward_from_maps", _ffi.ptr(before), _ffi.ptr(after), _ffi.ptr(sums), None, 1, env.stream)
     s1, s2 = (float(v) for v in sums[0].cpu())
-    absolute = s1 / (env.d.grid_x * env.d.grid_y)
+    absolute = s1 / before.numel()
     return absolute, s1 / s2
 
 

@@ -44,11 +44,10 @@ class VecEnv:
         self.pos = z(E, N, 3, dtype=torch.int32)
         self.pos_pre = z(E, N, 3, dtype=torch.int32)
         self.rect = z(E, N, 4, dtype=torch.int32)
-        self.truth = z(E, d.grid_x, d.grid_yp, dtype=torch.uint8)   # rows padded to the patch width
-        # beliefs: float32 log-odds (0 = prior 0.5) in patch-tiled storage; posterior_local()/posterior_global()
-        # export row-major probabilities
-        self.local = z(E, N, d.map_floats, dtype=torch.float32)
-        self.glob = z(E, d.map_floats, dtype=torch.float32)
+        self.truth = z(E, d.grid_x, d.grid_y, dtype=torch.uint8)
+        # beliefs are stored as float32 log-odds (0 = prior 0.5); posterior_local()/posterior_global() export p
+        self.local = z(E, N, d.grid_x, d.grid_y, dtype=torch.float32)
+        self.glob = z(E, d.grid_x, d.grid_y, dtype=torch.float32)
         self.code = z(E, N, S, S, dtype=torch.uint8)
         self.comm = z(E, N, N, dtype=torch.uint8)
         self.comm_range = z(E, dtype=torch.float32)
@@ -81,25 +80,9 @@ class VecEnv:
         return sum(t.numel() * t.element_size() for t in vars(self).values() if isinstance(t, torch.Tensor))
 
     def _to_prob(self, logodds: torch.Tensor) -> torch.Tensor:
-        """Patch-tiled log-odds [..., map_floats] -> row-major probabilities [..., gx, gy]."""
-        src = logodds.contiguous()
-        n_maps = src.numel() // self.d.map_floats
-        out = torch.empty(*src.shape[:-1], self.d.grid_x, self.d.grid_y, dtype=torch.float32, device=self.device)
-        self.ctx.call("ippm_logodds_to_prob", self._p(src), self._p(out), n_maps, self.stream)
+        out = torch.empty_like(logodds)
+        self.ctx.call("ippm_logodds_to_prob", self._p(logodds), self._p(out), logodds.numel(), self.stream)
         return out
-
-    def _to_logodds(self, prob: torch.Tensor) -> torch.Tensor:
-        """Row-major probabilities [..., gx, gy] -> patch-tiled log-odds [..., map_floats]."""
-        src = prob.to(self.device, torch.float32).contiguous()
-        n_maps = src.numel() // (self.d.grid_x * self.d.grid_y)
-        out = torch.empty(*src.shape[:-2], self.d.map_floats, dtype=torch.float32, device=self.device)
-        self.ctx.call("ippm_prob_to_logodds", self._p(src), self._p(out), n_maps, self.stream)
-        return out
-
-    @property
-    def truth_map(self) -> torch.Tensor:
-        """Ground truth without the row padding, uint8 [E, gx, gy]."""
-        return self.truth[:, :, : self.d.grid_y]
 
     def posterior_local(self) -> torch.Tensor:
         """Occupancy probabilities of the agents' local maps, float32 [E,N,gx,gy] (the reference's local_map)."""
@@ -129,8 +112,7 @@ class VecEnv:
                       self._p(self.split_pct), self._p(self.comm_range), self._p(self.ws), self._p(self.sums), self.E,
                       self.stream)
         if truth is not None:
-            self.truth.zero_()
-            self.truth[:, :, : d.grid_y].copy_(torch.as_tensor(truth).to(self.device, torch.uint8))
+            self.truth.copy_(torch.as_tensor(truth).to(self.device, torch.uint8))
         if start_positions is not None:
             self.pos.copy_(torch.as_tensor(start_positions).to(self.device, torch.int32))
         self.t = 0
@@ -260,6 +242,6 @@ class VecEnv:
         for e in range(self.E):
             for i in range(N):
                 yu, yd, xl, xr = (int(v) for v in rects[e, i])
-                off = yu & 7
+                off = yu & 3
                 out[e, i, : xr - xl, off: off + yd - yu] = np.asarray(tiles[e][i], dtype=np.uint8).reshape(xr - xl, yd - yu)
         return torch.from_numpy(out).to(self.device)

@@ -33,7 +33,7 @@ def test_derived_constants_match_reference(golden, name):
                 full.append(f), clip.append(c)
     assert np.array_equal(np.array(full), fx[f"{name}_fp_full"])  # integer tables reproduce the float64 knife edges
     assert np.array_equal(np.array(clip), fx[f"{name}_fp_clip"])
-    assert d.tile_stride % 8 == 0 and d.tile_stride >= 2 * max(d.radius_y) + 7
+    assert d.tile_stride % 4 == 0 and d.tile_stride >= 2 * max(d.radius_y) + 3
 
 
 def test_measurement_tables_match_reference_arithmetic(golden):
