@@ -37,7 +37,10 @@ K3_BYTES_PER_CELL = 10
 
 def bench_params(args):
     from ippmarl.params import grid256_params
-    return grid256_params(experiment__missions__n_agents=args.agents)
+    if args.grid == 256:
+        return grid256_params(experiment__missions__n_agents=args.agents)
+    number = {128: 15, 512: 60, 1024: 120}[args.grid]   # other BASELINE.json grid sizes (parity-test configs; not the metric)
+    return grid256_params(experiment__missions__n_agents=args.agents, sensor__pixel__number_x=number, sensor__pixel__number_y=number)
 
 
 def cpu_baseline(params, budget_s=15.0):
@@ -78,6 +81,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--envs", type=int, default=1024, help="envs per GPU")
     ap.add_argument("--agents", type=int, default=4)
+    ap.add_argument("--grid", type=int, default=256, choices=[128, 256, 512, 1024])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-events", type=int, default=1, help="time every K3 launch with HIP events (roofline)")
     ap.add_argument("--train-rounds", type=int, default=2, help="COMA rounds (rollout with the actor + full update) timed after "

@@ -275,3 +275,55 @@ def test_graph_replay_matches_eager():
         assert torch.equal(a.local, b.local) and torch.equal(a.glob, b.glob)
         a.reset(eps + 100)
         b.reset(eps + 100)
+
+
+def test_c_abi_error_paths():
+    """Error behaviour of the C-ABI: negative return codes with a message, never a crash."""
+    import ctypes as C
+    from ippmarl import _ffi
+    from ippmarl.derived import DerivedConstants
+    lib = _ffi.load_library()
+    d = DerivedConstants(make_params("small"))
+    # rejected configurations
+    for mutate, needle in ((lambda c: setattr(c, "prior", 0.3), "prior"), (lambda c: setattr(c, "n_agents", 40), "n_agents"),
+                           (lambda c: setattr(c, "n_actions", 5), "num_actions"), (lambda c: setattr(c, "tile_stride", 8), "tile_stride")):
+        cfg = _ffi.make_config(d)
+        mutate(cfg)
+        h = C.c_void_p()
+        rc = lib.ippm_ctx_create(C.byref(cfg), C.byref(h))
+        assert rc < 0 and needle in lib.ippm_last_error().decode(), (rc, lib.ippm_last_error())
+    ctx = _ffi.Context(d)
+    stream = torch.cuda.current_stream().cuda_stream
+    with pytest.raises(_ffi.IppmError, match="null argument"):
+        ctx.call("ippm_footprint", None, None, None, 1, stream)
+    with pytest.raises(_ffi.IppmError, match="Philox"):
+        z = torch.zeros(16, device="cuda")
+        ctx.call("ippm_sense_update", None, z.data_ptr(), z.data_ptr(), z.data_ptr(), None, z.data_ptr(), z.data_ptr(), None, 0, -1, 0, stream)
+    with pytest.raises(_ffi.IppmError, match="policy"):
+        ctx.call("ippm_mask_act_move", None, z.data_ptr(), None, None, 7, 0, z.data_ptr(), z.data_ptr(), None, 0, stream)
+    with pytest.raises(_ffi.IppmError, match="agent_sel"):
+        ctx.call("ippm_fuse_local", z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), 99, 0, stream)
+    # the feature kernels need the 11 x 11 lattice the networks are wired for
+    p = make_params("small", environment__x_dim=40)
+    env = _env(p, 1)
+    env.reset([1])
+    with pytest.raises(_ffi.IppmError, match="11x11"):
+        env.build_observations(0)
+    ctx.close()
+
+
+def test_empty_mask_sets_fault_flag():
+    """All actions blocked (where the reference's torch.multinomial raises): fault flag + a boundary-valid move."""
+    from ippmarl.vec_env import POLICY_UNIFORM
+    params = make_params("small")
+    env = _env(params, 1)
+    env.reset([1])
+    # corner agent at 15 m boxed in by neighbours that will have moved next to it
+    start = torch.tensor([[[5, 0, 15], [0, 5, 15], [0, 0, 10], [0, 0, 15]]], dtype=torch.int32)
+    env.reset([1], start_positions=start)
+    acts = torch.tensor([[1, 2, 0, 0]], dtype=torch.int32)   # agents 0,1 move to (0,0,15)'s x/y neighbours? they move onto (0,0): blocks
+    env.build_observations(0, features=False)
+    from ippmarl.vec_env import POLICY_EXPLICIT
+    env.steps(0, policy=POLICY_EXPLICIT, actions=acts, features=False)
+    p = env.pos[0].cpu().numpy()
+    assert (p[:, :2] >= 0).all() and (p[:, :2] <= 50).all() and set(p[:, 2]) <= {5, 10, 15}
