@@ -314,16 +314,31 @@ def test_c_abi_error_paths():
 
 def test_empty_mask_sets_fault_flag():
     """All actions blocked (where the reference's torch.multinomial raises): fault flag + a boundary-valid move."""
-    from ippmarl.vec_env import POLICY_UNIFORM
+    from ippmarl.vec_env import POLICY_SAMPLE
     params = make_params("small")
-    env = _env(params, 1)
-    env.reset([1])
-    # corner agent at 15 m boxed in by neighbours that will have moved next to it
-    start = torch.tensor([[[5, 0, 15], [0, 5, 15], [0, 0, 10], [0, 0, 15]]], dtype=torch.int32)
-    env.reset([1], start_positions=start)
-    acts = torch.tensor([[1, 2, 0, 0]], dtype=torch.int32)   # agents 0,1 move to (0,0,15)'s x/y neighbours? they move onto (0,0): blocks
+    d = O.Derived(params)
+    env = _env(params, 2)
+    # env 0: agent 3 sits in the corner column (0,0); the three agents moving before it end up at (5,0), (0,5) and in its
+    # own column -> +x, +y and both vertical moves get masked (action_space.py:328-344), nothing is left.  env 1: harmless.
+    start = torch.tensor([[[10, 0, 15], [0, 10, 15], [0, 0, 15], [0, 0, 10]],
+                          [[25, 25, 15], [30, 30, 15], [10, 40, 10], [40, 10, 5]]], dtype=torch.int32)
+    env.reset([1, 2], start_positions=start)
+    want = [[1, 2, 5, 0], [4, 4, 4, 4]]
+    probs = torch.zeros(2, 4, 6)
+    for e in range(2):
+        for i in range(4):
+            probs[e, i, want[e][i]] = 1.0
     env.build_observations(0, features=False)
-    from ippmarl.vec_env import POLICY_EXPLICIT
-    env.steps(0, policy=POLICY_EXPLICIT, actions=acts, features=False)
-    p = env.pos[0].cpu().numpy()
-    assert (p[:, :2] >= 0).all() and (p[:, :2] <= 50).all() and set(p[:, 2]) <= {5, 10, 15}
+    env.steps(0, policy=POLICY_SAMPLE, probs=probs.to(env.device), features=False)
+    assert env.fault.cpu().tolist() == [1 << 3, 0]
+    assert env.mask[0, 3].cpu().tolist() == [0, 0, 0, 0, 0, 0]
+    p = env.pos.cpu().numpy()
+    assert p[0, :3].tolist() == [[5, 0, 15], [0, 5, 15], [0, 0, 10]]
+    assert p[0, 3].tolist() == [0, 0, 15]          # first boundary-valid action (up) keeps the state on the lattice
+    assert p[1].tolist() == [[30, 25, 15], [35, 30, 15], [15, 40, 10], [45, 10, 5]]
+    # the oracle raises in the same situation, like torch.multinomial in the reference
+    m = O.action_mask(d, np.array([0, 0, 10]))
+    m = O.apply_collision_mask(d, np.array([0, 0, 10]), m, [np.array([5, 0, 15]), np.array([0, 5, 15]), np.array([0, 0, 10])])
+    assert m.sum() == 0
+    with pytest.raises(ValueError):
+        O.uniform_valid_action(123, m)
