@@ -816,3 +816,154 @@ def sample_masked_action(word: int, probs_masked: np.ndarray) -> int:
             if acc > target:
                 return a
     return last
+
+
+# --------------------------------------------------------------------------------------
+# greedy information-gain baseline (IG_baseline.py:32-325) and its evaluation metrics (utils/utils.py:43-76)
+# --------------------------------------------------------------------------------------
+
+
+def ig_individual(d: Derived, position, mask: np.ndarray, map_state: np.ndarray):
+    """IG_baseline.get_individual_ig (:222-289): expected weighted entropy reduction over each candidate footprint.
+    Returns (action_positions, information_gains); masked actions get position 0 and gain 0 like the reference."""
+    positions, gains = [], []
+    for action in range(len(mask)):
+        if mask[action] == 0:
+            positions.append(0)
+            gains.append(0)
+            continue
+        new_position = action_to_position(d, position, action)
+        _, fc = project_field_of_view(d, new_position)
+        section = map_state[fc[2]:fc[3], fc[0]:fc[1]].copy()
+        noise = noise_of_altitude(new_position[2])
+        cw1 = bayes_update(section.copy(), 1 - noise, d.prior)
+        cw2 = bayes_update(section.copy(), noise, d.prior)
+        cw1[cw1 > 0.501] = 1
+        cw1[cw1 < 0.499] = 0
+        cw2[cw2 > 0.501] = 1
+        cw2[cw2 < 0.499] = 0
+        h = shannon_entropy(section)  # clips `section` in place: every later use sees the clipped values
+        ig = (section * (h - shannon_entropy(bayes_update(section, 1 - noise, d.prior))) * cw1
+              + (1 - section) * (shannon_entropy(section) - shannon_entropy(bayes_update(section, noise, d.prior))) * cw2)
+        positions.append(new_position)
+        gains.append(np.sum(ig) / 1000)
+    return positions, gains
+
+
+def ig_relative(gain_lists):
+    """get_relative_ig (:291-298): per-agent normalisation, in place."""
+    for a in range(len(gain_lists)):
+        total = sum(gain_lists[a])
+        for k in range(len(gain_lists[a])):
+            gain_lists[a][k] = gain_lists[a][k] / total
+    return gain_lists
+
+
+def ig_cell_utilities(position_lists, rel):
+    """get_cell_utilities (:300-322): discount candidate cells other agents also consider; in place, order-dependent."""
+    for a in range(len(position_lists)):
+        for k1 in range(len(position_lists[a])):
+            p1, g1 = position_lists[a][k1], rel[a][k1]
+            for b in range(len(position_lists)):
+                if b == a:
+                    continue
+                for k2 in range(len(position_lists[b])):
+                    p2, g2 = position_lists[b][k2], rel[b][k2]
+                    if np.array_equal(p1, p2) and type(p1) is np.ndarray:
+                        rel[a][k1] = g1 * (1 - g2)
+    return rel
+
+
+def target_entropy(d: Derived, gmap: np.ndarray, truth: np.ndarray) -> float:
+    """Mean entropy over the target cells ("eval" weights come from the ground truth; IG_baseline.py:84-97)."""
+    wh = w_entropy_map(d, None, gmap, truth, "eval")[0]
+    masked = wh.copy()
+    masked[truth == 0] = 0
+    counts = np.unique(truth, return_counts=True)[1]
+    return float(np.sum(masked) / counts[-1])
+
+
+def f1_target(gmap: np.ndarray, truth: np.ndarray) -> float:
+    """F1 of class 1 of the map thresholded at 0.5 (utils/utils.py:64-76, sklearn f1_score(average=None)[1])."""
+    pred = gmap > 0.5
+    t = truth == 1
+    tp, fp, fn = np.sum(pred & t), np.sum(pred & ~t), np.sum(~pred & t)
+    den = 2 * tp + fp + fn
+    return float(2 * tp / den) if den > 0 else 0.0
+
+
+class OracleIGBaseline:
+    """IG_baseline.execute (:56-220) with injected sensing randomness (see OracleEpisode for the conventions)."""
+
+    def __init__(self, params: Dict, episode: int, correctness: Callable, comm_draw: Optional[Callable] = None, exact: bool = False):
+        self.d = Derived(params)
+        self.d.exact = exact
+        self.episode = episode
+        self.truth = make_truth(self.d, episode)
+        self.correctness = correctness
+        self.comm_draw = comm_draw or (lambda i, j, t: 1.0)
+        self.communication = params["experiment"]["baselines"]["information_gain"]["communication"]
+        self.comm_range = episode_comm_range(self.d, episode)
+
+    def execute(self):
+        d, n = self.d, self.d.n_agents
+        agents = [dict(local_map=init_prior_map(d), position=None, map2communicate=None, stage=0) for _ in range(n)]
+
+        def sense(i):
+            ag = agents[i]
+            _, fc = project_field_of_view(d, ag["position"])
+            corr = np.asarray(self.correctness(i, ag["stage"], tile_shape(fc)))
+            ag["stage"] += 1
+            lm, _, _, m2c, _ = update_grid_map(d, self.truth, ag["position"], ag["local_map"], corr)
+            ag.update(local_map=lm, map2communicate=m2c)
+
+        current_global = agents[0]["local_map"].copy()
+        entropies = [target_entropy(d, current_global, self.truth)]
+        f1s = [f1_target(current_global, self.truth)]
+        rel_rewards, abs_rewards, altitudes, positions_log, gains_log, actions_log = [], [], [], [], [], []
+        for t in range(d.budget + 1):
+            if t == 0:
+                for i in range(n):
+                    agents[i]["position"] = start_state(d, i, self.episode)
+                    sense(i)
+            published = {i: dict(position=agents[i]["position"], map2communicate=agents[i]["map2communicate"]) for i in range(n)}
+            pos = [published[i]["position"] for i in range(n)]
+            for i in range(n):
+                ks = received_set(pos, i, self.comm_range, d.failure_rate, [self.comm_draw(i, j, t) for j in range(n)])
+                agents[i]["local_map"] = fuse_map(d, agents[i]["local_map"], {j: published[j] for j in ks}, i, "local")
+            if t == 0:
+                positions_log.append([p.copy() for p in pos])
+                current_global = fuse_map(d, current_global, published, None, "global")
+            next_positions, pos_lists, gain_lists = [], [], []
+            for i in range(n):
+                m = action_mask(d, agents[i]["position"])
+                m = apply_collision_mask(d, agents[i]["position"], m, next_positions)
+                ap, ig = ig_individual(d, agents[i]["position"], m, agents[i]["local_map"])
+                pos_lists.append(ap)
+                gain_lists.append(ig)
+                next_positions.append(agents[i]["position"])
+            gains_log.append([list(g) for g in gain_lists])
+            rel = ig_relative(gain_lists)
+            util = ig_cell_utilities(pos_lists, rel) if self.communication else rel
+            step_actions, alts, m2cs = [], [], []
+            for i in range(n):
+                a = int(np.argmax(util[i]))
+                agents[i]["position"] = action_to_position(d, agents[i]["position"], a)
+                sense(i)
+                m2cs.append(agents[i]["map2communicate"])
+                next_positions.append(agents[i]["position"])
+                alts.append(int(agents[i]["position"][2]))
+                step_actions.append(a)
+            actions_log.append(step_actions)
+            positions_log.append([p.copy() for p in next_positions])
+            altitudes.append(alts)
+            next_global = fuse_map(d, current_global, m2cs, None, "global")
+            current_global = next_global.copy()
+            _, rel_r, abs_r = global_reward(d, current_global, next_global, self.truth)  # SURVEY Q18: constants
+            rel_rewards.append(rel_r)
+            abs_rewards.append(abs_r)
+            entropies.append(target_entropy(d, next_global, self.truth))
+            f1s.append(f1_target(next_global, self.truth))
+        self.agents, self.global_map = agents, current_global
+        return dict(relative_return=sum(rel_rewards), absolute_return=sum(abs_rewards), altitudes=altitudes, entropies=entropies,
+                    f1=f1s, gains=gains_log, actions=actions_log, positions=positions_log)

@@ -467,8 +467,38 @@ def gen_coma_step():
          n_critic_params=np.array(sum(x.numel() for x in wrapper.critic_network.parameters())))
 
 
+# ------------------------------------------------------------------ IG baseline (BASELINE config 1)
+def gen_ig_baseline():
+    import marl_framework.IG_baseline as ref_ig
+    from marl_framework import constants
+    for tag, params, episode in (("ig_c1_e1", make_params("c1"), 1),
+                                 ("ig_small3_e4", make_params("small", experiment__missions__n_agents=3), 4)):
+        torch.manual_seed(99 + episode)
+        np.random.seed(77 + episode)
+        with Recorder() as rec:
+            ig = ref_ig.IG_baseline(params, None, episode)
+            gains = []
+            real = ig.get_individual_ig
+
+            def spy(position, mask, map_state, _real=real, _g=gains):
+                ap, g = _real(position, mask, map_state)
+                _g.append([float(v) for v in g])
+                return ap, g
+
+            ig.get_individual_ig = spy
+            rel, ab, altitudes, entropies, rmses = ig.execute()
+        n = params["experiment"]["missions"]["n_agents"]
+        T = params["experiment"]["constraints"]["budget"] + 1
+        packed = [np.packbits(c) for c in rec.correctness]
+        save(tag, episode=np.array(episode), relative_return=np.array(rel), absolute_return=np.array(ab),
+             altitudes=np.array(altitudes, dtype=np.int32), entropies=np.array(entropies, dtype=np.float64),
+             f1=np.array(rmses, dtype=np.float64), gains=np.array(gains).reshape(T, n, -1),
+             corr_packed=np.concatenate(packed), corr_lens=np.array([len(c) for c in rec.correctness], dtype=np.int32),
+             comm_draws=np.array(rec.comm))
+
+
 GENERATORS = [gen_derived_and_footprints, gen_start_states, gen_truth, gen_masks, gen_comm, gen_bayes_measurement,
-              gen_entropy_reward, gen_episodes, gen_td_lambda, gen_coma_step]
+              gen_entropy_reward, gen_episodes, gen_td_lambda, gen_coma_step, gen_ig_baseline]
 
 if __name__ == "__main__":
     check_schema()

@@ -208,3 +208,37 @@ def test_exact_mode_differs_only_by_reference_quantisation(golden, tag):
         np.testing.assert_allclose(np.array(rec["observations"]), fx["obs"][t], rtol=RTOL, atol=1e-6)
     assert_posteriors(np.array([a["local_map"] for a in ep.agents]), fx["final_local"], strict=False, msg="final local")
     assert_posteriors(ep.global_map, fx["final_global"], strict=False, msg="final global")
+
+
+IG_CASES = {"ig_c1_e1": dict(name="c1", over={}), "ig_small3_e4": dict(name="small", over=dict(experiment__missions__n_agents=3))}
+
+
+@pytest.mark.parametrize("tag", list(IG_CASES))
+def test_ig_baseline_replay(golden, tag):
+    """BASELINE config 1 (2 UAVs, default 493 x 493 grid, greedy information-gain planner on the CPU) and a smaller case:
+    the oracle's IG_baseline restatement against the reference's own run (SURVEY Q18 known answers)."""
+    fx = golden(tag)
+    params = make_params(IG_CASES[tag]["name"], **IG_CASES[tag]["over"])
+    n = params["experiment"]["missions"]["n_agents"]
+    corr = unpack_correctness(fx)
+    comm = fx["comm_draws"]
+    stage_of = {}
+
+    def correctness(i, s, shape):
+        # the reference draws in call order: n start sensings, then n per step
+        return corr[s * n + i].reshape(shape)
+
+    ig = O.OracleIGBaseline(params, int(fx["episode"]), correctness, comm_draw=lambda i, j, t: comm[(t * n + i) * n + j])
+    out = ig.execute()
+    assert np.array_equal(np.array(out["altitudes"]), fx["altitudes"])
+    np.testing.assert_allclose(np.array(out["gains"]), fx["gains"], rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose(out["entropies"], fx["entropies"], rtol=RTOL)
+    np.testing.assert_allclose(out["f1"], fx["f1"], rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose(out["relative_return"], fx["relative_return"], rtol=RTOL)
+    np.testing.assert_allclose(out["absolute_return"], fx["absolute_return"], rtol=RTOL)
+    if tag == "ig_c1_e1":   # SURVEY Q18: the baseline's returns are constants, the informative outputs are entropy and F1
+        np.testing.assert_allclose(out["relative_return"], -7.5, rtol=1e-9)
+        np.testing.assert_allclose(out["absolute_return"], -2.55, rtol=1e-9)
+        assert abs(out["entropies"][0] - 1.0) < 1e-12 and out["f1"][0] == 0.0
+        assert 0.55 < out["entropies"][-1] < 0.70 and 0.65 < out["f1"][-1] < 0.80   # sensor-noise dependent (survey probe: 0.618 / 0.729)
+        assert [a[0] for a in out["altitudes"]][:3] == [15, 10, 10]                 # descends after the first step
