@@ -86,6 +86,8 @@ typedef struct ippm_config {
   double failure_rate;                /* link drop probability (communication_log.py:46-54) */
   uint64_t philox_seed;               /* key of the counter-based RNG (production randomness) */
   double gamma, lambda_;              /* TD(lambda) (batch_memory.py:17-21) */
+  float logit_noise[IPPM_MAX_Z];      /* ln((1-noise)/noise) from the float64 noise level: the hypothetical updates of
+                                         IG_baseline.get_individual_ig use the scalar noise, not a float32 measurement */
 } ippm_config;
 
 typedef struct ippm_ctx ippm_ctx;
@@ -214,6 +216,19 @@ int ippm_coma_advantage(ippm_ctx* ctx, const float* probs, const float* q, const
  * Q(s_t)[a_t] -> td_target, discounted_return float. */
 int ippm_td_lambda(ippm_ctx* ctx, const float* reward, const uint8_t* done, const float* q_sel, float* td_target,
                    float* disc_return, int32_t chains, int32_t len, void* stream);
+
+/* ---- greedy information-gain planner (IG_baseline.py:222-325) and evaluation metrics -------------------------
+ * ippm_ig_candidates (K9): gains float [E,N,A] = expected weighted entropy reduction over the footprint each valid action
+ * leads to, / 1000 (get_individual_ig); masked actions get 0.  ippm_ig_select (K10): get_relative_ig +
+ * get_cell_utilities (when communication != 0) + argmax -> action int32 [E,N]; utilities float [E,N,A] optional.
+ * ippm_f1_counts: int64 [n_maps,3] = (tp, fp, fn) of the map thresholded at p > 0.5 against the truth
+ * (utils/utils.py:64-76: sklearn f1_score(...)[1] = 2tp / (2tp + fp + fn)). */
+int ippm_ig_candidates(ippm_ctx* ctx, const float* local, const int32_t* pos, const uint8_t* mask, float* gains,
+                       int32_t n_envs, void* stream);
+int ippm_ig_select(ippm_ctx* ctx, const int32_t* pos, const uint8_t* mask, const float* gains, int32_t communication,
+                   int32_t* action, float* utilities, int32_t n_envs, void* stream);
+int ippm_f1_counts(ippm_ctx* ctx, const float* maps, const uint8_t* truth, int32_t maps_per_truth, int64_t* out,
+                   int32_t n_maps, void* stream);
 
 /* Host helpers (no GPU needed): exported so that CPU-only tests can pin the device's integer streams and
  * resize weights to NumPy / the oracle. */

@@ -1,0 +1,176 @@
+// Greedy information-gain planner (reference: IG_baseline.py:222-325) and evaluation metrics (utils/utils.py:43-76,
+// IG_baseline.py:84-97): K9 expected information gain of every candidate footprint, K10 the per-env selection logic,
+// and the target-class F1 counts.  The per-candidate reduction streams a footprint tile of the agent's local map
+// exactly like K3 does (4 grid-aligned cells per lane), accumulates in float64 and is deterministic (no atomics), so
+// candidates with identical cell multisets get bit-identical gains and argmax ties resolve like the reference's.
+#include "ippm_internal.h"
+
+__device__ __forceinline__ void ig_action_offset(int A, int a, int s, int& dx, int& dy, int& dz) {
+  dx = dy = dz = 0;
+  if (A == 4) {
+    if (a == 0) dx = -s; else if (a == 1) dy = -s; else if (a == 2) dy = s; else dx = s;
+  } else if (A == 6) {
+    if (a == 0) dz = s; else if (a == 1) dx = -s; else if (a == 2) dy = -s; else if (a == 3) dy = s;
+    else if (a == 4) dx = s; else dz = -s;
+  } else if (A == 9) {
+    dx = (a / 3 - 1) * s; dy = (a % 3 - 1) * s;
+  } else {
+    int layer = a / 9, c9 = a % 9;
+    dz = (1 - layer) * s; dx = (c9 / 3 - 1) * s; dy = (c9 % 3 - 1) * s;
+  }
+}
+
+// K9: one workgroup per (env, agent, action)
+__global__ void __launch_bounds__(256)
+k_ig_candidates(const ippm_config* __restrict__ c, const float* __restrict__ local, const int32_t* __restrict__ pos,
+                const uint8_t* __restrict__ mask, float* __restrict__ gains) {
+  const int n = c->n_agents, A = c->n_actions;
+  const int cand = blockIdx.x;
+  const int a = cand % A, i = (cand / A) % n, e = cand / (A * n);
+  if (!mask[cand]) { if (threadIdx.x == 0) gains[cand] = 0.f; return; }
+  const int32_t* p = pos + (size_t)(e * n + i) * 3;
+  int dx, dy, dz;
+  ig_action_offset(A, a, c->spacing, dx, dy, dz);
+  int r[4];
+  ippm_footprint_rect(c, p[0] + dx, p[1] + dy, p[2] + dz, r, nullptr);
+  const int yu = r[0], yd = r[1], xl = r[2], xr = r[3];
+  const int gx = c->grid_x, gy = c->grid_y;
+  const int k = ippm_alt_index(c, p[2] + dz);
+  const float ln = c->logit_noise[k];  // ln((1-noise)/noise) from the float64 noise level: update_cells(section, 1-noise)
+  const float lc = c->logit_clip, wt = c->logit_weight_thr;
+  const float* map = local + (size_t)(e * n + i) * gx * gy;
+  const bool vec = (gy & 3) == 0;
+  const int y0 = vec ? (yu & ~3) : yu;
+  const int step = vec ? 4 : 1;
+  const int groups = (yd - y0 + step - 1) / step;
+  const int h = xr - xl;
+  double acc = 0.0;
+  for (int idx = threadIdx.x; idx < h * groups; idx += blockDim.x) {
+    const int row = idx / groups, gi = idx - row * groups;
+    const int x = xl + row, y = y0 + gi * step;
+    float v[4];
+    if (vec) { const float4 t = *reinterpret_cast<const float4*>(map + (size_t)x * gy + y); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    else v[0] = map[(size_t)x * gy + y];
+    float part = 0.f;
+    for (int q = 0; q < step; ++q) {
+      if (y + q < yu || y + q >= yd) continue;
+      // IG_baseline.py:236-268 in log-odds: belief clipped once, hypothetical posteriors L +- ln
+      const float l = ippm_clampl(v[q], lc);
+      const float pb = ippm_sigmoid(l);
+      const float l1 = l + ln, l0 = l - ln;
+      const float hh = ippm_entropy_l(l, lc);
+      const float cw1 = l1 > wt ? 1.f : (l1 < -wt ? 0.f : ippm_sigmoid(l1));
+      const float cw0 = l0 > wt ? 1.f : (l0 < -wt ? 0.f : ippm_sigmoid(l0));
+      part += pb * (hh - ippm_entropy_l(l1, lc)) * cw1 + (1.f - pb) * (hh - ippm_entropy_l(l0, lc)) * cw0;
+    }
+    acc += (double)part;
+  }
+  // deterministic block reduction in float64
+  __shared__ double s[256];
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) gains[cand] = (float)(s[0] / 1000.0);
+}
+
+// K10: get_relative_ig + get_cell_utilities + select_action, literal and sequential, one thread per env
+__global__ void k_ig_select(const ippm_config* __restrict__ c, const int32_t* __restrict__ pos, const uint8_t* __restrict__ mask,
+                            const float* __restrict__ gains, int communication, int32_t* __restrict__ action,
+                            float* __restrict__ utilities, int n_envs) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_envs) return;
+  const int n = c->n_agents, A = c->n_actions;
+  float rel[IPPM_MAX_AGENTS * IPPM_MAX_ACTIONS];
+  for (int i = 0; i < n; ++i) {
+    float total = 0.f;
+    for (int a = 0; a < A; ++a) total += gains[(size_t)(e * n + i) * A + a];
+    for (int a = 0; a < A; ++a) rel[i * A + a] = gains[(size_t)(e * n + i) * A + a] / total;
+  }
+  if (communication) {
+    for (int i = 0; i < n; ++i)
+      for (int a1 = 0; a1 < A; ++a1) {
+        if (!mask[(size_t)(e * n + i) * A + a1]) continue;  // masked candidates carry the placeholder position 0
+        const float g1 = rel[i * A + a1];
+        int d1x, d1y, d1z;
+        ig_action_offset(A, a1, c->spacing, d1x, d1y, d1z);
+        const int32_t* pi = pos + (size_t)(e * n + i) * 3;
+        for (int j = 0; j < n; ++j) {
+          if (j == i) continue;
+          const int32_t* pj = pos + (size_t)(e * n + j) * 3;
+          for (int a2 = 0; a2 < A; ++a2) {
+            if (!mask[(size_t)(e * n + j) * A + a2]) continue;
+            int d2x, d2y, d2z;
+            ig_action_offset(A, a2, c->spacing, d2x, d2y, d2z);
+            if (pi[0] + d1x == pj[0] + d2x && pi[1] + d1y == pj[1] + d2y && pi[2] + d1z == pj[2] + d2z)
+              rel[i * A + a1] = g1 * (1.f - rel[j * A + a2]);
+          }
+        }
+      }
+  }
+  for (int i = 0; i < n; ++i) {
+    int best = 0;
+    float bv = rel[i * A];
+    for (int a = 1; a < A; ++a) {
+      const float v = rel[i * A + a];
+      if (v > bv) { bv = v; best = a; }   // np.argmax: first maximum (NaN never wins here)
+    }
+    action[e * n + i] = best;
+    if (utilities) for (int a = 0; a < A; ++a) utilities[(size_t)(e * n + i) * A + a] = rel[i * A + a];
+  }
+}
+
+// target-class confusion counts of a map thresholded at p > 0.5 (L > 0): out int64 [n_maps,3] = tp, fp, fn
+__global__ void __launch_bounds__(256)
+k_f1_counts(const ippm_config* __restrict__ c, const float* __restrict__ maps, const uint8_t* __restrict__ truth, int maps_per_truth,
+            unsigned long long* __restrict__ out) {
+  const int m = blockIdx.y;
+  const size_t total = (size_t)c->grid_x * c->grid_y;
+  const float* p = maps + (size_t)m * total;
+  const uint8_t* t = truth + (size_t)(m / maps_per_truth) * total;
+  unsigned tp = 0, fp = 0, fn = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const bool pred = p[i] > 0.f, tr = t[i] != 0;
+    tp += pred && tr; fp += pred && !tr; fn += !pred && tr;
+  }
+  const float a = ippm_wave_sum((float)tp), b = ippm_wave_sum((float)fp), d = ippm_wave_sum((float)fn);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&out[m * 3 + 0], (unsigned long long)a);
+    atomicAdd(&out[m * 3 + 1], (unsigned long long)b);
+    atomicAdd(&out[m * 3 + 2], (unsigned long long)d);
+  }
+}
+
+static inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+extern "C" int ippm_ig_candidates(ippm_ctx* ctx, const float* local, const int32_t* pos, const uint8_t* mask, float* gains,
+                                  int32_t n_envs, void* stream) {
+  if (!ctx || !local || !pos || !mask || !gains) { ippm_set_error("ippm_ig_candidates: null argument"); return -1; }
+  const int total = n_envs * ctx->cfg.n_agents * ctx->cfg.n_actions;
+  hipLaunchKernelGGL(k_ig_candidates, dim3(total), dim3(256), 0, S_(stream), ctx->dcfg, local, pos, mask, gains);
+  IPPM_LAUNCH_CHECK("ig_candidates");
+  return 0;
+}
+
+extern "C" int ippm_ig_select(ippm_ctx* ctx, const int32_t* pos, const uint8_t* mask, const float* gains, int32_t communication,
+                              int32_t* action, float* utilities, int32_t n_envs, void* stream) {
+  if (!ctx || !pos || !mask || !gains || !action) { ippm_set_error("ippm_ig_select: null argument"); return -1; }
+  hipLaunchKernelGGL(k_ig_select, dim3((n_envs + 63) / 64), dim3(64), 0, S_(stream), ctx->dcfg, pos, mask, gains, communication, action,
+                     utilities, n_envs);
+  IPPM_LAUNCH_CHECK("ig_select");
+  return 0;
+}
+
+extern "C" int ippm_f1_counts(ippm_ctx* ctx, const float* maps, const uint8_t* truth, int32_t maps_per_truth, int64_t* out,
+                              int32_t n_maps, void* stream) {
+  if (!ctx || !maps || !truth || !out) { ippm_set_error("ippm_f1_counts: null argument"); return -1; }
+  IPPM_HIP(hipMemsetAsync(out, 0, sizeof(int64_t) * 3 * n_maps, S_(stream)));
+  const size_t cells = (size_t)ctx->cfg.grid_x * ctx->cfg.grid_y;
+  const int gxb = (int)std::min<size_t>(32, (cells + 255) / 256);
+  hipLaunchKernelGGL(k_f1_counts, dim3(gxb, n_maps), dim3(256), 0, S_(stream), ctx->dcfg, maps, truth, maps_per_truth > 0 ? maps_per_truth : 1,
+                     reinterpret_cast<unsigned long long*>(out));
+  IPPM_LAUNCH_CHECK("f1_counts");
+  return 0;
+}

@@ -34,6 +34,7 @@ class IppmConfig(C.Structure):
         ("logit_prior", C.c_float), ("logit_clip", C.c_float), ("logit_weight_thr", C.c_float),
         ("comm_range", C.c_double), ("failure_rate", C.c_double),
         ("philox_seed", C.c_uint64), ("gamma", C.c_double), ("lambda_", C.c_double),
+        ("logit_noise", C.c_float * MAX_Z),
     ]
 
 
@@ -69,6 +70,9 @@ PROTOTYPES = {
     "ippm_critic_features": [P, P, P, P, P, P, P, I32, P],
     "ippm_coma_advantage": [P, P, P, P, P, P, P, I32, P],
     "ippm_td_lambda": [P, P, P, P, P, P, I32, I32, P],
+    "ippm_ig_candidates": [P, P, P, P, P, I32, P],
+    "ippm_ig_select": [P, P, P, P, I32, P, P, I32, P],
+    "ippm_f1_counts": [P, P, P, I32, P, I32, P],
     "ippm_area_weights": [I32, I32, P, P, P],
     "ippm_host_philox": [P, P],
     "ippm_host_start_state": [I32, I64, I32, I32, I32, I32, P],
@@ -137,6 +141,8 @@ def make_config(d: DerivedConstants) -> IppmConfig:
     c.comm_range, c.failure_rate = d.comm_range, d.failure_rate
     c.philox_seed = d.philox_seed & 0xFFFFFFFFFFFFFFFF
     c.gamma, c.lambda_ = d.gamma, d.lam
+    for k in range(d.space_z):
+        c.logit_noise[k] = float(d.logit_noise[k])
     return c
 
 

@@ -78,8 +78,11 @@ class DerivedConstants:
         self.meas_value = np.zeros((self.space_z, 2), dtype=np.float32)
         self.logit_meas = np.zeros((self.space_z, 2), dtype=np.float32)
         self.flip_threshold = np.zeros(self.space_z, dtype=np.uint64)
+        self.logit_noise = np.zeros(self.space_z, dtype=np.float64)   # IG planner: scalar float64 noise levels
         for k, z in enumerate(self.altitudes):
             nz = _noise(z)
+            with np.errstate(divide="ignore"):
+                self.logit_noise[k] = np.log((1 - nz) / nz) if nz > 0 else np.inf
             acc = 1 - nz
             y = np.float32(np.round(np.array([1 - acc, acc * 1.0]), 3))
             self.meas_value[k] = y

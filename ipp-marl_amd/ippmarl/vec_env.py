@@ -203,6 +203,24 @@ class VecEnv:
         self.t = t + 1
         return self.reward, t == d.budget, state
 
+    # ---- greedy information-gain policy (IG_baseline.py:127-148, 222-325) for the whole batch ---------------------
+    def ig_actions(self, communication: bool = True) -> torch.Tensor:
+        """Actions int32 [E,N] of the greedy expected-information-gain planner on the current local maps: masks against the
+        current positions of the agents before each one (the reference's quirk), K9 candidate gains, K10 selection."""
+        d, E, N, A = self.d, self.E, self.d.n_agents, self.d.n_actions
+        others = self.pos.view(E, 1, N, 3).expand(E, N, N, 3).contiguous()
+        n_others = torch.arange(N, dtype=torch.int32, device=self.device).view(1, N).expand(E, N).contiguous()
+        mask = torch.empty(E, N, A, dtype=torch.uint8, device=self.device)
+        self.ctx.call("ippm_action_mask", self._p(self.pos), self._p(others), self._p(n_others), N, None, self._p(mask), None, E * N,
+                      self.stream)
+        gains = torch.empty(E, N, A, dtype=torch.float32, device=self.device)
+        self.ctx.call("ippm_ig_candidates", self._p(self.local), self._p(self.pos), self._p(mask), self._p(gains), E, self.stream)
+        actions = torch.empty(E, N, dtype=torch.int32, device=self.device)
+        self.ctx.call("ippm_ig_select", self._p(self.pos), self._p(mask), self._p(gains), 1 if communication else 0, self._p(actions), None,
+                      E, self.stream)
+        self.ig_gains, self.ig_mask = gains, mask
+        return actions
+
     # ---- hipGraph replay of the launch-bound part of a random-policy step ------------------------------------
     def capture_step_graphs(self, policy: int = POLICY_UNIFORM):
         """Captures, for every t of an episode, the fixed launch sequence {K5 on the side stream || comm + K4} -> K1

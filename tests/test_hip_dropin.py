@@ -172,3 +172,54 @@ def test_batch_memory_td_targets(golden):
     np.testing.assert_allclose(dr, fx["dr"], rtol=2e-5, atol=2e-6)
     batches = bm.build_batches()
     assert len(batches) == (n * L) // 60 and all(len(b) == 60 for b in batches)
+
+
+@pytest.mark.parametrize("tag", ["ig_c1_e1", "ig_small3_e4"])
+def test_ig_baseline_replays_reference_run(golden, tag, monkeypatch):
+    """IG_baseline(params, writer, episode).execute() as IG_baseline.main drives it (BASELINE config 1 and a smaller case),
+    with the sensor noise the reference drew: chosen altitudes, candidate gains, target entropy and F1 per step."""
+    from ippmarl.IG_baseline import IG_baseline
+    from ippmarl.coma_wrapper import ReplayHooks
+    from test_oracle_golden import IG_CASES
+    fx = golden(tag)
+    params = make_params(IG_CASES[tag]["name"], **IG_CASES[tag]["over"])
+    n = params["experiment"]["missions"]["n_agents"]
+    corr = unpack_correctness(fx)
+    draws = iter(fx["comm_draws"])
+    monkeypatch.setattr(np.random, "random_sample", lambda *a, **k: next(draws))
+    ig = IG_baseline(params, None, int(fx["episode"]))
+    ig.replay = ReplayHooks(correctness=lambda agent_id, stage: corr[stage * n + agent_id])
+    rel, ab, altitudes, entropies, f1s = ig.execute()
+    assert np.array_equal(np.array(altitudes), fx["altitudes"])
+    np.testing.assert_allclose(np.array(ig.gains_log), fx["gains"], rtol=RTOL, atol=1e-9)
+    np.testing.assert_allclose(entropies, fx["entropies"], rtol=RTOL)
+    np.testing.assert_allclose(f1s, fx["f1"], rtol=RTOL, atol=1e-12)
+    np.testing.assert_allclose([rel, ab], [fx["relative_return"], fx["absolute_return"]], rtol=1e-9)
+
+
+def test_batched_ig_policy_matches_oracle():
+    """VecEnv.ig_actions (K9 + K10 for all envs at once) against the oracle's literal restatement."""
+    from ippmarl.vec_env import VecEnv, POLICY_EXPLICIT
+    params = make_params("small")
+    d = O.Derived(params)
+    d.exact = True
+    seed = 5
+    env = VecEnv(params, 6, philox_seed=seed)
+    eps = np.arange(40, 46)
+    env.reset(eps)
+    for t in range(4):
+        env.build_observations(t, features=False)
+        local = env.posterior_local().cpu().numpy()
+        pos = env.pos.cpu().numpy()
+        acts = env.ig_actions(communication=True)
+        gains, chosen = env.ig_gains.cpu().numpy(), acts.cpu().numpy()
+        for e in range(env.E):
+            pls, gls, prior = [], [], []
+            for i in range(d.n_agents):
+                m = O.apply_collision_mask(d, pos[e, i], O.action_mask(d, pos[e, i]), prior)
+                ap, g = O.ig_individual(d, pos[e, i], m, local[e, i].astype(np.float64))
+                np.testing.assert_allclose(gains[e, i], g, rtol=RTOL, atol=1e-9)
+                pls.append(ap), gls.append(g), prior.append(pos[e, i])
+            util = O.ig_cell_utilities(pls, O.ig_relative(gls))
+            assert [int(np.argmax(u)) for u in util] == list(chosen[e]), (t, e)
+        env.steps(t, policy=POLICY_EXPLICIT, actions=acts, features=False)
