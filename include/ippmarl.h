@@ -221,14 +221,16 @@ int ippm_td_lambda(ippm_ctx* ctx, const float* reward, const uint8_t* done, cons
  * ippm_ig_candidates (K9): gains float [E,N,A] = expected weighted entropy reduction over the footprint each valid action
  * leads to, / 1000 (get_individual_ig); masked actions get 0.  ippm_ig_select (K10): get_relative_ig +
  * get_cell_utilities (when communication != 0) + argmax -> action int32 [E,N]; utilities float [E,N,A] optional.
- * ippm_f1_counts: int64 [n_maps,3] = (tp, fp, fn) of the map thresholded at p > 0.5 against the truth
- * (utils/utils.py:64-76: sklearn f1_score(...)[1] = 2tp / (2tp + fp + fn)). */
+ * ippm_f1_counts: int64 [n_maps,3] = (tp, fp, fn) of the map thresholded at log-odds > logodds_threshold (0 <=> p > 0.5)
+ * against the truth (utils/utils.py:64-76: sklearn f1_score(...)[1] = 2tp / (2tp + fp + fn)).  Cells whose evidence
+ * cancels exactly sit at p = 0.5 +- rounding noise in the reference, which decides their class there; the threshold lets
+ * a caller bracket that. */
 int ippm_ig_candidates(ippm_ctx* ctx, const float* local, const int32_t* pos, const uint8_t* mask, float* gains,
                        int32_t n_envs, void* stream);
 int ippm_ig_select(ippm_ctx* ctx, const int32_t* pos, const uint8_t* mask, const float* gains, int32_t communication,
                    int32_t* action, float* utilities, int32_t n_envs, void* stream);
-int ippm_f1_counts(ippm_ctx* ctx, const float* maps, const uint8_t* truth, int32_t maps_per_truth, int64_t* out,
-                   int32_t n_maps, void* stream);
+int ippm_f1_counts(ippm_ctx* ctx, const float* maps, const uint8_t* truth, int32_t maps_per_truth, float logodds_threshold,
+                   int64_t* out, int32_t n_maps, void* stream);
 
 /* Host helpers (no GPU needed): exported so that CPU-only tests can pin the device's integer streams and
  * resize weights to NumPy / the oracle. */

@@ -122,17 +122,17 @@ __global__ void k_ig_select(const ippm_config* __restrict__ c, const int32_t* __
   }
 }
 
-// target-class confusion counts of a map thresholded at p > 0.5 (L > 0): out int64 [n_maps,3] = tp, fp, fn
+// target-class confusion counts of a map thresholded at L > thr (thr = 0 <=> p > 0.5): out int64 [n_maps,3] = tp, fp, fn
 __global__ void __launch_bounds__(256)
 k_f1_counts(const ippm_config* __restrict__ c, const float* __restrict__ maps, const uint8_t* __restrict__ truth, int maps_per_truth,
-            unsigned long long* __restrict__ out) {
+            float thr, unsigned long long* __restrict__ out) {
   const int m = blockIdx.y;
   const size_t total = (size_t)c->grid_x * c->grid_y;
   const float* p = maps + (size_t)m * total;
   const uint8_t* t = truth + (size_t)(m / maps_per_truth) * total;
   unsigned tp = 0, fp = 0, fn = 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const bool pred = p[i] > 0.f, tr = t[i] != 0;
+    const bool pred = p[i] > thr, tr = t[i] != 0;
     tp += pred && tr; fp += pred && !tr; fn += !pred && tr;
   }
   const float a = ippm_wave_sum((float)tp), b = ippm_wave_sum((float)fp), d = ippm_wave_sum((float)fn);
@@ -163,14 +163,14 @@ extern "C" int ippm_ig_select(ippm_ctx* ctx, const int32_t* pos, const uint8_t* 
   return 0;
 }
 
-extern "C" int ippm_f1_counts(ippm_ctx* ctx, const float* maps, const uint8_t* truth, int32_t maps_per_truth, int64_t* out,
-                              int32_t n_maps, void* stream) {
+extern "C" int ippm_f1_counts(ippm_ctx* ctx, const float* maps, const uint8_t* truth, int32_t maps_per_truth, float logodds_threshold,
+                              int64_t* out, int32_t n_maps, void* stream) {
   if (!ctx || !maps || !truth || !out) { ippm_set_error("ippm_f1_counts: null argument"); return -1; }
   IPPM_HIP(hipMemsetAsync(out, 0, sizeof(int64_t) * 3 * n_maps, S_(stream)));
   const size_t cells = (size_t)ctx->cfg.grid_x * ctx->cfg.grid_y;
   const int gxb = (int)std::min<size_t>(32, (cells + 255) / 256);
   hipLaunchKernelGGL(k_f1_counts, dim3(gxb, n_maps), dim3(256), 0, S_(stream), ctx->dcfg, maps, truth, maps_per_truth > 0 ? maps_per_truth : 1,
-                     reinterpret_cast<unsigned long long*>(out));
+                     logodds_threshold, reinterpret_cast<unsigned long long*>(out));
   IPPM_LAUNCH_CHECK("f1_counts");
   return 0;
 }

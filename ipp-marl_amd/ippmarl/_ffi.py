@@ -72,7 +72,7 @@ PROTOTYPES = {
     "ippm_td_lambda": [P, P, P, P, P, P, I32, I32, P],
     "ippm_ig_candidates": [P, P, P, P, P, I32, P],
     "ippm_ig_select": [P, P, P, P, I32, P, P, I32, P],
-    "ippm_f1_counts": [P, P, P, I32, P, I32, P],
+    "ippm_f1_counts": [P, P, P, I32, C.c_float, P, I32, P],
     "ippm_area_weights": [I32, I32, P, P, P],
     "ippm_host_philox": [P, P],
     "ippm_host_start_state": [I32, I64, I32, I32, I32, I32, P],
