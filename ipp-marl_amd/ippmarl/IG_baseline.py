@@ -47,11 +47,14 @@ class IG_baseline:
         self.f1_bracket = []      # per evaluation: F1 with the exactly-cancelled cells counted as free / as occupied
 
     # ---- metrics of the fused global map that lives on the device --------------------------------------
-    def _f1(self, threshold: float = 0.0) -> float:
+    def _f1_counts(self, threshold: float = 0.0):
         env = self.mapping.engine.env
         counts = torch.zeros(1, 3, dtype=torch.int64, device=env.device)
         env.ctx.call("ippm_f1_counts", env._p(env.glob), env._p(env.truth), 1, float(threshold), _ffi.ptr(counts), 1, env.stream)
-        tp, fp, fn = (int(v) for v in counts[0].cpu())
+        return tuple(int(v) for v in counts[0].cpu())
+
+    @staticmethod
+    def _f1_of(tp, fp, fn) -> float:
         return 2 * tp / (2 * tp + fp + fn) if (2 * tp + fp + fn) > 0 else 0.0
 
     def _metrics(self):
@@ -60,9 +63,12 @@ class IG_baseline:
         ent = torch.zeros(1, dtype=torch.float64, device=env.device)
         env.ctx.call("ippm_weighted_entropy", env._p(env.glob), env._p(env.truth), 1, _ffi.ptr(ent), 1, env.stream)
         target = int(env.truth[0].sum())
-        # cells whose observations cancel exactly are classified by floating-point noise in the reference; keep the bracket
-        self.f1_bracket.append((self._f1(1e-5), self._f1(-1e-5)))
-        return float(ent[0]) / target, self._f1(0.0)
+        # Cells whose observations cancel exactly sit at p = 0.5 +- rounding noise in the reference, which classifies them
+        # by that noise.  Keep the attainable range: every such cell assigned to the wrong / to the right class.
+        tp_s, fp_s, fn_s = self._f1_counts(1e-5)
+        tp_l, fp_l, fn_l = self._f1_counts(-1e-5)
+        self.f1_bracket.append((self._f1_of(tp_s, fp_l, fn_s), self._f1_of(tp_l, fp_s, fn_l)))
+        return float(ent[0]) / target, self._f1_of(*self._f1_counts(0.0))
 
     def get_individual_ig(self, position, action_mask, map_state=None, agent_id: int = 0):
         """Expected information gain per action for the agent in engine slot ``agent_id`` (its device-resident local map;

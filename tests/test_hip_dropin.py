@@ -195,7 +195,7 @@ def test_ig_baseline_replays_reference_run(golden, tag, monkeypatch):
     np.testing.assert_allclose(entropies, fx["entropies"], rtol=RTOL)
     # F1 thresholds the map at p > 0.5.  Cells whose observations cancel exactly (47 % of the twice-observed cells at 15 m)
     # sit at 0.5 +- 1e-8 in the reference and are classified by its rounding noise, so the recorded F1 can only be
-    # bracketed: all such cells free <= reference <= all such cells occupied.
+    # bracketed: every such cell in the wrong class <= reference <= every such cell in the right class.
     assert f1s[0] == fx["f1"][0] == 0.0
     for (lo, hi), want in zip(ig.f1_bracket, fx["f1"]):
         assert min(lo, hi) - 1e-9 <= want <= max(lo, hi) + 1e-9, (lo, want, hi)
