@@ -21,13 +21,15 @@
  *   episode   int64  [E]          episode number of each env (seeds truth, start states, Philox streams)
  *   pos       int32  [E,N,3]      UAV position in metres (x,y,z)
  *   rect      int32  [E,N,4]      clipped footprint [yu,yd,xl,xr], half-open when sliced (cameras.py:62-77)
- *   truth     uint8  [E,gx,gy]    ground truth in {0,1}
+ *   truth     uint8  [E,TRB]      ground truth, BIT-PACKED: cell (x,y) = bit (x*gy+y) of the env's little-endian bit string,
+ *                                 TRB = ceil(gx*gy/32)*4 bytes
  *   local     float  [E,N,gx,gy]  per-agent occupancy belief, stored as LOG-ODDS ln(p/(1-p)) (0 = prior 0.5);
  *   global    float  [E,gx,gy]    fused team belief, log-odds.  ippm_logodds_to_prob / ippm_prob_to_logodds
  *                                 convert at the boundary (DESIGN.md "log-odds storage")
- *   code      uint8  [E,N,S,S]    last measurement of each agent as 1-byte codes (1 = observed occupied);
- *                                 cell (x,y) of the footprint lives at [x-xl][y-(yu & ~3)] so that four
- *                                 grid-aligned cells share one aligned 32-bit word
+ *   code      uint8  [E,N,TB]     last measurement of each agent, 1 bit per cell (1 = observed occupied).  With col =
+ *                                 y-(yu & ~3): when gy % 4 == 0 the four grid-aligned cells of a lane group share the low
+ *                                 nibble of byte [x-xl][col/4] (row stride S/4, TB = S*S/4); otherwise one byte per cell at
+ *                                 [x-xl][col] (row stride S, TB = S*S).  (1-byte-per-cell planes cost K3 27 % of its time.)
  *   flips     uint8  same layout as code; 1 = this cell's observation is flipped (parity mode)
  *   comm      uint8  [E,N,N]      comm[e,i,j] = 1 iff agent i receives agent j's message (diagonal = 1)
  *   mask      uint8  [E,N,A]      action mask after boundary + collision masking

@@ -129,10 +129,10 @@ k_f1_counts(const ippm_config* __restrict__ c, const float* __restrict__ maps, c
   const int m = blockIdx.y;
   const size_t total = (size_t)c->grid_x * c->grid_y;
   const float* p = maps + (size_t)m * total;
-  const uint8_t* t = truth + (size_t)(m / maps_per_truth) * total;
+  const uint8_t* t = truth + (size_t)(m / maps_per_truth) * ippm_truth_bytes(c->grid_x, c->grid_y);
   unsigned tp = 0, fp = 0, fn = 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const bool pred = p[i] > thr, tr = t[i] != 0;
+    const bool pred = p[i] > thr, tr = ippm_truth1(t, i) != 0;
     tp += pred && tr; fp += pred && !tr; fn += !pred && tr;
   }
   const float a = ippm_wave_sum((float)tp), b = ippm_wave_sum((float)fp), d = ippm_wave_sum((float)fn);

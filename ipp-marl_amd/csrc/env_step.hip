@@ -3,7 +3,7 @@
 //
 // All of this is HBM-bound byte/float streaming over map tiles: no MFMA.  The layout rules are
 //   - a map row (y contiguous) is covered by lanes holding 4 grid-aligned cells each (one 16-byte access),
-//     the 1-byte truth/code/flip planes ride along as one aligned 32-bit word per lane;
+//     truth is bit-packed, measurement codes / flips are one nibble per lane group: one byte load per lane each;
 //   - narrow footprints pack several rows into one 64-lane wavefront (lanes-per-row = next pow2);
 //   - every map cell is read and written at most once per kernel, whatever the number of fused measurements.
 #include <algorithm>
@@ -62,12 +62,18 @@ __global__ void k_fill_truth(const ippm_config* __restrict__ c, const int32_t* _
     int start = -((dim * (pct - 1)) / 100);
     lo = start == 0 ? 0 : max(dim + start, 0);
   }
-  uint8_t* t = truth + (size_t)e * gx * gy;
-  int total = gx * gy;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    int x = i / gy, y = i - x * gy;
-    int v = (split < 2) ? x : y;
-    t[i] = (v >= lo && v < hi) ? 1 : 0;
+  uint8_t* t = truth + (size_t)e * ippm_truth_bytes(gx, gy);
+  const size_t total = (size_t)gx * gy, nbytes = ippm_truth_bytes(gx, gy);
+  for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b < nbytes; b += (size_t)gridDim.x * blockDim.x) {
+    uint32_t bits = 0;
+    for (int q = 0; q < 8; ++q) {
+      const size_t i = b * 8 + q;
+      if (i >= total) break;
+      const int x = (int)(i / gy), y = (int)(i - (size_t)x * gy);
+      const int v = (split < 2) ? x : y;
+      bits |= (v >= lo && v < hi) ? (1u << q) : 0u;
+    }
+    t[b] = (uint8_t)bits;
   }
 }
 
@@ -156,16 +162,18 @@ __device__ __forceinline__ void store_cells(float* p, const CellVec<VEC>& r) {
     p[0] = r.v[0];
   }
 }
-// VEC consecutive bytes as one word (aligned by construction when VEC == 4)
+// observation bits of a lane's cell group in a code / flips tile: low nibble of one byte (VEC == 4) or one byte per cell
 template <int VEC>
-__device__ __forceinline__ uint32_t load_bytes(const uint8_t* p) {
-  if (VEC == 4) return *reinterpret_cast<const uint32_t*>(p);
-  return p[0];
+__device__ __forceinline__ size_t tile_index(int row, int col, int S) {  // col = y - (yu & ~3)
+  return VEC == 4 ? (size_t)row * (S >> 2) + (col >> 2) : (size_t)row * S + col;
 }
 template <int VEC>
-__device__ __forceinline__ void store_bytes(uint8_t* p, uint32_t w) {
-  if (VEC == 4) *reinterpret_cast<uint32_t*>(p) = w;
-  else p[0] = (uint8_t)w;
+__device__ __forceinline__ uint32_t load_bits(const uint8_t* tile, int row, int col, int S) {
+  return tile[tile_index<VEC>(row, col, S)] & (VEC == 4 ? 0xFu : 1u);
+}
+template <int VEC>
+__device__ __forceinline__ void store_bits(uint8_t* tile, int row, int col, int S, uint32_t bits) {
+  tile[tile_index<VEC>(row, col, S)] = (uint8_t)bits;
 }
 
 // ======================================================================================================
@@ -202,9 +210,10 @@ k_sense_update(const ippm_config* __restrict__ c, const int64_t* __restrict__ ep
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int sub = lane >> g.shift, gl = lane & (g.lpr - 1);
   float* map = local + (size_t)(e * n + i) * gx * gy;
-  const uint8_t* tr = truth + (size_t)e * gx * gy;
-  uint8_t* cd = code + (size_t)(e * n + i) * S * S;
-  const uint8_t* fl = flips ? flips + (size_t)(e * n + i) * S * S : nullptr;
+  const uint8_t* tr = truth + (size_t)e * ippm_truth_bytes(gx, gy);
+  const size_t TB = ippm_tile_bytes(S, VEC);
+  uint8_t* cd = code + (size_t)(e * n + i) * TB;
+  const uint8_t* fl = flips ? flips + (size_t)(e * n + i) * TB : nullptr;
   const int64_t ep = episode ? episode[e] : 0;
   const uint32_t sw = ippm_stream_word((uint32_t)i, (uint32_t)stage, IPPM_DOMAIN_FLIP);
   const uint32_t k0 = (uint32_t)c->philox_seed, k1 = (uint32_t)(c->philox_seed >> 32);
@@ -223,8 +232,8 @@ k_sense_update(const ippm_config* __restrict__ c, const int64_t* __restrict__ ep
         if (rr < r1) {
           const size_t cell = (size_t)(xl + rr) * gy + y;
           m[u] = load_cells<VEC>(map + cell);
-          tw[u] = load_bytes<VEC>(tr + cell);
-          if (fl) fw[u] = load_bytes<VEC>(fl + (size_t)rr * S + (y - tile_y0));
+          tw[u] = VEC == 4 ? ippm_truth4(tr, cell) : ippm_truth1(tr, cell);
+          if (fl) fw[u] = load_bits<VEC>(fl, rr, y - tile_y0, S);
         }
       }
 #pragma unroll
@@ -240,21 +249,21 @@ k_sense_update(const ippm_config* __restrict__ c, const int64_t* __restrict__ ep
           // branch-free: cells of an edge group that lie outside the footprint keep their value
           const bool in = (unsigned)(y + q - yu) < (unsigned)w;
           uint32_t flip;
-          if (fl) flip = (fw[u] >> (8 * q)) & 1u;
+          if (fl) flip = (fw[u] >> q) & 1u;
           else if (VEC == 4) flip = ph.v[q] < thr ? 1u : 0u;
           else {
             Philox4 p1 = ippm_philox((uint32_t)((cell + q) >> 2), (uint32_t)ep, sw, (uint32_t)(ep >> 32), k0, k1);
             flip = p1.v[(cell + q) & 3] < thr ? 1u : 0u;
           }
-          const uint32_t obs = ((tw[u] >> (8 * q)) & 1u) ^ flip;
+          const uint32_t obs = ((tw[u] >> q) & 1u) ^ flip;
           // mappings.py:109-124 in log-odds: clip the prior belief, add the measurement's log-odds
           const float l = ippm_clampl(m[u].v[q], lc) + (obs ? lm1 : lm0);
           exceed |= in & (fabsf(l) > lc);
           m[u].v[q] = in ? l : m[u].v[q];
-          cw |= (in ? obs : 0u) << (8 * q);
+          cw |= (in ? obs : 0u) << q;
         }
         store_cells<VEC>(map + cell, m[u]);
-        store_bytes<VEC>(cd + (size_t)rr * S + (y - tile_y0), cw);
+        store_bits<VEC>(cd, rr, y - tile_y0, S, cw);
       }
     }
   }
@@ -421,7 +430,8 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int sub = lane >> g.shift, gl = lane & (g.lpr - 1);
   float* map = maps + (size_t)m * gx * gy;
-  const uint8_t* code_e = code + (size_t)e * n * S * S;
+  const size_t TB = ippm_tile_bytes(S, VEC);
+  const uint8_t* code_e = code + (size_t)e * n * TB;
   bool exceed = false;
   float a1 = 0.f, aD = 0.f, aT = 0.f;
   unsigned cells = 0, opcells = 0;
@@ -446,7 +456,7 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
     const bool isf = (kinfo & 0xFF) != 0;
     const int alt = (kinfo >> 16) & 0xFF;
     const float lm0 = isf ? c->logit_meas[alt][0] : 0.f, lm1 = isf ? c->logit_meas[alt][1] : 0.f;
-    const uint8_t* ctile = code_e + (size_t)((kinfo >> 8) & 0xFF) * S * S - (kyu & ~3);
+    const uint8_t* ctile = code_e + (size_t)((kinfo >> 8) & 0xFF) * TB;
     const int wdt = kyd - kyu;
     for (int gi = gl; gi < g.groups; gi += g.lpr) {
       const int y = g.y0 + gi * VEC;
@@ -457,11 +467,11 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
         const size_t cell = (size_t)(kxl + row) * gy + y;
         CellVec<VEC> mv = load_cells<VEC>(map + cell);
         uint32_t cw = 0;
-        if (isf) cw = load_bytes<VEC>(ctile + (size_t)row * S + y);
+        if (isf) cw = load_bits<VEC>(ctile, row, y - (kyu & ~3), S);
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
           const float b = mv.v[q];
-          float a = ippm_clampl(b, lc) + (((cw >> (8 * q)) & 1u) ? lm1 : lm0);
+          float a = ippm_clampl(b, lc) + (((cw >> q) & 1u) ? lm1 : lm0);
           a = k_is_last ? a : ippm_clampl(a, lc);
           const bool in = (inm >> q) & 1u;
           a = in ? a : b;
@@ -518,8 +528,7 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
         cw[o] = 0;
         if (!((hitmask >> o) & 1u)) continue;
         if (o <= k && (op[o].info & 0xFF) && ((unsigned)(act >> (o * VEC)) & QM))
-          cw[o] = load_bytes<VEC>(code_e + (size_t)((op[o].info >> 8) & 0xFF) * S * S + (size_t)(x - op[o].xl) * S +
-                                  (y - (op[o].yu & ~3)));
+          cw[o] = load_bits<VEC>(code_e + (size_t)((op[o].info >> 8) & 0xFF) * TB, x - op[o].xl, y - (op[o].yu & ~3), S);
       }
       const CellVec<VEC> old = mv;
       float L[VEC];
@@ -539,7 +548,7 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
           // every op of the reference clips its input over the whole grid (mappings.py:110-111)
-          const float l = ippm_clampl(L[q], lc) + (((cw[o] >> (8 * q)) & 1u) ? lm1 : lm0);
+          const float l = ippm_clampl(L[q], lc) + (((cw[o] >> q) & 1u) ? lm1 : lm0);
           L[q] = ((inm >> q) & 1u) ? l : L[q];
         }
         touched |= inm;
@@ -623,7 +632,8 @@ k_apply_ops_generic(const ippm_config* __restrict__ c, float* __restrict__ maps,
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int sub = lane >> g.shift, gl = lane & (g.lpr - 1);
   float* map = maps + (size_t)m * gx * gy;
-  const uint8_t* code_e = code + (size_t)e * n * S * S;
+  const size_t TB = ippm_tile_bytes(S, VEC);
+  const uint8_t* code_e = code + (size_t)e * n * TB;
   bool exceed = false;
   float a1 = 0.f, aD = 0.f, aT = 0.f;
   unsigned cells = 0, opcells = 0;
@@ -650,7 +660,7 @@ k_apply_ops_generic(const ippm_config* __restrict__ c, float* __restrict__ maps,
         uint32_t cw = 0;
         float lm0 = 0.f, lm1 = 0.f;
         if (op[OP_TYPE]) {
-          cw = load_bytes<VEC>(code_e + (size_t)op[OP_SRC] * S * S + (size_t)(x - op[OP_XL]) * S + (y - (op[OP_YU] & ~3)));
+          cw = load_bits<VEC>(code_e + (size_t)op[OP_SRC] * TB, x - op[OP_XL], y - (op[OP_YU] & ~3), S);
           lm0 = c->logit_meas[op[OP_ALT]][0];
           lm1 = c->logit_meas[op[OP_ALT]][1];
         }
@@ -659,7 +669,7 @@ k_apply_ops_generic(const ippm_config* __restrict__ c, float* __restrict__ maps,
           const int yy = y + q;
           if (yy >= op[OP_YU] && yy < op[OP_YD]) {
             L[q] = ippm_clampl(L[q], lc);
-            if (op[OP_TYPE]) { L[q] += ((cw >> (8 * q)) & 1u) ? lm1 : lm0; fused[q] = true; }
+            if (op[OP_TYPE]) { L[q] += ((cw >> q) & 1u) ? lm1 : lm0; fused[q] = true; }
             lastt[q] = o;
             ++opcells;
           }
@@ -726,12 +736,12 @@ k_weighted_entropy(const ippm_config* __restrict__ c, const float* __restrict__ 
   const int m = blockIdx.y;
   const size_t total = (size_t)c->grid_x * c->grid_y;
   const float* p = maps + (size_t)m * total;
-  const uint8_t* t = truth ? truth + (size_t)(m / maps_per_truth) * total : nullptr;
+  const uint8_t* t = truth ? truth + (size_t)(m / maps_per_truth) * ippm_truth_bytes(c->grid_x, c->grid_y) : nullptr;
   const float lc = c->logit_clip, wt = c->logit_weight_thr;
   float acc = 0.f;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const float v = p[i];
-    const float wgt = t ? (float)t[i] : ippm_weight_l(v, wt);
+    const float wgt = t ? (float)ippm_truth1(t, i) : ippm_weight_l(v, wt);
     acc += wgt * ippm_entropy_l(v, lc);
   }
   acc = ippm_wave_sum(acc);

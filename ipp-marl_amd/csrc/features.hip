@@ -116,7 +116,8 @@ k_actor_features(const ippm_config* __restrict__ c, const float* __restrict__ lo
   const int full_x = fu[3] - fu[2], full_y = fu[1] - fu[0];
   const int xoff = (cl[2] > fu[2]) ? full_x - hx : 0;
   const int yoff = (cl[0] > fu[0]) ? full_y - wy : 0;
-  const uint8_t* cd = code + (size_t)(e * n + i) * S * S;
+  const int vec = (gy & 3) == 0 ? 4 : 1;
+  const uint8_t* cd = code + (size_t)(e * n + i) * ippm_tile_bytes(S, vec);
   const int ycode0 = cl[0] - (cl[0] & ~3);
   const float mv0 = c->meas_value[k][0], mv1 = c->meas_value[k][1];
   TabView tfp;
@@ -128,7 +129,11 @@ k_actor_features(const ippm_config* __restrict__ c, const float* __restrict__ lo
   auto src_fp = [&](int r, int col, float* v) {
     const int u = r - xoff, w = col - yoff;
     float val = 0.5f;
-    if (u >= 0 && u < hx && w >= 0 && w < wy) val = cd[(size_t)u * S + w + ycode0] ? mv1 : mv0;
+    if (u >= 0 && u < hx && w >= 0 && w < wy) {
+      const int col = w + ycode0;
+      const uint32_t bit = vec == 4 ? (cd[(size_t)u * (S >> 2) + (col >> 2)] >> (col & 3)) & 1u : cd[(size_t)u * S + col];
+      val = bit ? mv1 : mv0;
+    }
     v[0] = val;
   };
   area_reduce<1>(src_fp, tfp, tfp, colsum, red_fp);

@@ -76,6 +76,18 @@ int ippm_check_hip(hipError_t err, const char* what);
 // ---- device helpers ------------------------------------------------------------------------------------
 #ifdef __HIPCC__
 
+// ---- bit-packed byte planes ------------------------------------------------------------------------------------
+// truth: one bit per cell, cell (x,y) -> bit (x*gy + y) of the env's bit string (bytes = ceil(gx*gy/32)*4).
+// code / flips tiles: the 4 observation bits of a lane's 4-cell group share one byte (low nibble) when the grid is a
+// multiple of 4 wide (row stride S/4 bytes); otherwise one byte per cell (row stride S).  Measured on MI355X: the
+// 1-byte-per-cell planes cost 27 % of K3's time for 20 % of its bytes; packed they cost 7 % (tools/probe).
+__device__ __forceinline__ uint32_t ippm_truth4(const uint8_t* tr, size_t lin) {  // lin % 4 == 0: cells lin..lin+3
+  return (tr[lin >> 3] >> (lin & 4)) & 0xFu;
+}
+__device__ __forceinline__ uint32_t ippm_truth1(const uint8_t* tr, size_t lin) { return (tr[lin >> 3] >> (lin & 7)) & 1u; }
+__host__ __device__ __forceinline__ size_t ippm_truth_bytes(int gx, int gy) { return (((size_t)gx * gy + 31) / 32) * 4; }
+__host__ __device__ __forceinline__ size_t ippm_tile_bytes(int S, int vec) { return vec == 4 ? (size_t)S * (S / 4) : (size_t)S * S; }
+
 __device__ __forceinline__ float ippm_clipf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 
 // Maps are stored as float32 LOG-ODDS L = ln(p/(1-p)) (DESIGN.md "log-odds storage"): the reference's

@@ -62,7 +62,7 @@ class IG_baseline:
         env = self.mapping.engine.env
         ent = torch.zeros(1, dtype=torch.float64, device=env.device)
         env.ctx.call("ippm_weighted_entropy", env._p(env.glob), env._p(env.truth), 1, _ffi.ptr(ent), 1, env.stream)
-        target = int(env.truth[0].sum())
+        target = int(env.truth_map[0].sum())
         # Cells whose observations cancel exactly sit at p = 0.5 +- rounding noise in the reference, which classifies them
         # by that noise.  Keep the attainable range: every such cell assigned to the wrong / to the right class.
         tp_s, fp_s, fn_s = self._f1_counts(1e-5)

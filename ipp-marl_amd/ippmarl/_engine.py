@@ -89,8 +89,7 @@ class EpisodeEngine:
         yu, yd, xl, xr = (int(v) for v in env.rect[0, i].cpu())
         pos = env.pos[0, i].cpu().numpy()
         k = min(max((int(pos[2]) - d.min_altitude) // d.spacing, 0), d.space_z - 1)
-        off = yu & 3
-        codes = env.code[0, i, : xr - xl, off: off + yd - yu].cpu().numpy()
+        codes = d.unpack_tile([yu, yd, xl, xr], env.code[0, i].cpu().numpy())
         meas = np.where(codes > 0, d.meas_value[k, 1], d.meas_value[k, 0]).astype(np.float32)
         m2c = np.full((d.grid_x, d.grid_y), 0.5, dtype=np.float32)
         m2c[xl:xr, yu:yd] = meas
@@ -119,9 +118,7 @@ class EpisodeEngine:
                 k = int(np.argmin(np.abs(d.meas_value[:, 1] - hi)))
                 rect, codes = [yu, yd, xl, xr], (vals > 0.5).astype(np.uint8)
         yu, yd, xl, xr = rect
-        tile = np.zeros((d.tile_stride, d.tile_stride), dtype=np.uint8)
-        tile[: xr - xl, (yu & 3): (yu & 3) + yd - yu] = codes
-        env.code[0, slot].copy_(torch.from_numpy(tile).to(env.device))
+        env.code[0, slot].copy_(torch.from_numpy(d.pack_tile(rect, codes)).to(env.device))
         env.rect[0, slot].copy_(torch.tensor(rect, dtype=torch.int32))
         # altitude level of the slot is read from pos[...,2] by the kernels
         env.pos[0, slot, 2] = d.altitudes[k]

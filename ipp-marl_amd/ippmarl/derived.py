@@ -115,5 +115,56 @@ class DerivedConstants:
         cx = lambda v: min(max(v, 0), self.grid_x - 1)  # noqa: E731
         return full, [cy(yu), cy(yd), cx(xl), cx(xr)]
 
+    # ---- packed byte planes (mirror of ippm_internal.h) ---------------------------------------------------------
+    @property
+    def vec(self) -> int:
+        return 4 if self.grid_y % 4 == 0 else 1
+
+    @property
+    def truth_bytes(self) -> int:
+        return (self.grid_x * self.grid_y + 31) // 32 * 4
+
+    @property
+    def tile_bytes(self) -> int:
+        s = self.tile_stride
+        return s * (s // 4) if self.vec == 4 else s * s
+
+    def pack_tile(self, rect, bits) -> np.ndarray:
+        """bits uint8 [h,w] in {0,1} of clipped rect [yu,yd,xl,xr] -> one device code/flips tile (uint8 [tile_bytes])."""
+        yu, yd, xl, xr = (int(v) for v in rect)
+        s = self.tile_stride
+        full = np.zeros((s, s), dtype=np.uint8)
+        off = yu & 3
+        full[: xr - xl, off: off + yd - yu] = np.asarray(bits, dtype=np.uint8).reshape(xr - xl, yd - yu)
+        if self.vec == 1:
+            return full.reshape(-1)
+        g = full.reshape(s, s // 4, 4)
+        return (g[..., 0] | (g[..., 1] << 1) | (g[..., 2] << 2) | (g[..., 3] << 3)).astype(np.uint8).reshape(-1)
+
+    def unpack_tile(self, rect, tile) -> np.ndarray:
+        yu, yd, xl, xr = (int(v) for v in rect)
+        s = self.tile_stride
+        tile = np.asarray(tile, dtype=np.uint8)
+        if self.vec == 1:
+            full = tile.reshape(s, s)
+        else:
+            t = tile.reshape(s, s // 4)
+            full = np.stack([(t >> q) & 1 for q in range(4)], axis=-1).reshape(s, s)
+        off = yu & 3
+        return full[: xr - xl, off: off + yd - yu].copy()
+
+    def pack_truth(self, truth) -> np.ndarray:
+        """uint8/bool [..., gx, gy] -> bit-packed uint8 [..., truth_bytes] (cell x*gy+y = bit of the little-endian string)."""
+        t = np.asarray(truth).astype(np.uint8).reshape(*np.shape(truth)[:-2], -1)
+        packed = np.packbits(t, axis=-1, bitorder="little")
+        out = np.zeros((*packed.shape[:-1], self.truth_bytes), dtype=np.uint8)
+        out[..., : packed.shape[-1]] = packed
+        return out
+
+    def unpack_truth(self, packed) -> np.ndarray:
+        p = np.asarray(packed, dtype=np.uint8)
+        bits = np.unpackbits(p, axis=-1, bitorder="little")[..., : self.grid_x * self.grid_y]
+        return bits.reshape(*p.shape[:-1], self.grid_x, self.grid_y)
+
     def max_start_seed(self, episode: int) -> int:
         return self.env_seed * int(episode) * max(self.n_agents - 1, 0)

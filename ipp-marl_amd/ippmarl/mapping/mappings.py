@@ -28,7 +28,7 @@ class Mapping:
         self.sensor = sensor
         self.prior = params["mapping"]["prior"]
         self.engine = EpisodeEngine(params, episode, device=device)
-        self.simulated_map = self.engine.env.truth[0].cpu().numpy().astype(np.float64)
+        self.simulated_map = self.engine.env.truth_map[0].numpy().astype(np.float64)
         self.simulation = _SimulationView(self.simulated_map)
         self._scratch_calls = 0
 
@@ -59,9 +59,8 @@ class Mapping:
 
     def _pack_one(self, i, fc, flips_tile):
         env, d = self.engine.env, self.engine.d
-        out = np.zeros((1, d.n_agents, d.tile_stride, d.tile_stride), dtype=np.uint8)
-        yu, yd, xl, xr = fc
-        out[0, i, : xr - xl, (yu & 3): (yu & 3) + yd - yu] = np.asarray(flips_tile, dtype=np.uint8).reshape(xr - xl, yd - yu)
+        out = np.zeros((1, d.n_agents, d.tile_bytes), dtype=np.uint8)
+        out[0, i] = d.pack_tile(fc, flips_tile)
         return torch.from_numpy(out).to(env.device)
 
     # ------------------------------------------------------------------------------------------------

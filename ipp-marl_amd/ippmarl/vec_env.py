@@ -44,11 +44,11 @@ class VecEnv:
         self.pos = z(E, N, 3, dtype=torch.int32)
         self.pos_pre = z(E, N, 3, dtype=torch.int32)
         self.rect = z(E, N, 4, dtype=torch.int32)
-        self.truth = z(E, d.grid_x, d.grid_y, dtype=torch.uint8)
+        self.truth = z(E, d.truth_bytes, dtype=torch.uint8)           # bit-packed ground truth (1 bit per cell)
         # beliefs are stored as float32 log-odds (0 = prior 0.5); posterior_local()/posterior_global() export p
         self.local = z(E, N, d.grid_x, d.grid_y, dtype=torch.float32)
         self.glob = z(E, d.grid_x, d.grid_y, dtype=torch.float32)
-        self.code = z(E, N, S, S, dtype=torch.uint8)
+        self.code = z(E, N, d.tile_bytes, dtype=torch.uint8)          # packed measurement codes (a nibble per 4-cell group)
         self.comm = z(E, N, N, dtype=torch.uint8)
         self.comm_range = z(E, dtype=torch.float32)
         self.mask = z(E, N, A, dtype=torch.uint8)
@@ -91,6 +91,11 @@ class VecEnv:
     def posterior_global(self) -> torch.Tensor:
         return self._to_prob(self.glob)
 
+    @property
+    def truth_map(self) -> torch.Tensor:
+        """Ground truth as row-major uint8 [E, gx, gy] (unpacked on the host: inspection / tests only)."""
+        return torch.from_numpy(self.d.unpack_truth(self.truth.cpu().numpy()))
+
     def footprints(self, pos: Optional[torch.Tensor] = None):
         pos = self.pos if pos is None else pos
         rect = torch.empty(self.E, self.d.n_agents, 4, dtype=torch.int32, device=self.device)
@@ -112,7 +117,8 @@ class VecEnv:
                       self._p(self.split_pct), self._p(self.comm_range), self._p(self.ws), self._p(self.sums), self.E,
                       self.stream)
         if truth is not None:
-            self.truth.copy_(torch.as_tensor(truth).to(self.device, torch.uint8))
+            packed = d.pack_truth(torch.as_tensor(truth).cpu().numpy().reshape(self.E, d.grid_x, d.grid_y))
+            self.truth.copy_(torch.from_numpy(packed).to(self.device))
         if start_positions is not None:
             self.pos.copy_(torch.as_tensor(start_positions).to(self.device, torch.int32))
         self.t = 0
@@ -254,12 +260,11 @@ class VecEnv:
         return self.ctx.counters(self.stream, reset)
 
     def pack_flips(self, tiles, rects: np.ndarray) -> torch.Tensor:
-        """tiles[e][i]: uint8 [h,w] (1 = flipped) for clipped rect rects[e,i] = [yu,yd,xl,xr] -> device layout."""
-        S, N = self.d.tile_stride, self.d.n_agents
-        out = np.zeros((self.E, N, S, S), dtype=np.uint8)
+        """tiles[e][i]: uint8 [h,w] (1 = flipped) for clipped rect rects[e,i] = [yu,yd,xl,xr] -> device tile layout."""
+        N = self.d.n_agents
+        out = np.zeros((self.E, N, self.d.tile_bytes), dtype=np.uint8)
         for e in range(self.E):
             for i in range(N):
-                yu, yd, xl, xr = (int(v) for v in rects[e, i])
-                off = yu & 3
-                out[e, i, : xr - xl, off: off + yd - yu] = np.asarray(tiles[e][i], dtype=np.uint8).reshape(xr - xl, yd - yu)
+                if tiles[e][i] is not None:
+                    out[e, i] = self.d.pack_tile(rects[e, i], tiles[e][i])
         return torch.from_numpy(out).to(self.device)

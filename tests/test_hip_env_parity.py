@@ -31,7 +31,7 @@ def test_reset_matches_numpy_legacy_streams():
     for e, ep in enumerate(eps):
         for a in range(d.n_agents):
             assert list(pos[e, a]) == list(O.start_state(d, a, int(ep))), (ep, a)
-        assert np.array_equal(env.truth[e].cpu().numpy(), O.make_truth(d, int(ep)).astype(np.uint8)), ep
+        assert np.array_equal(env.truth_map[e].numpy(), O.make_truth(d, int(ep)).astype(np.uint8)), ep
     sp = env.split_pct.cpu().numpy()
     assert [tuple(v) for v in sp] == [O.truth_split_params(int(ep)) for ep in eps]
 
@@ -56,7 +56,7 @@ def test_golden_episode_replay(golden, tag):
         return env.pack_flips(tiles, rects)
 
     env.reset([int(fx["episode"])], flips=flips_for(0, fx["positions"][0]))
-    assert np.array_equal(env.truth[0].cpu().numpy(), fx["truth"])
+    assert np.array_equal(env.truth_map[0].numpy(), fx["truth"])
     assert np.array_equal(env.pos[0].cpu().numpy(), fx["positions"][0])
     for t in range(T):
         obs = env.build_observations(t, comm_draws=torch.from_numpy(comm[t].copy()).to(env.device))

@@ -9,6 +9,7 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 constexpr int G = 256, NPC = G / 8, TPC = 14, TPR = 25;
 
+template <int MODE>  // 0: maps only, 1: maps + byte planes (u32 per lane), 2: maps + bit-packed truth + 1 code byte per lane
 __global__ void __launch_bounds__(256) kA(float* maps, const uint8_t* truth, uint8_t* code, const int* rect, int split) {
   const int m = blockIdx.x / split, part = blockIdx.x % split;
   const int yu = rect[m * 4], yd = rect[m * 4 + 1], xl = rect[m * 4 + 2], xr = rect[m * 4 + 3];
@@ -25,11 +26,15 @@ __global__ void __launch_bounds__(256) kA(float* maps, const uint8_t* truth, uin
     for (int row = r0 + wv * rpw + sub; row < r1; row += 4 * rpw) {
       float4* p = reinterpret_cast<float4*>(map + (size_t)(xl + row) * G + y);
       float4 v = *p;
-      const uint32_t t = *reinterpret_cast<const uint32_t*>(tr + (size_t)(xl + row) * G + y);
+      uint32_t t = 0x01000100u;
+      const size_t lin = (size_t)(xl + row) * G + y;
+      if (MODE == 1) t = *reinterpret_cast<const uint32_t*>(tr + lin);
+      if (MODE == 2) { const uint32_t b = (tr[lin >> 3] >> (lin & 4)) & 0xF; t = (b & 1) | ((b & 2) << 7) | ((b & 4) << 14) | ((b & 8) << 21); }
       float* f = &v.x; uint32_t cw = 0;
       for (int q = 0; q < 4; ++q) { const bool in = (unsigned)(y + q - yu) < (unsigned)w; const uint32_t o = (t >> (8 * q)) & 1; f[q] = in ? f[q] + (o ? 0.5f : -0.5f) : f[q]; cw |= (in ? o : 0) << (8 * q); }
       *p = v;
-      *reinterpret_cast<uint32_t*>(cd + (size_t)row * 96 + (y - y0)) = cw;
+      if (MODE == 1) *reinterpret_cast<uint32_t*>(cd + (size_t)row * 96 + (y - y0)) = cw;
+      if (MODE == 2) cd[(size_t)row * 24 + gi] = (uint8_t)((cw & 1) | ((cw >> 7) & 2) | ((cw >> 14) & 4) | ((cw >> 21) & 8));
     }
   }
 }
@@ -90,21 +95,23 @@ int main() {
   }
   CK(hipMalloc(&dr, M * 16)); CK(hipMemcpy(dr, r.data(), M * 16, hipMemcpyHostToDevice));
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-  for (int split : {1, 2}) for (int which = 0; which < 3; ++which) {
+  for (int split : {2}) for (int which = 0; which < 5; ++which) {
     int it = 0;
     auto launch = [&]() {
       const int set = (it++) % SETS;
       float* dm = d + (size_t)set * M * G * G; const uint8_t* tr = truth + (size_t)set * (M / 4) * G * G; uint8_t* cd = code + (size_t)set * M * TPR * TPC * 32;
-      if (which == 0) kA<<<M * split, 256>>>(dm, tr, cd, dr, split);
+      if (which == 0) kA<1><<<M * split, 256>>>(dm, tr, cd, dr, split);
       else if (which == 1) kT<false><<<M * split, 256>>>(dm, tr, cd, dr, split);
-      else kT<true><<<M * split, 256>>>(dm, tr, cd, dr, split);
+      else if (which == 2) kT<true><<<M * split, 256>>>(dm, tr, cd, dr, split);
+      else if (which == 3) kA<0><<<M * split, 256>>>(dm, tr, cd, dr, split);
+      else kA<2><<<M * split, 256>>>(dm, tr, cd, dr, split);
     };
     for (int rep = 0; rep < 3; ++rep) launch();
     CK(hipEventRecord(a));
     for (int rep = 0; rep < 12; ++rep) launch();
     CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
     float ms; CK(hipEventElapsedTime(&ms, a, b));
-    const char* nm[3] = {"A row-major pow2", "B tiled pow2", "C tiled dense"};
+    const char* nm[5] = {"A row-major pow2", "B tiled pow2", "C tiled dense", "A maps only", "A packed planes"};
     printf("%-18s split=%d: %.1f us/launch, %.0f GB/s algorithmic (10 B/cell, %.1f M cells)\n", nm[which], split, ms * 1000 / 12, cells * 10 / (ms * 1e-3 / 12) / 1e9, cells / 1e6);
   }
   return 0;
