@@ -463,31 +463,47 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
       unsigned inm = 0;
 #pragma unroll
       for (int q = 0; q < VEC; ++q) inm |= ((unsigned)(y + q - kyu) < (unsigned)wdt) ? (1u << q) : 0u;
-      for (int row = r0 + wv * g.rpw + sub; row < r1; row += 4 * g.rpw) {
-        const size_t cell = (size_t)(kxl + row) * gy + y;
-        CellVec<VEC> mv = load_cells<VEC>(map + cell);
-        uint32_t cw = 0;
-        if (isf) cw = load_bits<VEC>(ctile, row, y - (kyu & ~3), S);
+      constexpr int FU = 2;  // independent rows in flight per lane (latency hiding at the low occupancy of these launches)
+      const int rstride = 4 * g.rpw;
+      for (int row0 = r0 + wv * g.rpw + sub; row0 < r1; row0 += rstride * FU) {
+        CellVec<VEC> mvu[FU];
+        uint32_t cwu[FU];
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) {
-          const float b = mv.v[q];
-          float a = ippm_clampl(b, lc) + (((cw >> q) & 1u) ? lm1 : lm0);
-          a = k_is_last ? a : ippm_clampl(a, lc);
-          const bool in = (inm >> q) & 1u;
-          a = in ? a : b;
-          exceed |= fabsf(a) > lc && in;
-          mv.v[q] = a;
-          if (REWARD && !(dbg & 1)) {
-            const float sel = (in && isf) ? 1.f : 0.f;
-            const float wa = ippm_weight_l(a, wt), wb = ippm_weight_l(b, wt);
-            const float hb = ippm_entropy_l(b, lc), ha = ippm_entropy_l(a, lc);
-            a1 += sel * (wa * (hb - ha));
-            aD += sel * ((wa - wb) * hb);
-            aT += sel * (wa * ha - wb * hb);
+        for (int u = 0; u < FU; ++u) {
+          const int row = row0 + u * rstride;
+          cwu[u] = 0;
+          if (row < r1) {
+            mvu[u] = load_cells<VEC>(map + (size_t)(kxl + row) * gy + y);
+            if (isf) cwu[u] = load_bits<VEC>(ctile, row, y - (kyu & ~3), S);
           }
         }
-        cells += __popc(inm);
-        store_cells<VEC>(map + cell, mv);
+#pragma unroll
+        for (int u = 0; u < FU; ++u) {
+          const int row = row0 + u * rstride;
+          if (row >= r1) continue;
+          CellVec<VEC>& mv = mvu[u];
+          const uint32_t cw = cwu[u];
+#pragma unroll
+          for (int q = 0; q < VEC; ++q) {
+            const float b = mv.v[q];
+            float a = ippm_clampl(b, lc) + (((cw >> q) & 1u) ? lm1 : lm0);
+            a = k_is_last ? a : ippm_clampl(a, lc);
+            const bool in = (inm >> q) & 1u;
+            a = in ? a : b;
+            exceed |= fabsf(a) > lc && in;
+            mv.v[q] = a;
+            if (REWARD && !(dbg & 1)) {
+              const float sel = (in && isf) ? 1.f : 0.f;
+              const float wa = ippm_weight_l(a, wt), wb = ippm_weight_l(b, wt);
+              const float hb = ippm_entropy_l(b, lc), ha = ippm_entropy_l(a, lc);
+              a1 += sel * (wa * (hb - ha));
+              aD += sel * ((wa - wb) * hb);
+              aT += sel * (wa * ha - wb * hb);
+            }
+          }
+          cells += __popc(inm);
+          store_cells<VEC>(map + (size_t)(kxl + row) * gy + y, mv);
+        }
       }
     }
     opcells = cells;
