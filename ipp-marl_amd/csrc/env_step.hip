@@ -394,7 +394,7 @@ template <int VEC, bool REWARD, int NK>
 __global__ void __launch_bounds__(256)
 k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const uint8_t* __restrict__ code,
             const int32_t* __restrict__ plan_ro, int32_t* __restrict__ ws, double* __restrict__ sums,
-            unsigned long long* __restrict__ counters, int split, int min_ops, int agent_sel, int dbg) {
+            unsigned long long* __restrict__ counters, int split, int min_ops, int agent_sel) {
   const int n = c->n_agents;
   const int part = blockIdx.x % split;
   // map index: (e,i) for local maps (one agent per env when agent_sel >= 0), e for global maps
@@ -492,7 +492,7 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
             a = in ? a : b;
             exceed |= fabsf(a) > lc && in;
             mv.v[q] = a;
-            if (REWARD && !(dbg & 1)) {
+            if (REWARD) {
               const float sel = (in && isf) ? 1.f : 0.f;
               const float wa = ippm_weight_l(a, wt), wb = ippm_weight_l(b, wt);
               const float hb = ippm_entropy_l(b, lc), ha = ippm_entropy_l(a, lc);
@@ -606,7 +606,7 @@ k_apply_ops(const ippm_config* __restrict__ c, float* __restrict__ maps, const u
     if (REWARD) { a1 = ippm_wave_sum(a1); aD = ippm_wave_sum(aD); aT = ippm_wave_sum(aT); }
     if (lane == 0) { s_red[wv][0] = a1; s_red[wv][1] = aD; s_red[wv][2] = aT; s_red[wv][3] = fc; s_red[wv][4] = fo; }
     __syncthreads();
-    if (threadIdx.x < 5 && !(dbg & 2)) {
+    if (threadIdx.x < 5) {
       const float t = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
       if (threadIdx.x < 3) {
         if (REWARD && t != 0.f) atomicAdd(&sums[(size_t)e * 8 + SUM_ACC1 + threadIdx.x], (double)t);
@@ -1047,7 +1047,7 @@ static void launch_apply(ippm_ctx* ctx, float* maps, const uint8_t* code, int32_
   dim3 block(256);
 #define IPPM_APPLY(V, NK, MINOPS)                                                                                      \
   hipLaunchKernelGGL((k_apply_ops<V, REWARD, NK>), dim3((unsigned)n_maps* split, std::min(max_ops, NK)), block, 0, st, \
-                     ctx->dcfg, maps, code, ws, ws, sums, ctx->dcounters, split, MINOPS, agent_sel, env_int("IPPM_DEBUG", 0))
+                     ctx->dcfg, maps, code, ws, ws, sums, ctx->dcounters, split, MINOPS, agent_sel)
   if (ctx->vec == 4) {
     IPPM_APPLY(4, 6, 1);
     if (max_ops > 6) IPPM_APPLY(4, 10, 7);

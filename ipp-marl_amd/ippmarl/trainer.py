@@ -155,6 +155,47 @@ class COMATrainer:
                 log(stats)
         return history
 
+    # ------------------------------------------------------------------------------------------------
+    def map_metrics(self):
+        """Per-env evaluation metrics of the fused global maps (coma_test.py:84-97,177-196; IG_baseline.py:84-97): mean
+        entropy over the target cells (weights from the ground truth) and F1 of the target class at p > 0.5."""
+        env = self.env
+        ent = torch.zeros(self.E, dtype=torch.float64, device=self.device)
+        env.ctx.call("ippm_weighted_entropy", env._p(env.glob), env._p(env.truth), 1, _ffi.ptr(ent), self.E, env.stream)
+        counts = torch.zeros(self.E, 3, dtype=torch.int64, device=self.device)
+        env.ctx.call("ippm_f1_counts", env._p(env.glob), env._p(env.truth), 1, 0.0, _ffi.ptr(counts), self.E, env.stream)
+        tp, fp, fn = counts[:, 0].double(), counts[:, 1].double(), counts[:, 2].double()
+        target = (tp + fn).clamp_min(1)
+        f1 = torch.where(2 * tp + fp + fn > 0, 2 * tp / (2 * tp + fp + fn).clamp_min(1), torch.zeros_like(tp))
+        return ent / target, f1
+
+    def evaluate(self, waves: int = 1) -> Dict[str, object]:
+        """Greedy (argmax) deployment of the current actor, the reference's coma_test loop for E envs at once: mean return and
+        the per-step curves of target entropy and F1 (index 0 = before the first step)."""
+        returns, ent_curves, f1_curves = [], [], []
+        for _ in range(waves):
+            env = self.env
+            eps_ids = episode_ids(self.first_episode, self.wave, self.E, self.rank, self.world)
+            env.reset(eps_ids)
+            e0, f0 = self.map_metrics()
+            ents, f1s = [e0.mean().item()], [f0.mean().item()]
+            ret = torch.zeros(self.E, device=self.device)
+            for t in range(self.T):
+                obs = env.build_observations(t)
+                with torch.no_grad():
+                    probs, _ = self.actor(obs.view(self.E * self.N, 11, 11, 7), self.eps)
+                reward, _, _ = env.steps(t, policy=POLICY_ARGMAX, probs=probs.view(self.E, self.N, self.A))
+                ret += reward[:, 0]
+                e, f = self.map_metrics()
+                ents.append(e.mean().item())
+                f1s.append(f.mean().item())
+            self.wave += 1
+            returns.append(float(ret.mean()))
+            ent_curves.append(ents)
+            f1_curves.append(f1s)
+        mean = lambda rows: [sum(c) / len(c) for c in zip(*rows)]  # noqa: E731
+        return {"episode_return": sum(returns) / len(returns), "target_entropy": mean(ent_curves), "f1": mean(f1_curves)}
+
     def save_actor(self, path: str):
         """Whole-module pickle of the actor, the reference's checkpoint format (coma_mission.py:425-451)."""
         torch.save(self.actor, path)

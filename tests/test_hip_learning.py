@@ -100,3 +100,23 @@ def test_sampling_policy_matches_oracle():
     env.steps(3, policy=POLICY_ARGMAX, probs=torch.tensor(probs, device=env.device), features=False)
     act, mask = env.action.cpu().numpy(), env.mask.cpu().numpy()
     assert np.array_equal(act, np.argmax(probs * mask, axis=-1))
+
+
+def test_evaluation_metrics_match_oracle():
+    """COMATrainer.map_metrics / evaluate: target entropy and F1 of the global maps against the oracle's restatement."""
+    from ippmarl.trainer import COMATrainer
+    params = make_params("small")
+    d = O.Derived(params)
+    torch.manual_seed(1)
+    tr = COMATrainer(params, n_envs=5, first_episode=9)
+    out = tr.evaluate(waves=1)
+    assert len(out["target_entropy"]) == tr.T + 1 and out["target_entropy"][0] == pytest.approx(1.0)
+    assert out["f1"][0] == 0.0 and np.isfinite(out["episode_return"])
+    assert out["target_entropy"][-1] < out["target_entropy"][0]
+    ent, f1 = tr.map_metrics()
+    glob = tr.env.posterior_global().cpu().numpy()
+    truth = tr.env.truth_map.numpy().astype(np.float64)
+    for e in range(tr.E):
+        np.testing.assert_allclose(float(ent[e]), O.target_entropy(d, glob[e].astype(np.float64), truth[e]), rtol=1e-5)
+        # exactly-cancelled cells are classified by rounding noise on both sides: F1 agrees to a few cells
+        assert abs(float(f1[e]) - O.f1_target(glob[e], truth[e])) < 0.02

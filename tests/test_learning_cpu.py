@@ -134,3 +134,45 @@ def test_gradient_allreduce_equals_single_process(tmp_path):
         torch.testing.assert_close(got["weights"][n], p.detach(), rtol=0, atol=2.5e-4)
     n_grad = sum(v.numel() for v in ref.values())
     assert got["bytes"] == 4 * n_grad == 4 * (2307846 - 256 * 256 - 256)  # one flat bucket, fc2 skipped
+
+
+def test_reference_checkpoint_format_loads(tmp_path):
+    """A whole-module pickle naming the reference's class path (actor.network.ActorNetwork) loads onto our ActorNetwork."""
+    import sys
+    import types
+    from ippmarl.checkpoint import load_reference_actor, save_actor
+    from ippmarl.networks import ActorNetwork
+    params = make_params("c2")
+    # fabricate the reference's module path with an architecture-identical class (the reference itself cannot travel)
+    mod_pkg, mod = types.ModuleType("actor"), types.ModuleType("actor.network")
+
+    class RefActor(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1 = torch.nn.Conv2d(7, 256, (5, 5)); self.conv2 = torch.nn.Conv2d(256, 256, (4, 4))
+            self.conv3 = torch.nn.Conv2d(256, 256, (4, 4)); self.fc1 = torch.nn.Linear(256, 256)
+            self.fc2 = torch.nn.Linear(256, 256); self.fc3 = torch.nn.Linear(256, 6)
+            self.device = torch.device("cpu"); self.hidden_states = [[]] * 4; self.baseline = "no"
+
+    RefActor.__module__, RefActor.__qualname__, RefActor.__name__ = "actor.network", "ActorNetwork", "ActorNetwork"
+    mod.ActorNetwork = RefActor
+    sys.modules["actor"], sys.modules["actor.network"] = mod_pkg, mod
+    try:
+        torch.manual_seed(3)
+        ref = RefActor()
+        path = str(tmp_path / "best_model.pth")
+        torch.save(ref, path)
+    finally:
+        del sys.modules["actor"], sys.modules["actor.network"]
+    actor = load_reference_actor(path, params)
+    assert isinstance(actor, ActorNetwork)
+    for (n1, p1), (n2, p2) in zip(ref.named_parameters(), actor.named_parameters()):
+        assert n1 == n2 and torch.equal(p1, p2)
+    x = torch.rand(3, 11, 11, 7)
+    with torch.no_grad():
+        probs, _ = actor(x, 0.1)
+    assert probs.shape == (3, 6) and torch.allclose(probs.sum(-1), torch.ones(3))
+    # our own save format round-trips through the same loader
+    save_actor(actor, str(tmp_path / "mine.pth"))
+    again = load_reference_actor(str(tmp_path / "mine.pth"), params)
+    assert all(torch.equal(a, b) for a, b in zip(actor.parameters(), again.parameters()))
