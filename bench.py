@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--profile-events", type=int, default=1, help="time every K3 launch with HIP events (roofline)")
     ap.add_argument("--train-rounds", type=int, default=2, help="COMA rounds (rollout with the actor + full update) timed after "
                     "the env-only region for the COMA updates/s figure; 0 disables")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI; gloo lets the "
+                    "multi-rank code path be exercised on a single GPU)")
     ap.add_argument("--graphs", type=int, default=1, help="replay the launch-bound part of each step (comm, K4, K5, K1) from "
                     "hipGraphs; K3 stays an ordinary launch bracketed by events")
     ap.add_argument("--calib", action="store_true", help="PMC calibration: 3 device-to-device clones of the local maps (known "
@@ -101,7 +103,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        n_dev = torch.cuda.device_count()
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank % n_dev}"))
+        else:
+            dist.init_process_group(args.dist_backend)
+        local_rank %= n_dev
     device = f"cuda:{local_rank}"
     torch.cuda.set_device(device)
 
