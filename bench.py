@@ -43,7 +43,7 @@ def bench_params(args):
     return grid256_params(experiment__missions__n_agents=args.agents, sensor__pixel__number_x=number, sensor__pixel__number_y=number)
 
 
-def cpu_baseline(params, budget_s=15.0):
+def cpu_baseline(params, budget_s=15.0, terrain="random_field"):
     """Oracle (kind 'port'): same env-only workload, one env at a time, explicit NumPy on one core."""
     import ipp_oracle as O
     torch.set_num_threads(1)
@@ -60,7 +60,9 @@ def cpu_baseline(params, budget_s=15.0):
 
         ep = O.OracleEpisode(params, episode, correctness,
                              lambda i, t, m, o: O.uniform_valid_action(O.philox_action_word(seed, episode, i, t), m),
-                             build_features=False)
+                             build_features=False,
+                             truth=O.grf_field(d.gx, d.gy, episode, float(params["sensor"]["simulation"]["cluster_radius"]))
+                             if terrain == "random_field" else None)
         holder["ep"] = ep
         for t in range(d.budget + 1):
             ep.step(t)
@@ -82,6 +84,9 @@ def main():
     ap.add_argument("--envs", type=int, default=1024, help="envs per GPU")
     ap.add_argument("--agents", type=int, default=4)
     ap.add_argument("--grid", type=int, default=256, choices=[128, 256, 512, 1024])
+    ap.add_argument("--terrain", default="random_field", choices=["random_field", "split"],
+                    help="ground truth: the power-law random field of ground_truths.py:25-40 generated on the device, or "
+                         "the half-plane split the reference flies over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-events", type=int, default=1, help="time every K3 launch with HIP events (roofline)")
     ap.add_argument("--train-rounds", type=int, default=2, help="COMA rounds (rollout with the actor + full update) timed after "
@@ -114,7 +119,7 @@ def main():
 
     from ippmarl.vec_env import VecEnv, POLICY_UNIFORM
     params = bench_params(args)
-    env = VecEnv(params, args.envs, device=device, philox_seed=3)
+    env = VecEnv(params, args.envs, device=device, philox_seed=3, terrain=args.terrain)
     E, N, T = env.E, env.d.n_agents, env.d.budget + 1
     base = torch.arange(1, E + 1, dtype=torch.int64) + rank * E  # disjoint episodes per rank
     wave = [0]
@@ -226,7 +231,7 @@ def main():
         env.sense = None
         env = None  # release the env-only state before the trainer allocates its own
         torch.cuda.empty_cache()
-        tr = COMATrainer(params, args.envs, device=device, philox_seed=3, rank=rank, world=world)
+        tr = COMATrainer(params, args.envs, device=device, philox_seed=3, rank=rank, world=world, terrain=args.terrain)
         tr.rollout("train")
         tr.update()  # warm-up round (MIOpen kernel selection, allocator)
         torch.cuda.synchronize()
@@ -255,17 +260,19 @@ def main():
             "metric": "agent-env steps/s (4 UAVs, 256x256 grid, random policy, env-step HIP kernels)",
             "value": total_steps / dt, "unit": "agent-env steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic (device-generated half-plane truth, Philox sensor noise)",
+            "vs_baseline": None, "dtype": "f32", "data": ("synthetic random-field terrain (power-law Gaussian random field thresholded at 0.5, generated on the device per "
+                     "episode; Philox sensor noise)" if args.terrain == "random_field" else
+                     "synthetic (device-generated half-plane truth, Philox sensor noise)"),
             "config": {"workload": "BASELINE.json configs[1]: 4 UAVs, 256x256 grid, 1024 batched envs per GPU, random policy, "
                                    "env-step kernels only", "envs_per_gpu": E, "n_agents": N, "grid": grid,
-                       "episode_steps": T, "parallelism": f"env-sharded x{world} (no data-path collective)", "hip_graphs": bool(args.graphs)},
+                       "episode_steps": T, "terrain": args.terrain, "parallelism": f"env-sharded x{world} (no data-path collective)", "hip_graphs": bool(args.graphs)},
             "faults": faults,
             "cells": counters,
             "roofline": roofline,
             "coma_training": coma,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(params)
+            out["cpu_baseline"] = cpu_baseline(params, terrain=args.terrain)
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -234,6 +234,26 @@ int ippm_ig_select(ippm_ctx* ctx, const int32_t* pos, const uint8_t* mask, const
 int ippm_f1_counts(ippm_ctx* ctx, const float* maps, const uint8_t* truth, int32_t maps_per_truth, float logodds_threshold,
                    int64_t* out, int32_t n_maps, void* stream);
 
+/* Synthetic random-field terrain: the device ends of the spectral synthesis the reference performs for every episode
+ * (mapping/ground_truths.py:16-40; mapping/simulations.py:34-40) and then overwrites with the half-plane split.  The
+ * caller runs the two FFTs and the sqrt(P(k)) product between the calls (ippmarl/terrain.py uses rocFFT via torch.fft).
+ * ippm_terrain_noise: standard-normal white noise float [E,gx,gy] from Philox(seed; episode, cell), so an episode's
+ *   terrain is the same in every batch and on every rank.
+ * Power-of-two grids (sides 8..1024) do the whole synthesis in the library: the spectrum is drawn directly (the FFT of
+ *   real N(0,1) noise is Hermitian complex white noise) and inverted in two LDS passes.
+ *   ippm_terrain_spectrum: spec complex64 [E,gx,gy/2+1] = amp[gx,gy/2+1] * bin noise, Philox(seed; episode, bin).
+ *   ippm_terrain_field: field float [E,gx,gy] = unnormalised inverse real transform of `spec`, or, when spec is NULL,
+ *     of the spectrum ippm_terrain_spectrum would have written for (episode, amp) (drawn in-kernel, never stored);
+ *     work = complex64 [E,gy/2+1,gx] scratch.  range_keys (uint32 [E,2], optional) receives each field's (min, max)
+ *     as order-preserving keys (key = ~bits for negative floats, bits | 0x80000000 otherwise) for ippm_terrain_pack.
+ * ippm_terrain_pack: truth bit = (f - min f)/(max f - min f) >= 0.5 per env (ground_truths.py:32-40), written in the
+ *   bit-packed truth layout above; min/max are taken from range_keys when given, else reduced here. */
+int ippm_terrain_noise(ippm_ctx* ctx, const int64_t* episode, float* noise, int32_t n_envs, void* stream);
+int ippm_terrain_spectrum(ippm_ctx* ctx, const int64_t* episode, const float* amp, float* spec, int32_t n_envs, void* stream);
+int ippm_terrain_field(ippm_ctx* ctx, const int64_t* episode, const float* amp, const float* spec, float* work, float* field,
+                       uint32_t* range_keys, int32_t n_envs, void* stream);
+int ippm_terrain_pack(ippm_ctx* ctx, const float* field, const uint32_t* range_keys, uint8_t* truth, int32_t n_envs, void* stream);
+
 /* Host helpers (no GPU needed): exported so that CPU-only tests can pin the device's integer streams and
  * resize weights to NumPy / the oracle. */
 int ippm_area_weights(int32_t n_src, int32_t n_dst, int32_t* bin0, float* w0, float* w1);

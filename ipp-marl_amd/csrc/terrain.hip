@@ -1,0 +1,417 @@
+// Synthetic random-field terrain: the two device ends of the spectral synthesis the reference runs for every
+// episode (mapping/ground_truths.py:16-40: white noise -> FFT -> sqrt(P(k)) -> inverse FFT -> min/max normalise
+// -> >= 0.5).  The FFTs between the two kernels are rocFFT calls made by the host side (ippmarl/terrain.py).
+#include "ippm_internal.h"
+
+#define IPPM_DOMAIN_TERRAIN 3u
+
+static inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Standard-normal white noise, four cells per Philox block (two Box-Muller pairs).  The stream depends on
+// (seed, episode, cell) only, so an episode's terrain does not depend on the batch it is generated in.
+__global__ __launch_bounds__(256) void k_terrain_noise(const ippm_config* __restrict__ c, const int64_t* __restrict__ episode,
+                                                       float* __restrict__ noise, size_t cells) {
+  const int e = blockIdx.y;
+  const uint64_t ep = (uint64_t)episode[e];
+  const uint32_t k0 = (uint32_t)c->philox_seed, k1 = (uint32_t)(c->philox_seed >> 32);
+  const uint32_t sw = ippm_stream_word(0u, 0u, IPPM_DOMAIN_TERRAIN);
+  float* out = noise + (size_t)e * cells;
+  const size_t groups = (cells + 3) >> 2;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (size_t)gridDim.x * blockDim.x) {
+    Philox4 ph = ippm_philox((uint32_t)g, (uint32_t)ep, sw, (uint32_t)(ep >> 32), k0, k1);
+    float z[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      // u1 in (0,1], u2 in [0,1)
+      const float u1 = ((float)(ph.v[2 * h] >> 8) + 1.0f) * (1.0f / 16777216.0f);
+      const float u2 = (float)(ph.v[2 * h + 1] >> 8) * (1.0f / 16777216.0f);
+      const float r = sqrtf(-2.0f * logf(u1));
+      float s, co;
+      sincospif(2.0f * u2, &s, &co);
+      z[2 * h] = r * co;
+      z[2 * h + 1] = r * s;
+    }
+    const size_t base = g << 2;
+    if (base + 3 < cells && (cells & 3) == 0) {
+      *reinterpret_cast<float4*>(out + base) = make_float4(z[0], z[1], z[2], z[3]);
+    } else {
+      for (int q = 0; q < 4 && base + q < cells; ++q) out[base + q] = z[q];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Power-of-two grids: the spectrum is drawn directly (the FFT of real white noise is Hermitian complex white noise, so
+// the forward transform of ground_truths.py:26 is not needed) and the inverse transform is done here, in two passes
+// through LDS, because rocFFT's batched 2-D real transforms run at ~0.5 TB/s on this shape (tools/terrain_probe.py:
+// 446 + 626 us for 1024 fields of 256 x 256 against ~150 us for the two passes below).
+//   pass X: one workgroup per (env, tile of CW ky-columns): bins -> LDS (bit-reversed kx) -> radix-2 DIT along x ->
+//           T[e, ky, x] (x contiguous: fully coalesced writes)
+//   pass Y: one workgroup per (env, XW x-rows): T[e, 0..gy/2, x] -> LDS rows, Hermitian-extended to gy bins
+//           (bit-reversed ky) -> radix-2 DIT along y -> real part -> field[e, x, y]
+// Only the half spectrum ky in [0, gy/2] is ever stored (the real field's other half is its conjugate mirror).
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ uint32_t bitrev(uint32_t v, int bits) { return __brev(v) >> (32 - bits); }
+
+// Bin (kx, ky) of the half spectrum of N(0,1) white noise, up to a common factor: generic bins are a + ib with
+// a, b ~ N(0,1); on the self-mirrored columns ky in {0, gy/2} bin (gx - kx) is the conjugate of bin kx and the four
+// self-conjugate bins are real with twice the variance.
+__device__ __forceinline__ float2 terrain_bin(uint64_t ep, uint32_t k0, uint32_t k1, int gx, int gy, int kx, int ky, float amp) {
+  const bool edge = ky == 0 || 2 * ky == gy;
+  int cx = kx;
+  bool conj = false;
+  if (edge && 2 * kx > gx) { cx = gx - kx; conj = true; }
+  const bool self = edge && (cx == 0 || 2 * cx == gx);
+  const uint32_t bin = (uint32_t)cx * (uint32_t)(gy / 2 + 1) + (uint32_t)ky;
+  Philox4 ph = ippm_philox(bin, (uint32_t)ep, ippm_stream_word(0u, 1u, IPPM_DOMAIN_TERRAIN), (uint32_t)(ep >> 32), k0, k1);
+  const float u1 = ((float)(ph.v[0] >> 8) + 1.0f) * (1.0f / 16777216.0f);
+  const float u2 = (float)(ph.v[1] >> 8) * (1.0f / 16777216.0f);
+  const float r = sqrtf(-2.0f * logf(u1));
+  float sn, cs;
+  sincospif(2.0f * u2, &sn, &cs);
+  if (self) return make_float2(amp * 1.41421356237f * r * cs, 0.0f);
+  return make_float2(amp * r * cs, conj ? -amp * r * sn : amp * r * sn);
+}
+
+__global__ __launch_bounds__(256) void k_terrain_spectrum(const ippm_config* __restrict__ c, const int64_t* __restrict__ episode,
+                                                          const float* __restrict__ amp, float2* __restrict__ spec) {
+  const int e = blockIdx.y, gx = c->grid_x, gy = c->grid_y, hy = gy / 2 + 1;
+  const uint64_t ep = (uint64_t)episode[e];
+  const uint32_t k0 = (uint32_t)c->philox_seed, k1 = (uint32_t)(c->philox_seed >> 32);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < gx * hy; i += gridDim.x * blockDim.x)
+    spec[(size_t)e * gx * hy + i] = terrain_bin(ep, k0, k1, gx, gy, i / hy, i % hy, amp[i]);
+}
+
+// ---- register-resident FFT pieces ----------------------------------------------------------------------------
+__device__ constexpr float TWC[16] = {1.000000000f, 0.980785280f, 0.923879533f, 0.831469612f, 0.707106781f, 0.555570233f,
+                                      0.382683432f, 0.195090322f, 0.000000000f, -0.195090322f, -0.382683432f, -0.555570233f,
+                                      -0.707106781f, -0.831469612f, -0.923879533f, -0.980785280f};
+__device__ constexpr float TWS[16] = {0.000000000f, 0.195090322f, 0.382683432f, 0.555570233f, 0.707106781f, 0.831469612f,
+                                      0.923879533f, 0.980785280f, 1.000000000f, 0.980785280f, 0.923879533f, 0.831469612f,
+                                      0.707106781f, 0.555570233f, 0.382683432f, 0.195090322f};
+
+// inverse (e^{+i..}) FFT of R = 8/16/32 points held in registers, natural order in and out; every index is a
+// compile-time constant after unrolling, so the array never leaves the VGPRs
+template <int R>
+__device__ __forceinline__ void fft_reg(float2 (&a)[R]) {
+  constexpr int LOG = R == 8 ? 3 : (R == 16 ? 4 : 5);
+  static_assert((1 << LOG) == R, "fft_reg: R must be 8, 16 or 32");
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    int j = 0;
+#pragma unroll
+    for (int b = 0; b < LOG; ++b) j |= ((i >> b) & 1) << (LOG - 1 - b);
+    if (i < j) {
+      const float2 t = a[i];
+      a[i] = a[j];
+      a[j] = t;
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < LOG; ++s) {
+#pragma unroll
+    for (int j = 0; j < R / 2; ++j) {
+      const int half = 1 << s, pos = j & (half - 1), i0 = ((j >> s) << (s + 1)) + pos, i1 = i0 + half, t = pos * (16 >> s);
+      const float2 u = a[i0], v = cmul(a[i1], make_float2(TWC[t], TWS[t]));
+      a[i0] = make_float2(u.x + v.x, u.y + v.y);
+      a[i1] = make_float2(u.x - v.x, u.y - v.y);
+    }
+  }
+}
+
+// Four-step FFT of Q sequences of n = N1 * N2 points per workgroup.  In: thread (q_in, i2) holds x[i1 * N2 + i2],
+// i1 = 0..N1-1.  N1-point transforms in registers, twiddle by W_n^(i2 k1), one exchange through LDS, N2-point
+// transforms in registers.  Out: thread (k1, q_out) holds X[k1 + N1 * k2], k2 = 0..N2-1.
+template <int N1, int N2, int Q>
+struct FourStep {
+  static constexpr int SEQ = N1 * (N2 + 1) + 1;  // padded so that neither side of the exchange piles onto few LDS banks
+  static constexpr int THREADS = Q * (N1 > N2 ? N1 : N2);
+  float2 xbuf[Q * SEQ];
+  float2 twn[N1 * N2];
+
+  __device__ __forceinline__ void init_twiddles() {
+    for (int i = threadIdx.x; i < N1 * N2; i += THREADS) {
+      float sn, cs;
+      sincospif(2.0f * (float)i / (float)(N1 * N2), &sn, &cs);
+      twn[i] = make_float2(cs, sn);
+    }
+    __syncthreads();
+  }
+  __device__ __forceinline__ void run(float2 (&v)[N1], float2 (&o)[N2], int q_in, int i2, bool in_active, int q_out, int k1,
+                                      bool out_active) {
+    if (in_active) {
+      fft_reg<N1>(v);
+#pragma unroll
+      for (int k = 0; k < N1; ++k) xbuf[q_in * SEQ + k * (N2 + 1) + i2] = cmul(v[k], twn[i2 * k]);
+    }
+    __syncthreads();
+    if (out_active) {
+#pragma unroll
+      for (int i = 0; i < N2; ++i) o[i] = xbuf[q_out * SEQ + k1 * (N2 + 1) + i];
+      fft_reg<N2>(o);
+    }
+  }
+};
+
+// float <-> uint32 key with the same ordering, so that min/max of floats can use integer atomics
+__device__ __forceinline__ uint32_t order_key(float f) {
+  const uint32_t b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key_value(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
+
+// pass X: sequences are the ky columns of the half spectrum (length gx = N1 * N2), Q columns per workgroup
+template <int N1, int N2, int Q, bool GEN>
+__global__ __launch_bounds__((FourStep<N1, N2, Q>::THREADS)) void k_terrain_fft_x(const ippm_config* __restrict__ c,
+                                                                               const int64_t* __restrict__ episode,
+                                                                               const float* __restrict__ amp,
+                                                                               const float2* __restrict__ spec,
+                                                                               float2* __restrict__ work,
+                                                                               uint32_t* __restrict__ range_keys) {
+  __shared__ FourStep<N1, N2, Q> fs;
+  const int e = blockIdx.y, gx = N1 * N2, gy = c->grid_y, hy = gy / 2 + 1, c0 = blockIdx.x * Q, tid = threadIdx.x;
+  if (range_keys && blockIdx.x == 0 && tid == 0) {   // pass Y accumulates the field's (min, max) here
+    range_keys[2 * e] = 0xFFFFFFFFu;
+    range_keys[2 * e + 1] = 0u;
+  }
+  fs.init_twiddles();
+  const int q_in = tid % Q, i2 = tid / Q, k1 = tid % N1, q_out = tid / N1;
+  const bool in_active = i2 < N2, out_active = q_out < Q;
+  float2 v[N1], o[N2];
+  if (in_active) {
+    const int ky = c0 + q_in;
+    const uint64_t ep = GEN ? (uint64_t)episode[e] : 0;
+    const uint32_t k0 = (uint32_t)c->philox_seed, k1s = (uint32_t)(c->philox_seed >> 32);
+#pragma unroll
+    for (int i1 = 0; i1 < N1; ++i1) {
+      const int kx = i1 * N2 + i2;
+      v[i1] = make_float2(0.0f, 0.0f);
+      if (ky < hy) {
+        if (GEN) v[i1] = terrain_bin(ep, k0, k1s, gx, gy, kx, ky, amp[(size_t)kx * hy + ky]);
+        else v[i1] = spec[((size_t)e * gx + kx) * hy + ky];
+      }
+    }
+  }
+  fs.run(v, o, q_in, i2, in_active, q_out, k1, out_active);
+  if (out_active && c0 + q_out < hy) {
+    float2* dst = work + ((size_t)e * hy + c0 + q_out) * gx + k1;
+#pragma unroll
+    for (int k2 = 0; k2 < N2; ++k2) dst[N1 * k2] = o[k2];
+  }
+}
+
+// pass Y: sequences are the x rows (length gy = N1 * N2 after the Hermitian extension), Q rows per workgroup
+template <int N1, int N2, int Q>
+__global__ __launch_bounds__((FourStep<N1, N2, Q>::THREADS)) void k_terrain_fft_y(const ippm_config* __restrict__ c,
+                                                                               const float2* __restrict__ work,
+                                                                               float* __restrict__ field,
+                                                                               uint32_t* __restrict__ range_keys) {
+  __shared__ FourStep<N1, N2, Q> fs;
+  const int e = blockIdx.y, gx = c->grid_x, gy = N1 * N2, hy = gy / 2 + 1, x0 = blockIdx.x * Q, tid = threadIdx.x;
+  fs.init_twiddles();
+  const int q_in = tid % Q, i2 = tid / Q, k1 = tid % N1, q_out = tid / N1;
+  const bool in_active = i2 < N2, out_active = q_out < Q;
+  float2 v[N1], o[N2];
+  if (in_active) {
+    const float2* src = work + (size_t)e * hy * gx + x0 + q_in;
+#pragma unroll
+    for (int i1 = 0; i1 < N1; ++i1) {
+      const int i = i1 * N2 + i2, m = 2 * i > gy ? gy - i : i;   // bins above gy/2 are the conjugate mirror
+      float2 t = src[(size_t)m * gx];
+      if (2 * i > gy) t.y = -t.y;
+      if (i == 0 || 2 * i == gy) t.y = 0.0f;                     // self-mirrored bins of a real transform
+      v[i1] = t;
+    }
+  }
+  fs.run(v, o, q_in, i2, in_active, q_out, k1, out_active);
+  float lo = INFINITY, hi = -INFINITY;
+  if (out_active) {
+    float* dst = field + ((size_t)e * gx + x0 + q_out) * gy + k1;
+#pragma unroll
+    for (int k2 = 0; k2 < N2; ++k2) {
+      dst[N1 * k2] = o[k2].x;
+      lo = fminf(lo, o[k2].x);
+      hi = fmaxf(hi, o[k2].x);
+    }
+  }
+  if (range_keys) {   // wavefront, then workgroup reduction; one atomic pair per workgroup
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+      lo = fminf(lo, __shfl_xor(lo, m, 64));
+      hi = fmaxf(hi, __shfl_xor(hi, m, 64));
+    }
+    __shared__ float s_lo[8], s_hi[8];
+    constexpr int NW = FourStep<N1, N2, Q>::THREADS / 64;
+    if ((tid & 63) == 0) { s_lo[tid >> 6] = lo; s_hi[tid >> 6] = hi; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < NW; ++w) { lo = fminf(lo, s_lo[w]); hi = fmaxf(hi, s_hi[w]); }
+      atomicMin(range_keys + 2 * e, order_key(lo));
+      atomicMax(range_keys + 2 * e + 1, order_key(hi));
+    }
+  }
+}
+
+// IPPM_PACK_PARTS workgroups per env: each one reduces min/max over the whole env field (256 KiB at 256 x 256: the
+// repeats are L2 hits) and then writes its share of truth bits, bit = (f - min)/(max - min) >= 0.5, packed 64 cells
+// per wavefront ballot in the library's truth layout (bit lin & 7 of byte lin >> 3).
+#define IPPM_PACK_PARTS 4
+__global__ __launch_bounds__(1024) void k_terrain_pack(const float* __restrict__ field, uint8_t* __restrict__ truth, size_t cells,
+                                                       size_t truth_bytes) {
+  __shared__ float s_lo[16], s_hi[16];
+  const int e = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
+  const float* f = field + (size_t)e * cells;
+  float lo = INFINITY, hi = -INFINITY;
+  if ((cells & 3) == 0) {
+    const float4* f4 = reinterpret_cast<const float4*>(f);
+    const size_t n4 = cells >> 2;
+#pragma unroll 4
+    for (size_t i = tid; i < n4; i += blockDim.x) {
+      const float4 v = f4[i];
+      lo = fminf(fminf(lo, fminf(v.x, v.y)), fminf(v.z, v.w));
+      hi = fmaxf(fmaxf(hi, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    }
+  } else {
+    for (size_t i = tid; i < cells; i += blockDim.x) {
+      const float v = f[i];
+      lo = fminf(lo, v);
+      hi = fmaxf(hi, v);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, o, 64));
+    hi = fmaxf(hi, __shfl_xor(hi, o, 64));
+  }
+  if (lane == 0) { s_lo[wave] = lo; s_hi[wave] = hi; }
+  __syncthreads();
+  lo = s_lo[0];
+  hi = s_hi[0];
+  for (int w = 1; w < nwave; ++w) {
+    lo = fminf(lo, s_lo[w]);
+    hi = fmaxf(hi, s_hi[w]);
+  }
+  const float span = hi - lo;
+  uint32_t* out = reinterpret_cast<uint32_t*>(truth + (size_t)e * truth_bytes);  // truth_bytes is a multiple of 4
+  const size_t words = truth_bytes >> 2;
+  const size_t chunks = (cells + 63) >> 6;
+  for (size_t ch = (size_t)blockIdx.x * nwave + wave; ch < chunks; ch += (size_t)gridDim.x * nwave) {
+    const size_t i = (ch << 6) + lane;
+    const bool one = i < cells && (f[i] - lo) / span >= 0.5f;
+    const uint64_t bits = __ballot(one);
+    if (lane < 2 && 2 * ch + lane < words) out[2 * ch + lane] = (uint32_t)(bits >> (32 * lane));
+  }
+}
+
+// same thresholding with the (min, max) already known (ippm_terrain_field's range_keys): one flat pass
+__global__ __launch_bounds__(256) void k_terrain_pack_keys(const float* __restrict__ field, const uint32_t* __restrict__ range_keys,
+                                                           uint8_t* __restrict__ truth, size_t cells, size_t truth_bytes) {
+  const int e = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  const float* f = field + (size_t)e * cells;
+  const float lo = key_value(range_keys[2 * e]), span = key_value(range_keys[2 * e + 1]) - lo;
+  uint32_t* out = reinterpret_cast<uint32_t*>(truth + (size_t)e * truth_bytes);
+  const size_t words = truth_bytes >> 2, chunks = (cells + 63) >> 6;
+  const size_t stride = (size_t)gridDim.x * nwave;
+  for (size_t ch0 = (size_t)blockIdx.x * nwave + wave; ch0 < chunks; ch0 += 4 * stride) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {   // four independent loads in flight before the first ballot
+      const size_t i = ((ch0 + u * stride) << 6) + lane;
+      v[u] = i < cells ? f[i] : lo;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const size_t ch = ch0 + u * stride;
+      const uint64_t bits = __ballot(((ch << 6) + lane) < cells && (v[u] - lo) / span >= 0.5f);
+      if (ch < chunks && lane < 2 && 2 * ch + lane < words) out[2 * ch + lane] = (uint32_t)(bits >> (32 * lane));
+    }
+  }
+}
+
+extern "C" int ippm_terrain_noise(ippm_ctx* ctx, const int64_t* episode, float* noise, int32_t n_envs, void* stream) {
+  if (!ctx || !episode || !noise) { ippm_set_error("ippm_terrain_noise: null argument"); return -1; }
+  if (n_envs <= 0) return 0;
+  const size_t cells = (size_t)ctx->cfg.grid_x * ctx->cfg.grid_y;
+  const int gx = (int)std::min<size_t>(64, (cells / 4 + 255) / 256);
+  hipLaunchKernelGGL(k_terrain_noise, dim3(gx > 0 ? gx : 1, n_envs), dim3(256), 0, S_(stream), ctx->dcfg, episode, noise, cells);
+  IPPM_LAUNCH_CHECK("terrain_noise");
+  return 0;
+}
+
+extern "C" int ippm_terrain_pack(ippm_ctx* ctx, const float* field, const uint32_t* range_keys, uint8_t* truth, int32_t n_envs,
+                                 void* stream) {
+  if (!ctx || !field || !truth) { ippm_set_error("ippm_terrain_pack: null argument"); return -1; }
+  if (n_envs <= 0) return 0;
+  const size_t cells = (size_t)ctx->cfg.grid_x * ctx->cfg.grid_y;
+  if (range_keys) {
+    const int gxb = (int)std::min<size_t>(64, ((cells + 63) / 64 + 15) / 16);
+    hipLaunchKernelGGL(k_terrain_pack_keys, dim3(gxb > 0 ? gxb : 1, n_envs), dim3(256), 0, S_(stream), field, range_keys, truth, cells,
+                       ippm_truth_bytes(ctx->cfg.grid_x, ctx->cfg.grid_y));
+    IPPM_LAUNCH_CHECK("terrain_pack_keys");
+    return 0;
+  }
+  hipLaunchKernelGGL(k_terrain_pack, dim3(IPPM_PACK_PARTS, n_envs), dim3(1024), 0, S_(stream), field, truth, cells,
+                     ippm_truth_bytes(ctx->cfg.grid_x, ctx->cfg.grid_y));
+  IPPM_LAUNCH_CHECK("terrain_pack");
+  return 0;
+}
+
+static bool terrain_side_ok(int n) { return n == 128 || n == 256 || n == 512 || n == 1024; }
+
+static int terrain_pow2_check(const ippm_ctx* ctx, const char* who) {
+  if (!terrain_side_ok(ctx->cfg.grid_x) || !terrain_side_ok(ctx->cfg.grid_y)) {
+    ippm_set_error(std::string(who) + ": grid sides must be 128, 256, 512 or 1024 (use ippm_terrain_noise + an FFT library otherwise)");
+    return -1;
+  }
+  return 0;
+}
+
+// n = N1 * N2 split and sequences per workgroup for each supported side
+#define TERRAIN_DISPATCH(n, CALL)                \
+  switch (n) {                                   \
+    case 128: { CALL(8, 16, 16); break; }        \
+    case 256: { CALL(16, 16, 16); break; }       \
+    case 512: { CALL(16, 32, 8); break; }        \
+    default: { CALL(32, 32, 4); break; }         \
+  }
+
+extern "C" int ippm_terrain_spectrum(ippm_ctx* ctx, const int64_t* episode, const float* amp, float* spec, int32_t n_envs,
+                                     void* stream) {
+  if (!ctx || !episode || !amp || !spec) { ippm_set_error("ippm_terrain_spectrum: null argument"); return -1; }
+  if (terrain_pow2_check(ctx, "ippm_terrain_spectrum")) return -1;
+  if (n_envs <= 0) return 0;
+  const int bins = ctx->cfg.grid_x * (ctx->cfg.grid_y / 2 + 1);
+  hipLaunchKernelGGL(k_terrain_spectrum, dim3(std::min(64, (bins + 255) / 256), n_envs), dim3(256), 0, S_(stream), ctx->dcfg,
+                     episode, amp, reinterpret_cast<float2*>(spec));
+  IPPM_LAUNCH_CHECK("terrain_spectrum");
+  return 0;
+}
+
+extern "C" int ippm_terrain_field(ippm_ctx* ctx, const int64_t* episode, const float* amp, const float* spec, float* work,
+                                  float* field, uint32_t* range_keys, int32_t n_envs, void* stream) {
+  if (!ctx || !work || !field) { ippm_set_error("ippm_terrain_field: null argument"); return -1; }
+  if (!spec && (!episode || !amp)) { ippm_set_error("ippm_terrain_field: needs either spec or (episode, amp)"); return -1; }
+  if (terrain_pow2_check(ctx, "ippm_terrain_field")) return -1;
+  if (n_envs <= 0) return 0;
+  const int gx = ctx->cfg.grid_x, gy = ctx->cfg.grid_y, hy = gy / 2 + 1;
+  const float2* spec2 = reinterpret_cast<const float2*>(spec);
+  float2* work2 = reinterpret_cast<float2*>(work);
+#define LAUNCH_X(N1, N2, Q)                                                                                                  \
+  if (spec)                                                                                                                  \
+    hipLaunchKernelGGL((k_terrain_fft_x<N1, N2, Q, false>), dim3((hy + Q - 1) / Q, n_envs), dim3(FourStep<N1, N2, Q>::THREADS), 0, \
+                       S_(stream), ctx->dcfg, episode, amp, spec2, work2, range_keys);                                                 \
+  else                                                                                                                       \
+    hipLaunchKernelGGL((k_terrain_fft_x<N1, N2, Q, true>), dim3((hy + Q - 1) / Q, n_envs), dim3(FourStep<N1, N2, Q>::THREADS), 0, \
+                       S_(stream), ctx->dcfg, episode, amp, spec2, work2, range_keys)
+  TERRAIN_DISPATCH(gx, LAUNCH_X)
+#undef LAUNCH_X
+  IPPM_LAUNCH_CHECK("terrain_fft_x");
+#define LAUNCH_Y(N1, N2, Q)                                                                                                  \
+  hipLaunchKernelGGL((k_terrain_fft_y<N1, N2, Q>), dim3(gx / Q, n_envs), dim3(FourStep<N1, N2, Q>::THREADS), 0, S_(stream),   \
+                     ctx->dcfg, (const float2*)work2, field, range_keys)
+  TERRAIN_DISPATCH(gy, LAUNCH_Y)
+#undef LAUNCH_Y
+  IPPM_LAUNCH_CHECK("terrain_fft_y");
+  return 0;
+}

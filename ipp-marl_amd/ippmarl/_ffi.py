@@ -73,6 +73,10 @@ PROTOTYPES = {
     "ippm_ig_candidates": [P, P, P, P, P, I32, P],
     "ippm_ig_select": [P, P, P, P, I32, P, P, I32, P],
     "ippm_f1_counts": [P, P, P, I32, C.c_float, P, I32, P],
+    "ippm_terrain_noise": [P, P, P, I32, P],
+    "ippm_terrain_spectrum": [P, P, P, P, I32, P],
+    "ippm_terrain_field": [P, P, P, P, P, P, P, I32, P],
+    "ippm_terrain_pack": [P, P, P, P, I32, P],
     "ippm_area_weights": [I32, I32, P, P, P],
     "ippm_host_philox": [P, P],
     "ippm_host_start_state": [I32, I64, I32, I32, I32, I32, P],

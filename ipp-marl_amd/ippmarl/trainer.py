@@ -21,9 +21,10 @@ from .vec_env import VecEnv, POLICY_ARGMAX, POLICY_SAMPLE
 
 class COMATrainer:
     def __init__(self, params: Dict, n_envs: int, device: str = "cuda:0", philox_seed: int = 3, waves_per_update: int = 1,
-                 quirks: str = "reference", rank: int = 0, world: int = 1, first_episode: int = 1):
+                 quirks: str = "reference", rank: int = 0, world: int = 1, first_episode: int = 1,
+                 terrain: str = "split"):
         self.params = params
-        self.env = VecEnv(params, n_envs, device=device, philox_seed=philox_seed)
+        self.env = VecEnv(params, n_envs, device=device, philox_seed=philox_seed, terrain=terrain)
         self.device = self.env.device
         self.rank, self.world = rank, world
         self.first_episode = first_episode

@@ -28,7 +28,7 @@ POLICY_EXPLICIT, POLICY_UNIFORM, POLICY_SAMPLE, POLICY_ARGMAX = 0, 1, 2, 3
 
 
 class VecEnv:
-    def __init__(self, params: Dict, n_envs: int, device: str = "cuda:0", philox_seed: int = 3):
+    def __init__(self, params: Dict, n_envs: int, device: str = "cuda:0", philox_seed: int = 3, terrain: str = "split"):
         if not torch.cuda.is_available():
             raise _ffi.IppmError("VecEnv needs an AMD GPU (HIP): there is no CPU path for the env step")
         self.params = params
@@ -61,6 +61,12 @@ class VecEnv:
         self.obs = None
         self.state = None
         self.t = 0
+        # "split": the half-plane truth the reference flies over (ground_truths.py:42-56); "random_field": the
+        # power-law random field it synthesises first (ground_truths.py:25-40), generated on the device (terrain.py)
+        if terrain not in ("split", "random_field"):
+            raise ValueError(f"unknown terrain {terrain!r}")
+        self.terrain = terrain
+        self._field = None
         # K5 (global fusion + reward) only reads what K3 of the previous step wrote and touches no array K4 / K6 /
         # the actor use, so it runs on a side stream concurrently with them (both are latency-bound kernels with
         # spare occupancy); steps() joins before K1.
@@ -105,20 +111,31 @@ class VecEnv:
 
     # ------------------------------------------------------------------------------------------------
     def reset(self, episodes, truth: Optional[torch.Tensor] = None, start_positions: Optional[torch.Tensor] = None,
-              flips: Optional[torch.Tensor] = None):
-        """Starts episode ``episodes[e]`` in env e (all envs at once) and performs the t=0 start-position sensing."""
+              flips: Optional[torch.Tensor] = None, terrain: Optional[str] = None):
+        """Starts episode ``episodes[e]`` in env e (all envs at once) and performs the t=0 start-position sensing.
+        ``truth`` (explicit [E,gx,gy] field) overrides ``terrain`` ("split" | "random_field", default: the env's)."""
         d = self.d
+        terrain = self.terrain if terrain is None else terrain
         ep = torch.as_tensor(episodes, dtype=torch.int64).reshape(self.E)
         if int(ep.max()) * d.env_seed * max(d.n_agents - 1, 1) >= 2 ** 32 or int(ep.min()) < 0:
             raise ValueError("episode * seed * agent_id must stay below 2**32 (NumPy legacy seeding limit)")
         self.episode.copy_(ep.to(self.device))
         self.ctx.call("ippm_reset_episode", self._p(self.episode), self._p(self.pos),
-                      None if truth is not None else self._p(self.truth), self._p(self.local), self._p(self.glob),
+                      self._p(self.truth) if truth is None and terrain == "split" else None, self._p(self.local),
+                      self._p(self.glob),
                       self._p(self.split_pct), self._p(self.comm_range), self._p(self.ws), self._p(self.sums), self.E,
                       self.stream)
         if truth is not None:
             packed = d.pack_truth(torch.as_tensor(truth).cpu().numpy().reshape(self.E, d.grid_x, d.grid_y))
             self.truth.copy_(torch.from_numpy(packed).to(self.device))
+        elif terrain == "random_field":
+            if self._field is None:
+                from .terrain import RandomFieldTerrain
+                self._field = RandomFieldTerrain(d, self.ctx, self.device,
+                                                 self.params["sensor"]["simulation"]["cluster_radius"])
+            self._field.generate(self.episode, self.truth, self.stream)
+        elif terrain != "split":
+            raise ValueError(f"unknown terrain {terrain!r}")
         if start_positions is not None:
             self.pos.copy_(torch.as_tensor(start_positions).to(self.device, torch.int32))
         self.t = 0

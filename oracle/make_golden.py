@@ -143,6 +143,31 @@ def gen_truth():
     save("truth", split_pct=np.array(sp, dtype=np.int32), **fields)
 
 
+def gen_terrain():
+    """The random field the reference synthesises for every episode and then overwrites with the half-plane split
+    (ground_truths.py:25-40).  It is a local of gaussian_random_field, so the inverse-FFT output is observed through
+    a spy on np.fft.ifft2 while the reference runs; normalise + threshold (its lines 32-40) are then applied here."""
+    out = {}
+    real = np.fft.ifft2
+    for e, (r, c) in [(3, (64, 64)), (7, (45, 45)), (11, (48, 80))]:
+        seen = []
+
+        def spy(a, *args, _seen=seen, **kw):
+            res = real(a, *args, **kw)
+            _seen.append(res)
+            return res
+
+        np.fft.ifft2 = spy
+        try:
+            ground_truths.gaussian_random_field(lambda k: k ** (-5.0), c, r, e)
+        finally:
+            np.fft.ifft2 = real
+        f = seen[-1].real
+        f = (f - np.min(f)) / (np.max(f) - np.min(f))
+        out[f"field_e{e}_{r}x{c}"] = np.packbits((f >= 0.5).astype(np.uint8), axis=None)
+    save("terrain", **out)
+
+
 # ------------------------------------------------------------------ 5: masks
 def gen_masks():
     out = {}
@@ -497,7 +522,7 @@ def gen_ig_baseline():
              comm_draws=np.array(rec.comm))
 
 
-GENERATORS = [gen_derived_and_footprints, gen_start_states, gen_truth, gen_masks, gen_comm, gen_bayes_measurement,
+GENERATORS = [gen_derived_and_footprints, gen_start_states, gen_truth, gen_terrain, gen_masks, gen_comm, gen_bayes_measurement,
               gen_entropy_reward, gen_episodes, gen_td_lambda, gen_coma_step, gen_ig_baseline]
 
 if __name__ == "__main__":

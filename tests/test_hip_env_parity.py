@@ -77,7 +77,7 @@ def test_golden_episode_replay(golden, tag):
     assert_posteriors(env.posterior_global()[0].cpu().numpy(), fx["final_global"], strict=False, msg="final global")
 
 
-def _oracle_philox_episode(params, episode, seed, learned_probs=None):
+def _oracle_philox_episode(params, episode, seed, learned_probs=None, truth=None):
     d = O.Derived(params)
 
     def correctness(i, s, shape):
@@ -90,7 +90,7 @@ def _oracle_philox_episode(params, episode, seed, learned_probs=None):
 
     ep = O.OracleEpisode(params, episode, correctness, choose,
                          comm_draw=lambda i, j, t: O.philox_comm_draw(seed, episode, i, j, t), build_features=True,
-                         exact=True)
+                         exact=True, truth=truth)
     return ep, ep.run()
 
 
@@ -141,6 +141,122 @@ def test_production_randomness_matches_oracle(name, over, n_envs):
     final = env.posterior_local().cpu().numpy()
     for e, (ep, log) in enumerate(oracles):
         assert_posteriors(final[e], np.array([a["local_map"] for a in ep.agents]), strict=True, msg=f"final local e={e}")
+
+
+def _field_checks(got, want, tag):
+    assert (want != got).mean() < 2e-3, (tag, (want != got).mean())   # float32 transform near the threshold
+    assert 0.02 < got.mean() < 0.98, tag
+    assert (got[1:, :] == got[:-1, :]).mean() > 0.95, tag              # k^-5 spectrum: large blobs
+
+
+def test_random_field_terrain_fft_path():
+    """Grids that are not powers of two (default 493 x 493, odd: one zero amplitude row/column): device noise + rocFFT +
+    threshold kernel against a float64 host evaluation of the same noise."""
+    from ippmarl import _ffi
+    from ippmarl.terrain import amplitude_table
+    params = make_params("default")
+    E = 4
+    env = _env(params, E, terrain="random_field")
+    eps = np.array([3, 1000003, 17, 4])
+    env.reset(eps)
+    assert not env_terrain(env).native
+    got = env.truth_map.numpy()
+    gx, gy = env.d.grid_x, env.d.grid_y
+    noise = torch.empty(E, gx, gy, dtype=torch.float32, device=env.device)
+    env.ctx.call("ippm_terrain_noise", _ffi.ptr(env.episode), _ffi.ptr(noise), E, env.stream)
+    z = noise.cpu().numpy().astype(np.float64)
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1.0) < 0.02
+    # Box-Muller over Philox(cell group; episode; terrain stream word), first group of env 1
+    w = _ffi.host_philox(0, int(eps[1]) & 0xFFFFFFFF, 3 << 24, int(eps[1]) >> 32, 3, 0)
+    u1, u2 = ((w[0] >> 8) + 1.0) / 2 ** 24, (w[1] >> 8) / 2 ** 24
+    r = np.sqrt(-2.0 * np.log(u1))
+    np.testing.assert_allclose(z[1].reshape(-1)[:2], [r * np.cos(2 * np.pi * u2), r * np.sin(2 * np.pi * u2)], rtol=2e-5, atol=2e-6)
+    amp = amplitude_table(gx, gy, params["sensor"]["simulation"]["cluster_radius"])
+    for e in range(E):
+        f = np.fft.ifft2(np.fft.fft2(z[e]) * amp).real
+        f = (f - f.min()) / (f.max() - f.min())
+        _field_checks(got[e], (f >= 0.5).astype(np.uint8), e)
+
+
+def env_terrain(env):
+    return env._field
+
+
+@pytest.mark.parametrize("name", ["small", "c2", "c5"])   # 128, 256, 1024 cells a side
+def test_random_field_terrain_native_path(name):
+    """Power-of-two grids: spectrum drawn in the library + two-pass LDS inverse transform + threshold."""
+    from ippmarl import _ffi
+    from ippmarl.terrain import amplitude_table
+    params = make_params(name, experiment__missions__n_agents=2)
+    E = 3
+    env = _env(params, E, terrain="random_field")
+    eps = np.array([3, 1000003, 17])
+    env.reset(eps)
+    assert env_terrain(env).native
+    got = env.truth_map.numpy()
+    gx, gy = env.d.grid_x, env.d.grid_y
+    hy = gy // 2 + 1
+    amp = amplitude_table(gx, gy, params["sensor"]["simulation"]["cluster_radius"])[:, :hy]
+    amp_dev = torch.from_numpy(np.ascontiguousarray(amp).astype(np.float32)).to(env.device)
+    spec = torch.empty(E, gx, hy, 2, dtype=torch.float32, device=env.device)
+    env.ctx.call("ippm_terrain_spectrum", _ffi.ptr(env.episode), _ffi.ptr(amp_dev), _ffi.ptr(spec), E, env.stream)
+    S = spec.cpu().numpy().astype(np.float64)
+    S = S[..., 0] + 1j * S[..., 1]
+    # a generic bin against the host Philox + Box-Muller; stream word = (stage 1, domain 3)
+    kx, ky = 5, 9
+    w = _ffi.host_philox(kx * hy + ky, int(eps[1]) & 0xFFFFFFFF, (1 << 8) | (3 << 24), int(eps[1]) >> 32, 3, 0)
+    u1, u2 = ((w[0] >> 8) + 1.0) / 2 ** 24, (w[1] >> 8) / 2 ** 24
+    r = np.sqrt(-2.0 * np.log(u1)) * amp[kx, ky]
+    np.testing.assert_allclose([S[1, kx, ky].real, S[1, kx, ky].imag], [r * np.cos(2 * np.pi * u2), r * np.sin(2 * np.pi * u2)],
+                               rtol=1e-4, atol=1e-7)
+    # Hermitian structure of the self-mirrored columns; white-noise statistics of the generic bins
+    for col in (0, gy // 2):
+        assert np.array_equal(S[:, 1:gx // 2, col], np.conj(S[:, :gx // 2:-1, col]))
+        assert np.all(S[:, [0, gx // 2], col].imag == 0)
+    white = (S[:, 1:, 1:gy // 2] / amp[None, 1:, 1:gy // 2]).reshape(-1)
+    assert abs(white.real.std() - 1) < 0.02 and abs(white.imag.std() - 1) < 0.02 and abs(white.mean()) < 0.02
+    # inverse transform of an explicit spectrum against NumPy
+    work = torch.empty(E, hy, gx, 2, dtype=torch.float32, device=env.device)
+    field = torch.empty(E, gx, gy, dtype=torch.float32, device=env.device)
+    keys = torch.empty(E, 2, dtype=torch.int32, device=env.device)
+    env.ctx.call("ippm_terrain_field", None, None, _ffi.ptr(spec), _ffi.ptr(work), _ffi.ptr(field), _ffi.ptr(keys), E, env.stream)
+    f_dev = field.cpu().numpy().astype(np.float64)
+    for e in range(E):
+        f = np.fft.irfft2(S[e], s=(gx, gy)) * (gx * gy)
+        assert np.abs(f_dev[e] - f).max() < 2e-5 * np.abs(f).max(), (e, np.abs(f_dev[e] - f).max(), np.abs(f).max())
+        fn = (f - f.min()) / (f.max() - f.min())
+        _field_checks(got[e], (fn >= 0.5).astype(np.uint8), e)
+    # the fused path (spectrum never stored) is the same arithmetic
+    for rk in (None, keys):   # min/max reduced by the pack kernel, or taken from pass Y's atomics
+        packed = torch.zeros_like(env.truth)
+        env.ctx.call("ippm_terrain_pack", _ffi.ptr(field), _ffi.ptr(rk), _ffi.ptr(packed), E, env.stream)
+        assert torch.equal(packed, env.truth)
+    # an episode's terrain does not depend on the batch it is generated in
+    solo = _env(params, 1, terrain="random_field")
+    solo.reset([int(eps[1])])
+    assert np.array_equal(solo.truth_map.numpy()[0], got[1])
+    assert not np.array_equal(got[0], got[2])
+
+
+def test_episode_on_random_field_terrain_matches_oracle():
+    """Every step against the oracle flying over the same generated field (truth handed to both sides)."""
+    from ippmarl.vec_env import POLICY_UNIFORM
+    params = make_params("small")
+    seed = 77
+    env = _env(params, 3, philox_seed=seed, terrain="random_field")
+    eps = [5, 6, 7]
+    env.reset(eps)
+    truth = env.truth_map.numpy().astype(np.float64)
+    oracles = [_oracle_philox_episode(params, ep, seed, truth=truth[e]) for e, ep in enumerate(eps)]
+    for t in range(env.d.budget + 1):
+        env.build_observations(t, features=False)
+        reward, done, _ = env.steps(t, policy=POLICY_UNIFORM, features=False)
+        glob = env.posterior_global().cpu().numpy()
+        for e, (ep, log) in enumerate(oracles):
+            rec = log[t]
+            assert np.array_equal(env.pos[e].cpu().numpy(), rec["next_positions"]), (t, e)
+            assert_posteriors(glob[e], rec["global_map"], strict=True, msg=f"global t={t} e={e}")
+            np.testing.assert_allclose(reward[e].cpu().numpy(), [rec["relative_reward"], rec["absolute_reward"]], rtol=RTOL, atol=1e-6)
 
 
 def test_saturation_and_deferred_clamp():

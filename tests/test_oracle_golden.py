@@ -57,6 +57,18 @@ def test_truth(golden):
         assert np.array_equal(O.truth_from_split(r, c, s, pc).astype(np.uint8), fx[key]), key
 
 
+def test_random_field_terrain(golden):
+    """The thresholded power-law field of ground_truths.py:25-40 (odd sizes leave one amplitude row/column at 0)."""
+    fx = golden("terrain")
+    for key in fx:
+        e = int(key.split("_")[1][1:])
+        r, c = (int(v) for v in key.split("_")[2].split("x"))
+        want = np.unpackbits(fx[key])[: r * c].reshape(r, c)
+        got = O.grf_field(r, c, e, 5.0).astype(np.uint8)
+        assert np.array_equal(got, want), key
+        assert 0.05 < got.mean() < 0.95
+
+
 @pytest.mark.parametrize("A", [4, 6, 9, 27])
 def test_action_masks_and_moves(golden, A):
     fx = golden("masks")
