@@ -17,6 +17,7 @@ from .agent.agent import Agent
 from .agent.state_space import AgentStateSpace
 from .batch_memory import BatchMemory
 from .coma_wrapper import COMAWrapper, ReplayHooks
+from ._mission import MissionMetrics
 from .mapping.grid_maps import GridMap
 from .mapping.mappings import Mapping
 from .sensors import Sensor
@@ -24,7 +25,7 @@ from .sensors.cameras import Camera
 from .sensors.models.sensor_models import AltitudeSensorModel
 
 
-class IG_baseline:
+class IG_baseline(MissionMetrics):
     def __init__(self, params: Dict, writer, num_episode):
         self.params = params
         self.num_episode = num_episode
@@ -45,30 +46,6 @@ class IG_baseline:
         self.replay = None        # optional ReplayHooks(correctness=...) for parity tests
         self.gains_log = []
         self.f1_bracket = []      # per evaluation: F1 with the exactly-cancelled cells counted as free / as occupied
-
-    # ---- metrics of the fused global map that lives on the device --------------------------------------
-    def _f1_counts(self, threshold: float = 0.0):
-        env = self.mapping.engine.env
-        counts = torch.zeros(1, 3, dtype=torch.int64, device=env.device)
-        env.ctx.call("ippm_f1_counts", env._p(env.glob), env._p(env.truth), 1, float(threshold), _ffi.ptr(counts), 1, env.stream)
-        return tuple(int(v) for v in counts[0].cpu())
-
-    @staticmethod
-    def _f1_of(tp, fp, fn) -> float:
-        return 2 * tp / (2 * tp + fp + fn) if (2 * tp + fp + fn) > 0 else 0.0
-
-    def _metrics(self):
-        """(mean entropy over the target cells, F1 of the target class at p > 0.5) of the fused global map."""
-        env = self.mapping.engine.env
-        ent = torch.zeros(1, dtype=torch.float64, device=env.device)
-        env.ctx.call("ippm_weighted_entropy", env._p(env.glob), env._p(env.truth), 1, _ffi.ptr(ent), 1, env.stream)
-        target = int(env.truth_map[0].sum())
-        # Cells whose observations cancel exactly sit at p = 0.5 +- rounding noise in the reference, which classifies them
-        # by that noise.  Keep the attainable range: every such cell assigned to the wrong / to the right class.
-        tp_s, fp_s, fn_s = self._f1_counts(1e-5)
-        tp_l, fp_l, fn_l = self._f1_counts(-1e-5)
-        self.f1_bracket.append((self._f1_of(tp_s, fp_l, fn_s), self._f1_of(tp_l, fp_s, fn_l)))
-        return float(ent[0]) / target, self._f1_of(*self._f1_counts(0.0))
 
     def get_individual_ig(self, position, action_mask, map_state=None, agent_id: int = 0):
         """Expected information gain per action for the agent in engine slot ``agent_id`` (its device-resident local map;
@@ -136,8 +113,3 @@ class IG_baseline:
             entropies.append(entropy)
             f1s.append(f1)
         return sum(relative_rewards), sum(absolute_rewards), agent_altitudes, entropies, f1s
-
-    def _fuse_global(self):
-        env = self.mapping.engine.env
-        env.ctx.call("ippm_fuse_global_reward", env._p(env.glob), env._p(env.code), env._p(env.rect), env._p(env.pos), env._p(env.ws),
-                     env._p(env.sums), env._p(env.reward), 1, env.stream)

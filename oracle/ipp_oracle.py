@@ -967,3 +967,72 @@ class OracleIGBaseline:
         self.agents, self.global_map = agents, current_global
         return dict(relative_return=sum(rel_rewards), absolute_return=sum(abs_rewards), altitudes=altitudes, entropies=entropies,
                     f1=f1s, gains=gains_log, actions=actions_log, positions=positions_log)
+
+
+# --------------------------------------------------------------------------------------
+# comparison / deployment scripts (random_baseline.py, lawn_mower.py, coma_test.py): metric curves
+# --------------------------------------------------------------------------------------
+
+
+def lawnmower_paths(altitude: int) -> List[np.ndarray]:
+    """positions1..8 of lawn_mower.py:46-203: two row-wise and two column-wise 15-cell sweeps, each listed twice."""
+    run = list(range(10, 45, 5))
+
+    def lane(c, along_x):
+        cells = [(v, c) for v in run] + [(40, c + 5)] + [(v, c + 10) for v in run[::-1]]
+        return np.array([[a, b, altitude] if along_x else [b, a, altitude] for a, b in cells])
+
+    four = [lane(10, True), lane(30, True), lane(10, False), lane(30, False)]
+    return four + [p.copy() for p in four]
+
+
+def shared_map_curves(d: Derived, truth: np.ndarray, visits, correctness: Callable):
+    """random_baseline.py:40-124 / lawn_mower.py:231-313: ONE map, updated in place by every platform's sensing
+    (Mapping.update_grid_map on the shared map), metrics after each step.  ``visits[s]`` = positions sensed in step s (in
+    order); ``correctness(k)`` = draws of the k-th sensing overall.  -> (entropies, f1s), initial prior entry first."""
+    m = init_prior_map(d)
+    ent, f1 = [target_entropy(d, m.copy(), truth)], [f1_target(m, truth)]
+    k = 0
+    for step in visits:
+        for pos in step:
+            _, fc = project_field_of_view(d, pos)
+            corr = np.asarray(correctness(k)).reshape(fc[3] - fc[2], fc[1] - fc[0])
+            m = update_grid_map(d, truth, pos, m.copy(), corr)[0]
+            k += 1
+        ent.append(target_entropy(d, m.copy(), truth))
+        f1.append(f1_target(m, truth))
+    return ent, f1
+
+
+def deployment_curves(params: Dict, episode: int, actions: Callable, correctness: Callable, comm_draw: Optional[Callable] = None):
+    """coma_test.py:98-196 with the greedy choices given (``actions(t, i)``): the episode runs as in training (publish,
+    receive, fuse local maps, move, sense) but the global map fuses the start measurements at t = 0 and then, every
+    step, the measurements taken right after the move (no one-step lag), and both metrics are logged per step.
+    The measurements go in as the script passes them: through the dict branch of fuse_map at t = 0 (float32 cast) and
+    as a bare list afterwards (no cast: a measurement published from an already-fused, hence promoted, local map stays
+    float64 under NumPy 2, and so do that step's updates -- this decides the class of exactly-cancelled cells).
+    ``correctness(s, i)``: draws of agent i's sensing stage s.  -> (entropies, f1s, positions[T+2? no: T+1 stages])"""
+    seen = {}
+    ep = OracleEpisode(params, episode, lambda i, s, shape: np.asarray(correctness(s, i)).reshape(shape),
+                       lambda i, t, m, o: actions(t, i), comm_draw=comm_draw, build_features=False)
+    real_sense = ep._sense
+
+    def sense(i, s):
+        real_sense(i, s)
+        seen[(i, s)] = ep.agents[i]["map2communicate"]
+
+    ep._sense = sense
+    d, n = ep.d, ep.d.n_agents
+    g = init_prior_map(d)
+    ent, f1 = [target_entropy(d, g.copy(), ep.truth)], [f1_target(g, ep.truth)]
+    stages = []
+    for t in range(d.budget + 1):
+        rec = ep.step(t)
+        if t == 0:
+            stages.append(rec["positions"])
+            g = fuse_map(d, g, {i: dict(map2communicate=seen[(i, 0)]) for i in range(n)}, None, "global")
+        stages.append(rec["next_positions"])
+        g = fuse_map(d, g, [seen[(i, t + 1)] for i in range(n)], None, "global")
+        ent.append(target_entropy(d, g.copy(), ep.truth))
+        f1.append(f1_target(g, ep.truth))
+    return ent, f1, np.array(stages)

@@ -522,8 +522,62 @@ def gen_ig_baseline():
              comm_draws=np.array(rec.comm))
 
 
+# ------------------------------------------------------------------ deployment / comparison scripts
+def gen_missions():
+    """random_baseline.py, lawn_mower.py and coma_test.py run as they are, every random draw recorded."""
+    import marl_framework.random_baseline as ref_rb
+    import marl_framework.lawn_mower as ref_lm
+    import marl_framework.coma_test as ref_ct
+    from marl_framework.actor.network import ActorNetwork
+
+    def pack(rec):
+        return dict(corr_packed=np.concatenate([np.packbits(c) for c in rec.correctness]),
+                    corr_lens=np.array([len(c) for c in rec.correctness], dtype=np.int32))
+
+    p = make_params("small", experiment__missions__n_agents=3)
+    torch.manual_seed(5)
+    with Recorder() as rec:
+        ret, entropies, f1 = ref_rb.RandomBaseline(p, None, 6).execute()
+    save("random_small3_e6", episode=np.array(6), ret=np.array(ret), entropies=np.array(entropies), f1=np.array(f1),
+         actions=np.array(rec.actions, dtype=np.int32), **pack(rec))
+
+    p = make_params("small", experiment__missions__n_agents=8, experiment__baselines__lawnmower__altitude=10)  # the script needs 8 slots
+    torch.manual_seed(6)
+    with Recorder() as rec:
+        ret, entropies, f1 = ref_lm.LawnMower(p, None, 2).execute()
+    save("lawnmower_small_e2", episode=np.array(2), ret=np.array(ret), entropies=np.array(entropies), f1=np.array(f1), **pack(rec))
+
+    p = make_params("small", experiment__missions__n_agents=3)
+    torch.manual_seed(31)
+    net = ActorNetwork(p)          # the script loads a whole-module pickle from a fixed path: hand it this one instead
+    real_load = torch.load
+    torch.load = lambda *a, **k: net
+    chosen = []
+    real_argmax = torch.argmax
+
+    def argmax_spy(x, *a, **k):
+        r = real_argmax(x, *a, **k)
+        if x.numel() == p["experiment"]["constraints"]["num_actions"]:
+            chosen.append(int(r))
+        return r
+
+    torch.argmax = argmax_spy
+    try:
+        torch.manual_seed(32)
+        with Recorder() as rec:
+            test = ref_ct.COMATest(p, None, 9)
+            ret, positions, altitudes, entropies, f1, rel = test.execute("random", 9)
+    finally:
+        torch.load = real_load
+        torch.argmax = real_argmax
+    save("comatest_small3_e9", episode=np.array(9), net_seed=np.array(31), ret=np.array(ret), relative_return=np.array(rel),
+         positions=np.array(positions, dtype=np.int32), altitudes=np.array(altitudes, dtype=np.int32),
+         entropies=np.array(entropies), f1=np.array(f1), actions=np.array(chosen, dtype=np.int32),
+         comm_draws=np.array(rec.comm), **pack(rec))
+
+
 GENERATORS = [gen_derived_and_footprints, gen_start_states, gen_truth, gen_terrain, gen_masks, gen_comm, gen_bayes_measurement,
-              gen_entropy_reward, gen_episodes, gen_td_lambda, gen_coma_step, gen_ig_baseline]
+              gen_entropy_reward, gen_episodes, gen_td_lambda, gen_coma_step, gen_ig_baseline, gen_missions]
 
 if __name__ == "__main__":
     check_schema()

@@ -202,6 +202,79 @@ def test_ig_baseline_replays_reference_run(golden, tag, monkeypatch):
     np.testing.assert_allclose([rel, ab], [fx["relative_return"], fx["absolute_return"]], rtol=1e-9)
 
 
+def _check_curves(obj, entropies, f1s, fx):
+    np.testing.assert_allclose(entropies, fx["entropies"], rtol=RTOL)
+    assert f1s[0] == fx["f1"][0] == 0.0
+    assert len(obj.f1_bracket) == len(fx["f1"])
+    for (lo, hi), want in zip(obj.f1_bracket, fx["f1"]):   # exactly-cancelled cells: see the IG test above
+        assert min(lo, hi) - 1e-9 <= want <= max(lo, hi) + 1e-9, (lo, want, hi)
+
+
+def test_random_baseline_replays_reference_run(golden):
+    """random_baseline.py: one shared map updated by every platform, uniform actions over the boundary mask."""
+    from ippmarl.random_baseline import RandomBaseline
+    from ippmarl.coma_wrapper import ReplayHooks
+    fx = golden("random_small3_e6")
+    params = make_params("small", experiment__missions__n_agents=3)
+    n, corr = 3, unpack_correctness(fx)
+    rb = RandomBaseline(params, None, int(fx["episode"]))
+    rb.replay = ReplayHooks(correctness=lambda i, t: corr[t * n + i], action=lambda i, t: int(fx["actions"][(t - 1) * n + i]))
+    ret, entropies, f1s = rb.execute()
+    assert ret == int(fx["ret"]) == 0
+    _check_curves(rb, entropies, f1s, fx)
+    # without hooks: device noise, host multinomial; the curve must still be a mapping run (entropy falls, F1 rises)
+    _, ent, f1 = RandomBaseline(params, None, 7).execute()
+    assert len(ent) == params["experiment"]["constraints"]["budget"] + 2 and ent[0] == 1.0 and ent[-1] < 0.95 and f1[-1] > 0.3
+
+
+def test_lawn_mower_replays_reference_run(golden):
+    """lawn_mower.py: eight fixed sweeps at the configured altitude update one shared map."""
+    from ippmarl.lawn_mower import LawnMower, coverage_paths
+    from ippmarl.coma_wrapper import ReplayHooks
+    fx = golden("lawnmower_small_e2")
+    params = make_params("small", experiment__missions__n_agents=8, experiment__baselines__lawnmower__altitude=10)
+    corr = unpack_correctness(fx)
+    assert len(corr) == 8 * 15 and all(p.shape == (15, 3) for p in coverage_paths(10))
+    lm = LawnMower(params, None, int(fx["episode"]))
+    lm.replay = ReplayHooks(correctness=lambda k, idx: corr[idx * 8 + k])
+    ret, entropies, f1s = lm.execute()
+    assert ret == 0
+    _check_curves(lm, entropies, f1s, fx)
+    # the script does not depend on n_agents (the reference needs 8 memory slots; the shared map needs one)
+    _, ent2, _ = LawnMower(make_params("small", experiment__baselines__lawnmower__altitude=10), None, 2).execute()
+    assert len(ent2) == 16 and ent2[-1] < 0.8
+
+
+def test_coma_test_replays_reference_run(golden):
+    """coma_test.py: greedy deployment of a (here: seeded, untrained) actor; positions, altitudes, entropy and F1 per step."""
+    from ippmarl.coma_test import COMATest
+    from ippmarl.coma_wrapper import ReplayHooks
+    from ippmarl.networks import ActorNetwork
+    fx = golden("comatest_small3_e9")
+    params = make_params("small", experiment__missions__n_agents=3)
+    n, corr = 3, unpack_correctness(fx)
+    torch.manual_seed(int(fx["net_seed"]))
+    net = ActorNetwork(params)
+
+    def run(force_actions):
+        ct = COMATest(params, None, int(fx["episode"]))
+        ct.net = net
+        ct.replay = ReplayHooks(correctness=lambda i, stage: corr[stage * n + i],
+                                action=(lambda i, t: int(fx["actions"][t * n + i])) if force_actions else None)
+        return ct, ct.execute("random", int(fx["episode"]))
+
+    ct, (ret, positions, altitudes, entropies, f1s, rel) = run(True)
+    assert np.array_equal(np.array(positions), fx["positions"])
+    assert np.array_equal(np.array(altitudes), fx["altitudes"])
+    np.testing.assert_allclose([ret, rel], [fx["ret"], fx["relative_return"]], rtol=1e-12)
+    _check_curves(ct, entropies, f1s, fx)
+    # the GPU forward + argmax picks the recorded actions by itself (float32 conv on another device: allow a rare near-tie)
+    assert np.mean(np.array(ct.greedy_actions) == fx["actions"]) >= 0.9
+    ct2, out2 = run(False)
+    if ct2.greedy_actions == list(fx["actions"]):
+        np.testing.assert_allclose(out2[3], fx["entropies"], rtol=RTOL)
+
+
 def test_batched_ig_policy_matches_oracle():
     """VecEnv.ig_actions (K9 + K10 for all envs at once) against the oracle's literal restatement."""
     from ippmarl.vec_env import VecEnv, POLICY_EXPLICIT

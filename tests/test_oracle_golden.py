@@ -254,3 +254,53 @@ def test_ig_baseline_replay(golden, tag):
         assert abs(out["entropies"][0] - 1.0) < 1e-12 and out["f1"][0] == 0.0
         assert 0.55 < out["entropies"][-1] < 0.70 and 0.65 < out["f1"][-1] < 0.80   # sensor-noise dependent (survey probe: 0.618 / 0.729)
         assert [a[0] for a in out["altitudes"]][:3] == [15, 10, 10]                 # descends after the first step
+
+
+def _unpack(fx):
+    from conftest import unpack_correctness
+    return unpack_correctness(fx)
+
+
+def test_random_baseline_curves(golden):
+    """random_baseline.py rerun by the oracle from the recorded draws (start cells from the legacy seed rule)."""
+    fx = golden("random_small3_e6")
+    params = make_params("small", experiment__missions__n_agents=3)
+    d = O.Derived(params)
+    n, corr, ep = 3, _unpack(fx), int(fx["episode"])
+    truth = O.make_truth(d, ep)
+    pos = [O.start_state(d, i, ep) for i in range(n)]
+    visits = [[p.copy() for p in pos]]
+    for t in range(1, d.budget + 1):
+        for i in range(n):
+            a = int(fx["actions"][(t - 1) * n + i])
+            assert O.action_mask(d, pos[i])[a] == 1
+            pos[i] = O.action_to_position(d, pos[i], a)
+        visits.append([p.copy() for p in pos])
+    ent, f1 = O.shared_map_curves(d, truth, visits, lambda k: corr[k])
+    np.testing.assert_allclose(ent, fx["entropies"], rtol=1e-6)
+    np.testing.assert_allclose(f1, fx["f1"], rtol=1e-9)   # incl. the exactly-cancelled cells (same float32 rounding noise)
+
+
+def test_lawn_mower_curves(golden):
+    fx = golden("lawnmower_small_e2")
+    params = make_params("small", experiment__missions__n_agents=8, experiment__baselines__lawnmower__altitude=10)
+    d = O.Derived(params)
+    corr = _unpack(fx)
+    paths = O.lawnmower_paths(10)
+    visits = [[p[idx] for p in paths] for idx in range(15)]
+    ent, f1 = O.shared_map_curves(d, O.make_truth(d, int(fx["episode"])), visits, lambda k: corr[k])
+    np.testing.assert_allclose(ent, fx["entropies"], rtol=1e-6)
+    np.testing.assert_allclose(f1, fx["f1"], rtol=1e-9)
+
+
+def test_coma_test_curves(golden):
+    fx = golden("comatest_small3_e9")
+    params = make_params("small", experiment__missions__n_agents=3)
+    d = O.Derived(params)
+    n, corr = 3, _unpack(fx)
+    ent, f1, stages = O.deployment_curves(params, int(fx["episode"]), lambda t, i: int(fx["actions"][t * n + i]),
+                                          lambda s, i: corr[s * n + i])
+    assert np.array_equal(stages, fx["positions"])
+    np.testing.assert_allclose(ent, fx["entropies"], rtol=1e-6)
+    np.testing.assert_allclose(f1, fx["f1"], rtol=1e-9)
+    assert np.isclose(float(fx["ret"]), -0.17 * 15) and np.isclose(float(fx["relative_return"]), -0.5 * 15)
