@@ -1,7 +1,8 @@
 """COMA learners on tensors: critic TD regression (critic/learner.py:58-198) and actor policy gradient with the
 counterfactual baseline (actor/learner.py:36-168).  The baseline/advantage arithmetic runs in the HIP kernel K7
 (ippm_coma_advantage); autograd, Adam and the convnets are PyTorch.  Metric-only work of the reference (KL via an
-extra forward pass, gradient-norm dumps, explained variance) is not reproduced."""
+extra forward pass, gradient-norm dumps, explained variance) is computed by ippmarl.metrics from the per-minibatch
+records the learners keep in ``.last`` when ``collect`` is switched on."""
 from __future__ import annotations
 
 import copy
@@ -26,6 +27,8 @@ class CriticLearner:
         self.tau = net["critic"]["tau"]
         self.optimizer = torch.optim.Adam(self.critic.parameters(), lr=self.lr)
         self.optimizer.zero_grad()
+        self.collect = False   # keep the tensors ippmarl.metrics.critic_metrics needs in self.last
+        self.last = None
 
     def update_target_network(self, num_train_step: int, data_pass: int):
         """Hard copy every copy_rate train steps on data pass 0, or Polyak (critic/learner.py:192-198)."""
@@ -49,7 +52,10 @@ class CriticLearner:
             grad_hook(self.critic)
         self.optimizer.step()
         with torch.no_grad():
-            q_new, _ = self.critic(states)
+            q_new, logp = self.critic(states)
+        if self.collect:
+            self.last = dict(loss=loss.detach(), q_chosen=q_chosen.detach(), td=td_targets.detach(), q_new=q_new,
+                             logp_chosen=logp.view(-1, q_new.shape[-1]).gather(1, actions.long().view(-1, 1)))
         return loss.detach(), q_new
 
 
@@ -63,6 +69,8 @@ class ActorLearner:
         self.lr = params["networks"]["actor"]["learning_rate"]
         self.optimizer = torch.optim.Adam(self.actor.parameters(), lr=self.lr)
         self.optimizer.zero_grad()
+        self.collect = False
+        self.last = None
 
     def advantage(self, probs: torch.Tensor, q_values: torch.Tensor, masks: torch.Tensor, actions: torch.Tensor):
         """A = Q(a) - sum_a' pi~(a') Q(a') mask(a') with pi~ the mask-renormalised, floored policy
@@ -84,7 +92,7 @@ class ActorLearner:
              grad_hook=None):
         """One minibatch (actor/learner.py:52-101).  The reference's loss broadcasts [B,1]*[B,1]*[B,A] before the
         mean, i.e. every sample is weighted by (#valid actions)/A."""
-        probs, _ = self.actor(observations, eps)
+        probs, hidden = self.actor(observations, eps)
         log_probs = torch.log(probs)
         adv = self.advantage(probs, q_values, masks, actions)
         log_chosen = log_probs.gather(1, actions.long().view(-1, 1)).squeeze(1)
@@ -95,4 +103,7 @@ class ActorLearner:
         if grad_hook is not None:
             grad_hook(self.actor)
         self.optimizer.step()
+        if self.collect:
+            self.last = dict(loss=loss.detach(), adv=adv.detach(), log_probs=log_probs.detach(), log_chosen=log_chosen.detach(),
+                             hidden0=hidden[0].detach())
         return loss.detach(), adv

@@ -55,6 +55,9 @@ class COMATrainer:
         self.filled = 0        # waves currently in the buffer
         self.train_step = 0
         self.eps = epsilon_schedule(params, 0)
+        self.keep_rollout_log = False
+        self.last_rollout = None
+        self.last_diagnostics = None
 
     # ------------------------------------------------------------------------------------------------
     def rollout(self, mode: str = "train") -> Dict[str, float]:
@@ -68,6 +71,7 @@ class COMATrainer:
         ret = torch.zeros(self.E, device=self.device)
         abs_ret = torch.zeros(self.E, device=self.device)
         policy = POLICY_ARGMAX if mode == "eval" else POLICY_SAMPLE
+        step_rewards, step_actions, step_altitudes = [], [], []
         for t in range(self.T):
             obs = env.build_observations(t)
             with torch.no_grad():
@@ -81,6 +85,14 @@ class COMATrainer:
                 self.buf_reward[w, t].copy_(reward[:, 0])
             ret += reward[:, 0]
             abs_ret += reward[:, 1]
+            if self.keep_rollout_log:
+                step_rewards.append(reward[:, 0].clone())
+                step_actions.append(env.action.clone())
+                step_altitudes.append(env.pos[:, :, 2].clone())
+        if self.keep_rollout_log:   # per-episode figures for the mission log (coma_mission.py:78-82)
+            self.last_rollout = dict(episode_returns=ret.clone(), absolute_returns=abs_ret.clone(),
+                                     rewards=torch.stack(step_rewards, 1), actions=torch.stack(step_actions, 1),
+                                     altitudes=torch.stack(step_altitudes, 1))
         self.wave += 1
         if mode == "train":
             self.filled += 1
@@ -115,12 +127,14 @@ class COMATrainer:
         to_buf = lambda x: x.view(E, N, W, T).permute(2, 3, 0, 1).reshape(-1)  # noqa: E731
         return to_buf(td), to_buf(dr)
 
-    def update(self) -> Dict[str, float]:
-        """One COMA round on everything in the buffer, then clear it (coma_mission.py:89-116)."""
+    def update(self, diagnostics: bool = False) -> Dict[str, float]:
+        """One COMA round on everything in the buffer, then clear it (coma_mission.py:89-116).  ``diagnostics``: also
+        compute the reference's per-training-step TensorBoard figures from data pass 0 (ippmarl.metrics) into
+        ``self.last_diagnostics`` (costs one extra actor forward per minibatch)."""
         W, T, E, N = self.filled, self.T, self.E, self.N
         assert W > 0, "update() needs at least one rollout wave"
         n = W * T * E * N
-        td, _ = self.td_targets()
+        td, dr = self.td_targets()
         obs = self.buf_obs[:W].reshape(n, 11, 11, 7)
         states = self.buf_state[:W].reshape(n, 11, 11, 12)
         actions = self.buf_action[:W].reshape(n)
@@ -130,14 +144,27 @@ class COMATrainer:
         for data_pass in range(self.data_passes):
             perm = torch.randperm(n, device=self.device)
             self.critic_learner.update_target_network(self.train_step, data_pass)
-            q_new = []
+            collect = diagnostics and data_pass == 0
+            self.critic_learner.collect = self.actor_learner.collect = collect
+            q_new, crit_rec, act_rec = [], [], []
             for b in range(self.batch_number):  # critic first over all minibatches (critic/learner.py:58-105)
                 idx = perm[b * bs:(b + 1) * bs]
                 closs, q = self.critic_learner.step(states[idx], actions[idx], td[idx], grad_hook=self.reducer)
                 q_new.append(q)
+                if collect:
+                    crit_rec.append(dict(self.critic_learner.last, discounted=dr[idx]))
             for b in range(self.batch_number):  # then the actor with the post-step Q values (actor/learner.py:36-101)
                 idx = perm[b * bs:(b + 1) * bs]
                 aloss, _ = self.actor_learner.step(obs[idx], actions[idx], masks[idx], q_new[b], self.eps, grad_hook=self.reducer)
+                if collect:
+                    act_rec.append(self.actor_learner.last)
+            if collect:
+                from . import metrics
+                with torch.no_grad():
+                    after = [self.actor(obs[perm[b * bs:(b + 1) * bs]], self.eps)[0] for b in range(self.batch_number)]
+                self.last_diagnostics = dict(metrics.critic_metrics(crit_rec, self.critic))
+                self.last_diagnostics.update(metrics.actor_metrics(act_rec, self.actor, after))
+                self.critic_learner.collect = self.actor_learner.collect = False
             if data_pass == 0:
                 self.train_step += 1
         self.filled = 0

@@ -488,6 +488,8 @@ def gen_coma_step():
          q0=q0.numpy(), pi0=pi0.numpy(), q_new=q_values[0].numpy(), critic_loss=np.array(float(cm[0])),
          actor_loss=np.array(float(am[0])), adv_mean=np.array(float(am[1])), adv_std=np.array(float(am[2])), pi1=pi1.numpy(),
          critic_fc3_b=wrapper.critic_network.fc3.bias.detach().numpy(), actor_fc3_b=wrapper.actor_network.fc3.bias.detach().numpy(),
+         critic_metrics=np.array([float(v) for v in cm[:13]] + [float(v) for v in cm[13]]),   # coma_mission.py:270-345 order
+         actor_metrics=np.array([float(v) for v in am[:7]] + [float(v) for v in am[7]]),
          n_actor_params=np.array(sum(x.numel() for x in wrapper.actor_network.parameters())),
          n_critic_params=np.array(sum(x.numel() for x in wrapper.critic_network.parameters())))
 

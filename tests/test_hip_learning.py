@@ -25,6 +25,7 @@ def test_actor_and_critic_step_match_reference(golden):
     t = lambda x, dt=None: torch.tensor(x, device=dev, dtype=dt)  # noqa: E731
     cl = CriticLearner(params, critic, dev)
     al = ActorLearner(params, actor, dev, ctx=ctx)
+    cl.collect = al.collect = True
     closs, q_new = cl.step(t(state), t(actions), t(td))
     np.testing.assert_allclose(float(closs), float(fx["critic_loss"]), rtol=1e-4)
     np.testing.assert_allclose(q_new.cpu().numpy(), fx["q_new"], rtol=2e-4, atol=2e-6)
@@ -36,6 +37,17 @@ def test_actor_and_critic_step_match_reference(golden):
         pi1, _ = actor(t(obs, torch.float32), float(fx["eps"]))
     np.testing.assert_allclose(pi1.cpu().numpy(), fx["pi1"], rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(actor.fc3.bias.detach().cpu().numpy(), fx["actor_fc3_b"], rtol=1e-4, atol=1e-6)
+    # the diagnostics the reference logs for this step (coma_mission.py:270-424)
+    from ippmarl import metrics
+    from test_learning_cpu import ACTOR_TAGS, CRITIC_TAGS
+    cm = metrics.critic_metrics([dict(cl.last, discounted=torch.zeros(60, device=dev))], critic)
+    am = metrics.actor_metrics([al.last], actor, [pi1])
+    assert list(cm) == CRITIC_TAGS and list(am) == ACTOR_TAGS
+    np.testing.assert_allclose([cm[k] for k in CRITIC_TAGS], fx["critic_metrics"], rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose([am[k] for k in ACTOR_TAGS[:7]], fx["actor_metrics"][:7], rtol=1e-3, atol=1e-6)
+    # L1 norms of the actor's gradients: sums of strongly cancelling terms (advantages of both signs), so MIOpen's
+    # float32 summation order shows up at the per-cent level while the Adam update above still agrees to 1e-4
+    np.testing.assert_allclose([am[k] for k in ACTOR_TAGS[7:]], fx["actor_metrics"][7:], rtol=3e-2, atol=1e-6)
 
 
 def test_trainer_round_and_td_chains():
@@ -73,6 +85,30 @@ def test_trainer_round_and_td_chains():
     # eval rollout (argmax policy) does not touch the buffer
     tr.rollout("eval")
     assert tr.filled == 0
+
+
+def test_coma_mission_cadence_and_scalar_names(tmp_path):
+    """COMAMission.execute: updates, the reference's TensorBoard tags per training step, eval rounds, best-model pickle."""
+    from ippmarl.checkpoint import load_reference_actor
+    from ippmarl.missions.mission_factories import MissionFactory
+    from ippmarl.utils.writers import ScalarLog
+    from test_learning_cpu import ACTOR_TAGS, CRITIC_TAGS
+    params = make_params("small", experiment__missions__n_episodes=4, experiment__missions__patience=2)
+    factory = MissionFactory(params, log_dir=str(tmp_path), eval_every=2, eval_episodes=7)
+    assert isinstance(factory.writer, ScalarLog)          # no tensorboard in this image
+    mission = factory.create_mission()
+    assert mission.n_envs == 5                            # 300 transitions / (15 steps x 4 UAVs), the reference's round
+    best = mission.execute()
+    log = factory.writer.scalars
+    returns = [f"{m}{k}/{s}" for m in ("train", "eval") for k in ("Return/Episode", "Rewards/Episode", "Return/Relative(used)/Episode")
+               for s in ("mean", "std", "max", "min")]
+    assert set(log) == set(returns + CRITIC_TAGS + ACTOR_TAGS)
+    assert [s for s, _ in log["Critic/Loss"]] == [1, 2, 3, 4] and [s for s, _ in log["evalReturn/Episode/mean"]] == [2, 4]
+    assert all(np.isfinite(v) for series in log.values() for _, v in series)
+    assert mission.environment_step_idx == 4 * 300 and sum(mission.last_counts["actions"]) == 2 * 5 * 15 * 4
+    assert np.isfinite(best) and best == mission.max_mean_episode_return
+    actor = load_reference_actor(str(tmp_path / "best_model.pth"), params)   # whole-module pickle, reference style
+    assert sum(p.numel() for p in actor.parameters()) == 2275846
 
 
 def test_sampling_policy_matches_oracle():

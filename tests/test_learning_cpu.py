@@ -48,6 +48,47 @@ def test_critic_minibatch_step_matches_reference(golden):
     assert critic.fc2.weight.grad is None  # the unused layer never gets a gradient (matters for the all-reduce)
 
 
+CRITIC_TAGS = ["Critic/Loss", "Critic/TD-Targets mean", "Critic/TD-Targets std", "Critic/Q chosen mean", "Critic/Q values mean",
+               "Critic/Q values min", "Critic/Q values std", "Critic/Explained variance", "Critic/Discounted returns mean",
+               "Critic/Discounted_returns std", "Critic/Abs deviation Q-value <-> Return mean",
+               "Critic/Abs deviation Q-value <-> Return std", "Critic/Log probs according to critic"] + \
+              [f"Parameters/Critic/{n} gradients" for n in ("Conv1", "Conv2", "Conv3", "FC1", "FC2", "FC3")]
+ACTOR_TAGS = ["Actor/Loss", "Actor/Advantages mean", "Actor/Advantages std", "Actor/Log probs chosen mean", "Actor/Policy entropy",
+              "Actor/KL divergence policy", "Actor/Hidden state entropy"] + \
+             [f"Parameters/Actor/{n} gradients" for n in ("Conv1", "Conv2", "Conv3", "FC1", "FC2", "FC3")]
+
+
+def test_critic_diagnostics_match_reference(golden):
+    """The 13 figures + 6 gradient norms CriticLearner.learn hands to TensorBoard (critic/learner.py:100-190), in the order
+    coma_mission.py:270-345 names them."""
+    from ippmarl import metrics
+    from ippmarl.learners import CriticLearner
+    fx = golden("coma_step")
+    params, actor, critic = _nets(int(fx["net_seed"]))
+    obs, state, actions, masks, td = synthetic_minibatch(60, 6, int(fx["mb_seed"]))
+    learner = CriticLearner(params, critic, torch.device("cpu"))
+    learner.collect = True
+    learner.step(torch.tensor(state), torch.tensor(actions), torch.tensor(td))
+    got = metrics.critic_metrics([dict(learner.last, discounted=torch.zeros(60))], critic)
+    assert list(got) == CRITIC_TAGS
+    np.testing.assert_allclose([got[t] for t in CRITIC_TAGS], fx["critic_metrics"], rtol=2e-4, atol=1e-7)
+    assert metrics.explained_variance(torch.tensor([1.0, 2.0, 4.0]), torch.tensor([1.0, 2.5, 3.5])) == pytest.approx(
+        1 - np.var([0, -0.5, 0.5]) / np.var([1, 2, 4]))
+
+
+def test_return_scalars_and_scalar_log(tmp_path):
+    from ippmarl import metrics
+    from ippmarl.utils.writers import ScalarLog
+    got = metrics.return_scalars("train", [1.0, 3.0], [[0.5, 1.5], [2.5, 3.5]], [-1.0, -2.0])
+    assert got["trainReturn/Episode/mean"] == 2.0 and got["trainReturn/Episode/std"] == 1.0
+    assert got["trainRewards/Episode/max"] == 3.5 and got["trainReturn/Relative(used)/Episode/min"] == -2.0
+    assert len(got) == 12
+    log = ScalarLog(str(tmp_path))
+    log.add_scalar("a/b", torch.tensor(1.5), 3)
+    log.close()
+    assert log.scalars["a/b"] == [(3, 1.5)] and "a/b" in (tmp_path / "scalars.jsonl").read_text()
+
+
 def test_epsilon_schedule():
     from ippmarl.networks import epsilon_schedule
     p = make_params("default")
