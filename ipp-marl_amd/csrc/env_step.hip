@@ -867,7 +867,13 @@ __global__ void k_mask_act_move(const ippm_config* __restrict__ c, const int64_t
   const int n = c->n_agents, A = c->n_actions, s = c->spacing;
   const int64_t ep = episode ? episode[e] : 0;
   const uint32_t k0 = (uint32_t)c->philox_seed, k1 = (uint32_t)(c->philox_seed >> 32);
-  int32_t* pe = pos + (size_t)e * n * 3;
+  // The agents of an env move one after the other (agent i is masked against the already-moved j < i), so this is a
+  // latency chain per thread.  All positions are fetched up front into LDS (3n independent loads in flight) and
+  // written back once at the end: the loop itself never waits on global memory for a position.
+  __shared__ int32_t s_pos[64][IPPM_MAX_AGENTS * 3 + 1];   // +1: odd row stride, no bank conflicts between threads
+  int32_t* pe = s_pos[threadIdx.x];
+  int32_t* pg = pos + (size_t)e * n * 3;
+  for (int q = 0; q < n * 3; ++q) pe[q] = pg[q];
   int flt = 0;
   for (int i = 0; i < n; ++i) {
     const int px = pe[i * 3], py = pe[i * 3 + 1], pz = pe[i * 3 + 2];
@@ -930,6 +936,7 @@ __global__ void k_mask_act_move(const ippm_config* __restrict__ c, const int64_t
     action_out[e * n + i] = a;
     for (int q = 0; q < A; ++q) mask_out[(size_t)(e * n + i) * A + q] = (m >> q) & 1u;
   }
+  for (int q = 0; q < n * 3; ++q) pg[q] = pe[q];
   if (fault) fault[e] = flt;
 }
 

@@ -11,6 +11,9 @@ from ippmarl.vec_env import VecEnv
 E = 1024
 env = VecEnv(grid256_params(), E)
 layouts = {"disjoint": [[10, 10, 15], [10, 40, 15], [40, 10, 15], [40, 40, 15]],
+           "disjoint10": [[10, 10, 10], [10, 40, 10], [40, 10, 10], [40, 40, 10]],
+           "disjoint5": [[10, 10, 5], [10, 40, 5], [40, 10, 5], [40, 40, 5]],
+           "near5": [[25, 25, 5], [25, 30, 5], [30, 25, 5], [30, 30, 5]],
            "stacked": [[25, 25, 15], [25, 30, 15], [30, 25, 15], [30, 30, 15]],
            "random": None}
 for name, lay in layouts.items():

@@ -18,3 +18,9 @@ torch.cuda.synchronize()
 t0 = time.perf_counter(); tr.rollout("train"); torch.cuda.synchronize(); t1 = time.perf_counter()
 tr.update(); torch.cuda.synchronize(); t2 = time.perf_counter()
 print(f"rollout {t1 - t0:.3f}s update {t2 - t1:.3f}s")
+if os.environ.get("MIOPEN_FIND", "0") == "1":   # second measurement with MIOpen's exhaustive find
+    torch.backends.cudnn.benchmark = True
+    tr.rollout("train"); tr.update(); torch.cuda.synchronize()
+    t0 = time.perf_counter(); tr.rollout("train"); torch.cuda.synchronize(); t1 = time.perf_counter()
+    tr.update(); torch.cuda.synchronize(); t2 = time.perf_counter()
+    print(f"cudnn.benchmark=True: rollout {t1 - t0:.3f}s update {t2 - t1:.3f}s")
