@@ -24,3 +24,10 @@ if os.environ.get("MIOPEN_FIND", "0") == "1":   # second measurement with MIOpen
     t0 = time.perf_counter(); tr.rollout("train"); torch.cuda.synchronize(); t1 = time.perf_counter()
     tr.update(); torch.cuda.synchronize(); t2 = time.perf_counter()
     print(f"cudnn.benchmark=True: rollout {t1 - t0:.3f}s update {t2 - t1:.3f}s")
+if os.environ.get("CHANNELS_LAST", "0") == "1":   # conv weights in channels_last as well (inputs already are)
+    for net in (tr.actor, tr.critic, tr.frozen_target, tr.critic_learner.target_critic):
+        net.to(memory_format=torch.channels_last)
+    tr.rollout("train"); tr.update(); torch.cuda.synchronize()
+    t0 = time.perf_counter(); tr.rollout("train"); torch.cuda.synchronize(); t1 = time.perf_counter()
+    tr.update(); torch.cuda.synchronize(); t2 = time.perf_counter()
+    print(f"channels_last weights: rollout {t1 - t0:.3f}s update {t2 - t1:.3f}s")
