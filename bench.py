@@ -213,16 +213,22 @@ def main():
         if pmc.get("envs_per_gpu") == E and pmc.get("n_agents") == N:
             traffic = pmc.get("k_sense_update", {}).get("hbm_bytes_per_launch")
     if k3_ms:
-        achieved = K3_BYTES_PER_CELL * sense_cells_step / (k3_ms * 1e-3) / 1e9
+        # kernel duration = bracketed time minus the cost of the bracket itself, calibrated just above on the same stream
+        # (an empty pair reads ~5 us; rocprofv3's kernel trace of the same command agrees with the corrected figure)
+        raw_us = 1e3 * k3_ms / len(ev_pairs)
+        launch_us = max(raw_us - event_overhead_us, 0.5 * raw_us)
+        achieved = K3_BYTES_PER_CELL * sense_cells_step / len(ev_pairs) / (launch_us * 1e-6) / 1e9
         roofline = {"bound": "hbm", "kernel": "k_sense_update (K3: sense + Bayes update of the footprint tile)",
                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic, "algorithmic_bytes_per_launch": K3_BYTES_PER_CELL * sense_cells_step / max(len(ev_pairs), 1),
                     "algorithmic_bytes_per_cell": K3_BYTES_PER_CELL,
                     "cells_per_launch": sense_cells_step / max(len(ev_pairs), 1),
-                    "avg_launch_us": 1e3 * k3_ms / len(ev_pairs), "launches": len(ev_pairs),
+                    "avg_launch_us": launch_us, "avg_launch_us_raw": raw_us, "launches": len(ev_pairs),
                     "empty_event_pair_us": event_overhead_us,
-                    "note": "achieved uses the raw event-bracketed time (conservative: it contains the event-pair cost above); "
-                            "profiles/r01/kernel_stats_*.csv has the kernel-only duration"}
+                    "frac_raw": K3_BYTES_PER_CELL * sense_cells_step / len(ev_pairs) / (raw_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                    "note": "avg_launch_us = event-bracketed time of every K3 launch of the timed region minus the cost of an "
+                            "empty event pair measured in the same run (avg_launch_us_raw / frac_raw keep the uncorrected "
+                            "figures); profiles/r01/kernel_stats_*.csv is rocprofv3's kernel-only duration of the same command"}
 
     coma = None
     if args.train_rounds > 0:
