@@ -260,6 +260,26 @@ def main():
                 "rollout_agent_env_steps_per_s": tr.E * tr.N * tr.T * world * args.train_rounds / roll_s,
                 "note": "one update = TD(lambda) targets + data_passes x batch_number minibatch steps of critic and actor "
                         "(reference round: 25+25 Adam steps on 300 transitions); nets float32 in PyTorch-ROCm"}
+        if world == 1:
+            # the reference's own round size for comparison with its 0.164 updates/s: 5 episodes ->
+            # 300 transitions per update, 25 + 25 Adam steps on 60-sample minibatches
+            del tr
+            torch.cuda.empty_cache()
+            per_episode = T * N
+            ref_envs = max(1, -(-params["networks"]["batch_size"] * params["networks"]["batch_number"] // per_episode))
+            tr = COMATrainer(params, ref_envs, device=device, philox_seed=3, terrain=args.terrain)
+            tr.rollout("train")
+            tr.update()
+            torch.cuda.synchronize()
+            rounds = 5
+            c0 = time.perf_counter()
+            for _ in range(rounds):
+                tr.rollout("train")
+                stats = tr.update()
+            torch.cuda.synchronize()
+            cdt = time.perf_counter() - c0
+            coma["reference_sized_round"] = {"updates_per_s": rounds / cdt, "transitions_per_update": stats["transitions"],
+                                             "envs": ref_envs, "adam_steps_per_update": stats["adam_steps"]}
     if rank == 0:
         total_steps = E * N * args.steps * world
         out = {
