@@ -8,10 +8,17 @@ critic/network.py:12-47) so that a reference ``state_dict`` / ``best_model.pth``
 """
 from __future__ import annotations
 
+import os
 from typing import Dict
 
 import torch
 from torch import nn
+
+# MIOpen's exhaustive solver search (needed: its fast mode picks kernels that make a COMA update 6x slower) also times the
+# naive reference convolutions, which take 0.3-0.5 s per run on the 12k-sample minibatches: 40 s of warm-up per process
+# for nothing.  Leave them out of the search unless the user says otherwise.
+for _v in ("FWD", "BWD", "WRW"):
+    os.environ.setdefault(f"MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_{_v}", "0")
 
 
 def epsilon_schedule(params: Dict, num_episode: int) -> float:
