@@ -102,6 +102,10 @@ def _oracle_philox_episode(params, episode, seed, learned_probs=None, truth=None
     ("c4", dict(), 1),                                        # BASELINE config 4 shape: 8 UAVs, 512 x 512 (9-op plans)
     ("c5", dict(experiment__missions__n_agents=3), 1),        # config 5 shape: 27 actions, 1024 x 1024, per-episode comm range
     ("small", dict(experiment__missions__n_agents=12, experiment__uav__communication_range=100), 1),  # >10 ops: generic fusion path
+    ("small", dict(experiment__missions__n_agents=16, experiment__uav__communication_range=100,
+                   experiment__constraints__num_actions=27), 1),                                        # the largest team the ABI admits
+    ("small", dict(experiment__missions__n_agents=2, experiment__constraints__num_actions=9,
+                   experiment__constraints__min_altitude=15, experiment__constraints__max_altitude=15), 2),  # smallest team, planar moves
 ])
 def test_production_randomness_matches_oracle(name, over, n_envs):
     """Philox mode (what bench/training use): device RNG streams, uniform random policy, every step vs the oracle."""
