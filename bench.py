@@ -204,6 +204,18 @@ def main():
     torch.cuda.synchronize()
     event_overhead_us = 1e3 * sum(a.elapsed_time(b) for a, b in empty) / len(empty)
     sense_cells_step = counters["sense_cells"]
+    # second denominator: what a plain device-to-device copy of the local maps reaches on this box
+    src = env.local
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    ca, cb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ca.record()
+    for _ in range(3):
+        dst.copy_(src)
+    cb.record()
+    torch.cuda.synchronize()
+    copy_gbs = 3 * 2 * src.numel() * 4 / (ca.elapsed_time(cb) * 1e-3) / 1e9
+    del dst
     roofline = None
     traffic = None
     pmc_file = os.path.join(ROOT, "profiles", "pmc_summary.json")
@@ -225,6 +237,7 @@ def main():
                     "cells_per_launch": sense_cells_step / max(len(ev_pairs), 1),
                     "avg_launch_us": launch_us, "avg_launch_us_raw": raw_us, "launches": len(ev_pairs),
                     "empty_event_pair_us": event_overhead_us,
+                    "stream_copy_GBps": copy_gbs, "frac_of_stream_copy": achieved / copy_gbs,
                     "frac_raw": K3_BYTES_PER_CELL * sense_cells_step / len(ev_pairs) / (raw_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                     "note": "avg_launch_us = event-bracketed time of every K3 launch of the timed region minus the cost of an "
                             "empty event pair measured in the same run (avg_launch_us_raw / frac_raw keep the uncorrected "
