@@ -159,6 +159,11 @@ int ippm_comm_matrix(ippm_ctx* ctx, const int64_t* episode, const int32_t* pos, 
  * (drop-in Agent.receive_messages). */
 int ippm_fuse_local(ippm_ctx* ctx, float* local, const uint8_t* code, const int32_t* rect, const int32_t* pos,
                     const uint8_t* comm, int32_t* ws, int32_t agent_sel, int32_t n_envs, void* stream);
+/* ippm_comm_matrix followed by ippm_fuse_local for all agents, with the comm matrix and the fusion plans built by ONE
+ * small kernel (both sit on the critical path of every step).  Same results as the two calls. */
+int ippm_comm_fuse_local(ippm_ctx* ctx, const int64_t* episode, const int32_t* pos, const float* comm_range,
+                         const double* draws, uint8_t* comm, float* local, const uint8_t* code, const int32_t* rect,
+                         int32_t* ws, int32_t t, int32_t n_envs, void* stream);
 
 /* ---- K5: Mapping.fuse_map(..., "global") + get_global_reward (mappings.py:91-102, utils/reward.py:11-82,
  * utils/state.py:53-121).  Fuses all N measurements into global[e] in place and returns

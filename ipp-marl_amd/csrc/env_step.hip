@@ -275,17 +275,16 @@ k_sense_update(const ippm_config* __restrict__ c, const int64_t* __restrict__ ep
 // ======================================================================================================
 // comm matrix
 // ======================================================================================================
-__global__ void k_comm(const ippm_config* __restrict__ c, const int64_t* __restrict__ episode,
-                       const int32_t* __restrict__ pos, const float* __restrict__ comm_range,
-                       const double* __restrict__ draws, uint8_t* __restrict__ comm, int t, int n_envs) {
-  int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  int n = c->n_agents;
-  if (tid >= n_envs * n) return;
-  int e = tid / n, i = tid % n;
+// row i of the comm matrix of env e: bit j set <=> agent i hears agent j (communication_log.py:39-58); also stored as bytes
+__device__ __forceinline__ uint32_t comm_row(const ippm_config* __restrict__ c, const int64_t* __restrict__ episode,
+                                             const int32_t* __restrict__ pos, const float* __restrict__ comm_range,
+                                             const double* __restrict__ draws, uint8_t* __restrict__ comm, int t, int e, int i) {
+  const int n = c->n_agents;
   const int32_t* pi = pos + (size_t)(e * n + i) * 3;
   const double range = comm_range ? (double)comm_range[e] : c->comm_range;
   const int64_t ep = episode ? episode[e] : 0;
   const uint32_t k0 = (uint32_t)c->philox_seed, k1 = (uint32_t)(c->philox_seed >> 32);
+  uint32_t row = 0;
   for (int j = 0; j < n; ++j) {
     const int32_t* pj = pos + (size_t)(e * n + j) * 3;
     long long dx = pi[0] - pj[0], dy = pi[1] - pj[1], dz = pi[2] - pj[2];
@@ -303,7 +302,18 @@ __global__ void k_comm(const ippm_config* __restrict__ c, const int64_t* __restr
       if (dist <= range && u >= c->failure_rate) ok = true;
     }
     comm[(size_t)(e * n + i) * n + j] = ok ? 1 : 0;
+    row |= ok ? (1u << j) : 0u;
   }
+  return row;
+}
+
+__global__ void k_comm(const ippm_config* __restrict__ c, const int64_t* __restrict__ episode,
+                       const int32_t* __restrict__ pos, const float* __restrict__ comm_range,
+                       const double* __restrict__ draws, uint8_t* __restrict__ comm, int t, int n_envs) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = c->n_agents;
+  if (tid >= n_envs * n) return;
+  comm_row(c, episode, pos, comm_range, draws, comm, t, tid / n, tid % n);
 }
 
 // ======================================================================================================
@@ -320,20 +330,16 @@ __device__ __forceinline__ void plan_push(int32_t* w, int& nops, int type, int s
   ++nops;
 }
 
-__global__ void k_plan(const ippm_config* __restrict__ c, const int32_t* __restrict__ rect,
-                       const int32_t* __restrict__ pos, const uint8_t* __restrict__ comm, int32_t* __restrict__ ws,
-                       int global_maps, int n_envs, int agent_sel) {
-  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+// plans map i of env e (i == n: the global map); recv = agents whose measurements map i receives this step
+__device__ __forceinline__ void plan_map(const ippm_config* __restrict__ c, const int32_t* __restrict__ rect,
+                                         const int32_t* __restrict__ pos, uint32_t recv, int32_t* __restrict__ ws,
+                                         int global_maps, int e, int i) {
   const int n = c->n_agents;
-  const int per = (global_maps || agent_sel >= 0) ? 1 : n;
-  if (tid >= n_envs * per) return;
-  const int e = tid / per;
-  const int i = global_maps ? n : (agent_sel >= 0 ? agent_sel : tid % n);
   int32_t* w = ws + (size_t)(e * (n + 1) + i) * IPPM_WS_WORDS;
   int nops = 0, x0 = 1 << 30, x1 = -1, y0 = 1 << 30, y1 = -1;
   int last_src = -1;
   for (int j = 0; j < n; ++j) {
-    bool take = global_maps ? true : (j != i && comm[(size_t)(e * n + i) * n + j] != 0);
+    bool take = global_maps ? true : (j != i && ((recv >> j) & 1u) != 0);
     if (take) last_src = j;
   }
   int32_t* hdr = w + WS_PLAN;
@@ -356,7 +362,7 @@ __global__ void k_plan(const ippm_config* __restrict__ c, const int32_t* __restr
   if (!global_maps && w[WS_FLAG_S]) plan_push(w, nops, 0, -1, 0, rect + (size_t)(e * n + i) * 4, x0, x1, y0, y1);
   int last_op = -1;
   for (int j = 0; j < n; ++j) {
-    bool take = global_maps ? true : (j != i && comm[(size_t)(e * n + i) * n + j] != 0);
+    bool take = global_maps ? true : (j != i && ((recv >> j) & 1u) != 0);
     if (!take) continue;
     const int32_t* rj = rect + (size_t)(e * n + j) * 4;
     int before = nops;
@@ -371,6 +377,35 @@ __global__ void k_plan(const ippm_config* __restrict__ c, const int32_t* __restr
   hdr[PL_NOPS] = nops;
   hdr[PL_X0] = x0; hdr[PL_X1] = x1; hdr[PL_Y0] = y0; hdr[PL_Y1] = y1;
   hdr[PL_LAST] = last_op;
+}
+
+__global__ void k_plan(const ippm_config* __restrict__ c, const int32_t* __restrict__ rect,
+                       const int32_t* __restrict__ pos, const uint8_t* __restrict__ comm, int32_t* __restrict__ ws,
+                       int global_maps, int n_envs, int agent_sel) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = c->n_agents;
+  const int per = (global_maps || agent_sel >= 0) ? 1 : n;
+  if (tid >= n_envs * per) return;
+  const int e = tid / per;
+  const int i = global_maps ? n : (agent_sel >= 0 ? agent_sel : tid % n);
+  uint32_t recv = 0;
+  if (!global_maps)
+    for (int j = 0; j < n; ++j) recv |= comm[(size_t)(e * n + i) * n + j] ? (1u << j) : 0u;
+  plan_map(c, rect, pos, recv, ws, global_maps, e, i);
+}
+
+// comm matrix + local-fusion plans in one launch (one thread per (env, agent)): the two small kernels sit on the critical
+// path of every step and each costs a launch latency of its own (18 + 28 us while K5 keeps the GPU busy)
+__global__ void k_comm_plan(const ippm_config* __restrict__ c, const int64_t* __restrict__ episode,
+                            const int32_t* __restrict__ pos, const float* __restrict__ comm_range,
+                            const double* __restrict__ draws, uint8_t* __restrict__ comm, const int32_t* __restrict__ rect,
+                            int32_t* __restrict__ ws, int t, int n_envs) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = c->n_agents;
+  if (tid >= n_envs * n) return;
+  const int e = tid / n, i = tid % n;
+  const uint32_t recv = comm_row(c, episode, pos, comm_range, draws, comm, t, e, i);
+  plan_map(c, rect, pos, recv, ws, 0, e, i);
 }
 
 // ======================================================================================================
@@ -1079,6 +1114,20 @@ extern "C" int ippm_fuse_local(ippm_ctx* ctx, float* local, const uint8_t* code,
   hipLaunchKernelGGL(k_plan, dim3(grid1(maps, 64)), dim3(64), 0, S_(stream), ctx->dcfg, rect, pos, comm, ws, 0, n_envs, agent_sel);
   IPPM_LAUNCH_CHECK("plan_local");
   launch_apply<false>(ctx, local, code, ws, nullptr, maps, std::max(1, env_int("IPPM_SPLIT_K4", 1)), S_(stream), agent_sel);
+  IPPM_LAUNCH_CHECK("fuse_local");
+  return 0;
+}
+
+extern "C" int ippm_comm_fuse_local(ippm_ctx* ctx, const int64_t* episode, const int32_t* pos, const float* comm_range,
+                                    const double* draws, uint8_t* comm, float* local, const uint8_t* code, const int32_t* rect,
+                                    int32_t* ws, int32_t t, int32_t n_envs, void* stream) {
+  if (!ctx || !pos || !comm || !local || !code || !rect || !ws) { ippm_set_error("ippm_comm_fuse_local: null argument"); return -1; }
+  if (!draws && !episode) { ippm_set_error("ippm_comm_fuse_local: Philox draws need the episode ids"); return -1; }
+  const int maps = n_envs * ctx->cfg.n_agents;
+  hipLaunchKernelGGL(k_comm_plan, dim3(grid1(maps, 64)), dim3(64), 0, S_(stream), ctx->dcfg, episode, pos, comm_range, draws, comm,
+                     rect, ws, t, n_envs);
+  IPPM_LAUNCH_CHECK("comm_plan");
+  launch_apply<false>(ctx, local, code, ws, nullptr, maps, std::max(1, env_int("IPPM_SPLIT_K4", 1)), S_(stream), -1);
   IPPM_LAUNCH_CHECK("fuse_local");
   return 0;
 }

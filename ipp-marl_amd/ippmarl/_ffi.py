@@ -60,6 +60,7 @@ PROTOTYPES = {
     "ippm_sense_update": [P, P, P, P, P, P, P, P, P, I32, I32, I32, P],
     "ippm_comm_matrix": [P, P, P, P, P, P, I32, I32, P],
     "ippm_fuse_local": [P, P, P, P, P, P, P, I32, I32, P],
+    "ippm_comm_fuse_local": [P, P, P, P, P, P, P, P, P, P, I32, I32, P],
     "ippm_action_mask": [P, P, P, P, I32, P, P, P, I32, P],
     "ippm_clamp_logodds": [P, P, I64, P],
     "ippm_fuse_global_reward": [P, P, P, P, P, P, P, P, I32, P],

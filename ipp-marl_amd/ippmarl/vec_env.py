@@ -168,8 +168,10 @@ class VecEnv:
             self.side.wait_stream(main)
             self._launch_k5(self.side.cuda_stream)
             self._k5_done = self.side.record_event()
-        self.comm_matrix(t, comm_draws)
-        self.fuse_local()
+        # comm matrix + local fusion (one planning kernel for both: ippm_comm_fuse_local)
+        self.ctx.call("ippm_comm_fuse_local", self._p(self.episode), self._p(self.pos), self._p(self.comm_range), self._p(comm_draws),
+                      self._p(self.comm), self._p(self.local), self._p(self.code), self._p(self.rect), self._p(self.ws), t, self.E,
+                      self.stream)
         if not features:
             return None
         if self.obs is None:

@@ -397,6 +397,25 @@ def test_graph_replay_matches_eager():
         b.reset(eps + 100)
 
 
+def test_fused_comm_and_plan_equals_separate_calls():
+    """ippm_comm_fuse_local == ippm_comm_matrix + ippm_fuse_local (bitwise), incl. link failures and per-episode ranges."""
+    from ippmarl.vec_env import POLICY_UNIFORM
+    params = make_params("small", experiment__uav__failure_rate=0.3, experiment__uav__fix_range=False, experiment__missions__n_agents=5)
+    a, b = _env(params, 24), _env(params, 24)
+    eps = np.arange(3, 27)
+    a.reset(eps)
+    b.reset(eps)
+    for t in range(a.d.budget + 1):
+        a.build_observations(t, features=False)          # fused entry point
+        b.comm_matrix(t)
+        b.fuse_local()
+        assert torch.equal(a.comm, b.comm) and torch.equal(a.local, b.local) and torch.equal(a.ws[:, :-1], b.ws[:, :-1]), t
+        a.steps(t, policy=POLICY_UNIFORM, features=False)
+        b._k5_done = None
+        b.steps(t, policy=POLICY_UNIFORM, features=False)
+        assert torch.equal(a.pos, b.pos) and torch.equal(a.glob, b.glob), t
+
+
 def test_c_abi_error_paths():
     """Error behaviour of the C-ABI: negative return codes with a message, never a crash."""
     import ctypes as C
