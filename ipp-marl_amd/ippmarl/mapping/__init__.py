@@ -1,0 +1,1 @@
+"""ippmarl.mapping: drop-in counterparts of the reference package of the same name."""

@@ -1,12 +1,16 @@
-"""Mission base class (reference: missions/missions.py:5-18)."""
+"""What every mission shares: the config, a scalar sink and the best running mean return seen so far.  A concrete mission
+(``coma_mission.COMAMission``) supplies ``execute`` (the reference keeps the same three attributes on its base class,
+missions/missions.py:5-18)."""
+from __future__ import annotations
+
 from typing import Dict
 
 
 class Mission:
-    def __init__(self, params: Dict, writer, max_mean_episode_return: float = -100):
-        self.params = params
-        self.writer = writer
-        self.max_mean_episode_return = max_mean_episode_return
+    def __init__(self, params: Dict, writer=None, max_mean_episode_return: float = -100.0):
+        self.params, self.writer = params, writer
+        self.max_mean_episode_return = float(max_mean_episode_return)
 
     def execute(self):
-        raise NotImplementedError("Planning mission does not implement 'execute' function!")
+        """Runs the mission and returns its figure of merit."""
+        raise NotImplementedError(f"{type(self).__name__} has no execute()")
