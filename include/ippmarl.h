@@ -38,6 +38,11 @@
  *                                 initialised by ippm_reset_episode, otherwise opaque (zero-fill to start)
  *   sums      double [E,8]        reward accumulators: [0]=S1 [1]=S2 [2]=T (running weighted entropy of the
  *                                 global map), [3..5] scratch; initialised by ippm_reset_episode
+ *   area      double [E,N+1,121]  11x11 area sums of every belief map (slot N = the global map): area[b] = sum over cells of
+ *                                 (11*overlap of the cell with row bin bx) * (same for by) * p(cell); area / (gx*gy) is the
+ *                                 exact area average cv2.resize(map, (11,11), INTER_AREA) of utils/state.py:22-41.  Optional
+ *                                 (NULL = not tracked): when given, every kernel that writes a map keeps it up to date, so
+ *                                 the K6 feature builders never stream a map; ippm_area_sums rebuilds it from scratch.
  */
 #ifndef IPPMARL_H
 #define IPPMARL_H
@@ -48,7 +53,7 @@
 extern "C" {
 #endif
 
-#define IPPM_VERSION 100
+#define IPPM_VERSION 200
 #define IPPM_MAX_AGENTS 16
 #define IPPM_MAX_LATTICE 64 /* lattice points per horizontal axis */
 #define IPPM_MAX_Z 8        /* altitude levels */
@@ -57,6 +62,10 @@ extern "C" {
 #define IPPM_ACTOR_PLANES 7
 #define IPPM_CRITIC_PLANES 12
 #define IPPM_WS_WORDS 160
+/* ippm_plan_step flags */
+#define IPPM_STEP_COMM 1   /* comm matrix + local-fusion plans */
+#define IPPM_STEP_GLOBAL 2 /* global-fusion plan */
+#define IPPM_STEP_MOVE 4   /* K1 mask/act/move (+ footprints of the new positions) */
 
 /* Derived constants, computed on the host in float64 with the reference's expression order
  * (ippmarl/derived.py) and handed over as plain integers/floats. */
@@ -79,9 +88,9 @@ typedef struct ippm_config {
   float logit_meas[IPPM_MAX_Z][2];    /* ln(y/(1-y)) in float32 for y = f32(round(noise,3)), f32(round(1-noise,3)) */
   float meas_value[IPPM_MAX_Z][2];    /* the two measurement values themselves (simulations.py:47-51) */
   uint32_t flip_threshold[IPPM_MAX_Z];/* observation flipped iff philox word < threshold = floor(noise*2^32) */
-  float prior;                        /* must be 0.5 on this path (full-grid prior shift) */
+  float prior;                        /* mapping.prior; != 0.5 takes the explicit full-grid slow path of the fusion */
   float clip_lo, clip_hi;             /* 1e-4, 0.9999 (mappings.py:110-111, state.py:119-120) */
-  float logit_prior;                  /* ln(prior/(1-prior)) = 0 */
+  float logit_prior;                  /* ln(prior/(1-prior)); 0 for the default prior 0.5 */
   float logit_clip;                   /* ln(clip_hi/(1-clip_hi)) = 9.21024...; the clip is symmetric in log-odds */
   float logit_weight_thr;             /* ln(0.501/0.499): class-weight thresholds of utils/state.py:65-66 */
   double comm_range;                  /* metres, used when fix_range != 0 */
@@ -122,16 +131,20 @@ int ippm_read_counters(ippm_ctx* ctx, ippm_counters* out, int reset, void* strea
  * (mappings.py:126-132) and CommunicationLog.__init__'s per-episode range (communication_log.py:22-31).
  * The MT19937 streams are regenerated on the device, bit-exactly.
  * truth may be NULL (caller supplies its own terrain; split_pct int32 [E,2] is required otherwise);
- * local, global, comm_range_out (float [E]) and sums may be NULL. */
+ * local, global, comm_range_out (float [E]), sums and area may be NULL. */
 int ippm_reset_episode(ippm_ctx* ctx, const int64_t* episode, int32_t* pos, uint8_t* truth, float* local,
                        float* global, int32_t* split_pct, float* comm_range_out, int32_t* ws, double* sums,
-                       int32_t n_envs, void* stream);
+                       double* area, int32_t n_envs, void* stream);
 
 /* Elementwise conversions between the stored log-odds and the reference's probabilities (n floats). */
 int ippm_logodds_to_prob(ippm_ctx* ctx, const float* src, float* dst, int64_t n, void* stream);
 int ippm_prob_to_logodds(ippm_ctx* ctx, const float* src, float* dst, int64_t n, void* stream);
 /* clip(p, 1e-4, 0.9999) of n stored log-odds in place: the full-grid input clip of one stand-alone fuse_map call. */
 int ippm_clamp_logodds(ippm_ctx* ctx, float* maps, int64_t n, void* stream);
+
+/* Plain device-to-device copy with 16-byte lane accesses (n_bytes and both pointers multiples of 16): the streaming-rate
+ * denominator bench.py quotes next to the HBM peak. */
+int ippm_stream_copy(ippm_ctx* ctx, const void* src, void* dst, int64_t n_bytes, void* stream);
 
 /* ---- K2: Camera.project_field_of_view (sensors/cameras.py:46-79) ------------------------------------ */
 int ippm_footprint(ippm_ctx* ctx, const int32_t* pos, int32_t* rect, int32_t* rect_unclipped, int32_t n_envs,
@@ -145,6 +158,14 @@ int ippm_footprint(ippm_ctx* ctx, const int32_t* pos, int32_t* rect, int32_t* re
 int ippm_sense_update(ippm_ctx* ctx, const int64_t* episode, const int32_t* pos, const uint8_t* truth,
                       float* local, const uint8_t* flips, uint8_t* code, int32_t* rect, int32_t* ws,
                       int32_t stage, int32_t agent_sel, int32_t n_envs, void* stream);
+/* K3 as the closing kernel of a batched env step (COMAWrapper.steps' `agent.step` calls, coma_wrapper.py:106-134):
+ * rect_in (optional) = the footprints ippm_plan_step projected for the new positions (saves the dependent
+ * pos -> lattice index -> centre-table loads); area (optional) = tracked area sums, updated for local[e,i];
+ * sums + reward (optional, together) = complete the reward of the step's global fusion in the same launch
+ * (what ippm_reward_finalize does; the fusion of ippm_fuse_step leaves it open). */
+int ippm_sense_step(ippm_ctx* ctx, const int64_t* episode, const int32_t* pos, const uint8_t* truth, float* local,
+                    const uint8_t* flips, uint8_t* code, const int32_t* rect_in, int32_t* rect, int32_t* ws, double* area,
+                    double* sums, float* reward, int32_t stage, int32_t agent_sel, int32_t n_envs, void* stream);
 
 /* ---- comm: CommunicationLog.get_messages (agent/communication_log.py:39-58) ---------------------------
  * draws: float64 [E,N,N] replacing np.random.random_sample() per ordered pair, or NULL -> Philox.
@@ -173,6 +194,25 @@ int ippm_comm_fuse_local(ippm_ctx* ctx, const int64_t* episode, const int32_t* p
 int ippm_fuse_global_reward(ippm_ctx* ctx, float* global, const uint8_t* code, const int32_t* rect,
                             const int32_t* pos, int32_t* ws, double* sums, float* reward, int32_t n_envs,
                             void* stream);
+
+/* ---- the batched step in three launches: ippm_plan_step -> ippm_fuse_step -> ippm_sense_step ---------------------------
+ * ippm_plan_step: everything of an env step that touches no map, one wavefront per env, selected by `flags`:
+ *   IPPM_STEP_COMM    CommunicationLog.get_messages for every agent + the local-fusion plans (as ippm_comm_fuse_local)
+ *   IPPM_STEP_GLOBAL  the global-fusion plan (as ippm_fuse_global_reward's first stage)
+ *   IPPM_STEP_MOVE    K1 = ippm_mask_act_move on the same positions (comm and the plans see the pre-move ones); also writes
+ *                     rect_next int32 [E,N,4] (optional) = the clipped footprints of the NEW positions for ippm_sense_step.
+ *                     Only policies that do not depend on this step's observations (0 explicit, 1 uniform) can share a call
+ *                     with COMM/GLOBAL; a learned policy calls MOVE separately after the actor.
+ * ippm_fuse_step: K4 for all local maps and K5 for all global maps from the plans above, in one launch; keeps `area`
+ *   (optional) up to date; leaves the reward sums open (ippm_sense_step or ippm_reward_finalize completes them).
+ * ippm_reward_finalize: reward[e] = (22*S1/S2 - 0.5, 10*S1/(gx*gy) - 0.17) from the accumulated sums (utils/reward.py:25-40). */
+int ippm_plan_step(ippm_ctx* ctx, const int64_t* episode, int32_t* pos, const float* comm_range, const double* draws,
+                   uint8_t* comm, const int32_t* rect, int32_t* ws, int32_t t, int32_t flags, const float* probs,
+                   const int32_t* action_in, int32_t policy, uint8_t* mask, int32_t* action, int32_t* fault,
+                   int32_t* rect_next, int32_t n_envs, void* stream);
+int ippm_fuse_step(ippm_ctx* ctx, float* local, float* global, const uint8_t* code, int32_t* ws, double* sums, double* area,
+                   int32_t n_envs, void* stream);
+int ippm_reward_finalize(ippm_ctx* ctx, double* sums, float* reward, int32_t n_envs, void* stream);
 
 /* Full-grid weighted entropy sum(w(p) H(p)) per map (utils/state.py:53-121, "reward" mode); n_maps maps of
  * gx*gy floats; out float64 [n_maps].  truth != NULL: weights from ground truth ("eval" mode), map m uses
@@ -204,14 +244,30 @@ int ippm_mask_act_move(ippm_ctx* ctx, const int64_t* episode, int32_t* pos, cons
 
 /* ---- K6: network inputs (actor/transformations.py:14-176, critic/transformations.py:17-132,
  * utils/state.py:22-41).  obs float [E,N,11,11,7]; state float [E,N,11,11,12].
- * ippm_actor_features must run after ippm_fuse_local of step t (uses the fused local maps, the published
- * measurements/rects/positions and comm); ippm_critic_features after ippm_fuse_global_reward and
- * ippm_mask_act_move of step t with pos_pre = the pre-move positions. */
-int ippm_actor_features(ippm_ctx* ctx, const float* local, const uint8_t* code, const int32_t* rect,
+ * The maps enter through their area sums `area` double [E,N+1,121] (tracked by the map kernels, or rebuilt by
+ * ippm_area_sums): the feature builders never stream a map.
+ * ippm_actor_features must run after the local fusion of step t (uses the fused local maps' sums, the published
+ * measurements/rects/positions and comm); ippm_critic_features after the global fusion and K1 of step t with
+ * pos_pre = the pre-move positions.
+ * ippm_area_sums: area slots of n_maps log-odds maps from scratch (a streaming pass: 16-byte loads, 2 rows in flight);
+ *   map m belongs to env m / maps_per_env, slot slot0 + m % maps_per_env (local maps: maps_per_env = N, slot0 = 0; global
+ *   maps: maps_per_env = 1, slot0 = N).
+ * ippm_area_resize: cv2.resize(src, (11,11), INTER_AREA) of n_arrays plain float arrays [rows,cols] -> dst float
+ *   [n_arrays,11,11]; scratch double [n_arrays,121]. */
+int ippm_actor_features(ippm_ctx* ctx, const double* area, const uint8_t* code, const int32_t* rect,
                         const int32_t* pos, const uint8_t* comm, int32_t t, float* obs, int32_t n_envs,
                         void* stream);
-int ippm_critic_features(ippm_ctx* ctx, const float* global, const int32_t* rect, const int32_t* pos_pre,
+int ippm_critic_features(ippm_ctx* ctx, const double* area, const int32_t* rect, const int32_t* pos_pre,
                          const int32_t* action, const float* obs, float* state, int32_t n_envs, void* stream);
+int ippm_area_sums(ippm_ctx* ctx, const float* maps, double* area, int32_t n_maps, int32_t maps_per_env, int32_t slot0,
+                   void* stream);
+int ippm_area_resize(ippm_ctx* ctx, const float* src, int32_t rows, int32_t cols, float* dst, double* scratch,
+                     int32_t n_arrays, void* stream);
+/* calculate_w_entropy on n explicit probabilities (utils/state.py:53-121): grid = clip(p, 1e-4, 0.9999), se = H(grid),
+ * weightings = class weight of `target` (NULL: of p itself -- "reward"/"actor"/"global"; the ground truth for "eval"),
+ * w_entropy = weightings * se.  Every output may be NULL. */
+int ippm_entropy_maps(ippm_ctx* ctx, const float* prob, const float* target, float* w_entropy, float* weightings,
+                      float* se, float* grid, int64_t n, void* stream);
 
 /* ---- K7: COMA counterfactual advantage (actor/learner.py:55-95).  probs/q float [B,A], mask uint8 [B,A],
  * action int32 [B] -> advantage float [B], pi_tilde float [B,A] (may be NULL). */

@@ -59,53 +59,6 @@ extern "C" int ippm_host_truth_params(int64_t episode, int32_t* out2) {
   return 0;
 }
 
-static int build_tables(ippm_ctx* ctx) {
-  const ippm_config& c = ctx->cfg;
-  std::vector<int32_t> ti;
-  std::vector<float> t0, t1;
-  auto add = [&](int n) -> int {
-    const int off = (int)ti.size();
-    std::vector<int32_t> b(n);
-    std::vector<float> a0(n), a1(n);
-    ippm_area_weights(n, IPPM_FEAT, b.data(), a0.data(), a1.data());
-    ti.insert(ti.end(), b.begin(), b.end());
-    for (int o = 0; o <= IPPM_FEAT; ++o) {  // bstart[o] = first source index with bin0 >= o
-      int first = n;
-      for (int i = 0; i < n; ++i)
-        if (b[i] >= o) { first = i; break; }
-      ti.push_back(first);
-    }
-    t0.insert(t0.end(), a0.begin(), a0.end());
-    t1.insert(t1.end(), a1.begin(), a1.end());
-    t0.resize(ti.size(), 0.f);
-    t1.resize(ti.size(), 0.f);
-    return off;
-  };
-  const bool feats = c.grid_x >= IPPM_FEAT && c.grid_y >= IPPM_FEAT;
-  ctx->off_rows = feats ? add(c.grid_x) : 0;
-  ctx->off_cols = feats ? add(c.grid_y) : 0;
-  for (int k = 0; k < IPPM_MAX_Z; ++k) {
-    ctx->n_fp[k] = 0;
-    ctx->off_fp[k] = 0;
-    if (k < c.space_z && feats && 2 * c.radius_y[k] >= IPPM_FEAT) {
-      ctx->n_fp[k] = 2 * c.radius_y[k];
-      ctx->off_fp[k] = add(ctx->n_fp[k]);
-    }
-  }
-  if (ti.empty()) { ti.push_back(0); t0.push_back(0.f); t1.push_back(0.f); }
-  IPPM_HIP(hipMalloc(&ctx->tab_bin0, ti.size() * sizeof(int32_t)));
-  IPPM_HIP(hipMalloc(&ctx->tab_w0, t0.size() * sizeof(float)));
-  IPPM_HIP(hipMalloc(&ctx->tab_w1, t1.size() * sizeof(float)));
-  IPPM_HIP(hipMemcpy(ctx->tab_bin0, ti.data(), ti.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  IPPM_HIP(hipMemcpy(ctx->tab_w0, t0.data(), t0.size() * sizeof(float), hipMemcpyHostToDevice));
-  IPPM_HIP(hipMemcpy(ctx->tab_w1, t1.data(), t1.size() * sizeof(float), hipMemcpyHostToDevice));
-  IPPM_HIP(hipMalloc(&ctx->d_fp_off, IPPM_MAX_Z * sizeof(int32_t)));
-  IPPM_HIP(hipMalloc(&ctx->d_fp_n, IPPM_MAX_Z * sizeof(int32_t)));
-  IPPM_HIP(hipMemcpy(ctx->d_fp_off, ctx->off_fp, IPPM_MAX_Z * sizeof(int32_t), hipMemcpyHostToDevice));
-  IPPM_HIP(hipMemcpy(ctx->d_fp_n, ctx->n_fp, IPPM_MAX_Z * sizeof(int32_t), hipMemcpyHostToDevice));
-  return 0;
-}
-
 extern "C" int ippm_ctx_create(const ippm_config* cfg, ippm_ctx** out) {
   if (!cfg || !out) { ippm_set_error("ippm_ctx_create: null argument"); return -1; }
   const ippm_config& c = *cfg;
@@ -116,8 +69,8 @@ extern "C" int ippm_ctx_create(const ippm_config* cfg, ippm_ctx** out) {
   if (c.space_z < 1 || c.space_z > IPPM_MAX_Z) return bad("too many altitude levels");
   if (!(c.n_actions == 4 || c.n_actions == 6 || c.n_actions == 9 || c.n_actions == 27)) return bad("num_actions must be 4, 6, 9 or 27");
   if (!(c.logit_clip > 0.f) || !(c.logit_weight_thr > 0.f)) return bad("logit_clip / logit_weight_thr not set");
-  if (c.prior != 0.5f) return bad("mapping.prior != 0.5 is not supported on the HIP path (the reference shifts every cell of a map by "
-                                  "-logit(prior) per fused message; see DESIGN.md)");
+  if (!(c.prior > 0.f && c.prior < 1.f)) return bad("mapping.prior must lie in (0, 1)");
+  // prior != 0.5 is the explicit slow path: every fusion then walks the whole grid (fuse.hip, SHIFT)
   if (c.tile_stride % 4 != 0) return bad("tile_stride must be a multiple of 4");
   for (int k = 0; k < c.space_z; ++k)
     if (2 * c.radius_x[k] > c.tile_stride || 2 * c.radius_y[k] + 3 > c.tile_stride) return bad("tile_stride too small for the footprint");
@@ -125,12 +78,13 @@ extern "C" int ippm_ctx_create(const ippm_config* cfg, ippm_ctx** out) {
   ippm_ctx* ctx = new ippm_ctx();
   std::memset(ctx, 0, sizeof(*ctx));
   ctx->cfg = c;
-  ctx->vec = (c.grid_y % 4 == 0) ? 4 : 1;
+  // 16-byte lane groups need a grid that is a multiple of 4 wide; the area sums additionally want a 4-cell group to span at
+  // most two of the 11 column bins (grid_y >= 44).  Everything else takes the one-cell-per-lane instantiations.
+  ctx->vec = (c.grid_y % 4 == 0 && c.grid_y >= 4 * IPPM_FEAT) ? 4 : 1;
   int rc = ippm_check_hip(hipMalloc(&ctx->dcfg, sizeof(ippm_config)), "hipMalloc(cfg)");
   if (!rc) rc = ippm_check_hip(hipMemcpy(ctx->dcfg, cfg, sizeof(ippm_config), hipMemcpyHostToDevice), "hipMemcpy(cfg)");
   if (!rc) rc = ippm_check_hip(hipMalloc(&ctx->dcounters, IPPM_COUNTER_SLOTS * 8 * sizeof(unsigned long long)), "hipMalloc(counters)");
   if (!rc) rc = ippm_check_hip(hipMemset(ctx->dcounters, 0, IPPM_COUNTER_SLOTS * 8 * sizeof(unsigned long long)), "hipMemset(counters)");
-  if (!rc) rc = build_tables(ctx);
   if (rc) { ippm_ctx_destroy(ctx); return rc; }
   *out = ctx;
   return 0;
@@ -140,11 +94,6 @@ extern "C" int ippm_ctx_destroy(ippm_ctx* ctx) {
   if (!ctx) return 0;
   if (ctx->dcfg) (void)hipFree(ctx->dcfg);
   if (ctx->dcounters) (void)hipFree(ctx->dcounters);
-  if (ctx->tab_bin0) (void)hipFree(ctx->tab_bin0);
-  if (ctx->tab_w0) (void)hipFree(ctx->tab_w0);
-  if (ctx->tab_w1) (void)hipFree(ctx->tab_w1);
-  if (ctx->d_fp_off) (void)hipFree(ctx->d_fp_off);
-  if (ctx->d_fp_n) (void)hipFree(ctx->d_fp_n);
   delete ctx;
   return 0;
 }

@@ -1,113 +1,181 @@
-// K6: network-input builders (actor 7 planes, critic 12 planes) and the full-grid reward of two given maps.
+// K6: network-input builders (actor 7 planes, critic 12 planes), the exact area-average resize they rest on, and the
+// full-grid reward / entropy planes of explicitly given maps.
 //
-// The expensive part is the exact area average G x G -> 11 x 11 (the reference's cv2.resize INTER_AREA,
-// utils/state.py:22-41).  It is separable: one pass streams the map row by row (coalesced: consecutive
-// lanes own consecutive columns) into per-column partial sums of the 11 row bins held in LDS, a second tiny
-// pass folds the columns.  The footprint planes are analytic functions of the rectangles and are
-// accumulated in the same pass without touching memory.
-#include "ippm_internal.h"
+//   actor/transformations.py:14-176, critic/transformations.py:17-132, utils/state.py:14-121
+//
+// The expensive input of every plane set is the exact area average G x G -> 11 x 11 of a belief map (the reference's
+// cv2.resize INTER_AREA, utils/state.py:22-41).  Round 1 streamed all N+1 maps of every env at every step to get it
+// (4 (N+1) G^2 bytes per env step: 757 + 181 us at 1024 envs x 4 UAVs x 256^2, a third of a learned-policy step).  Now the
+// kernels that WRITE maps (K3, K4, K5) keep the 121 area sums of each map up to date (ippm_tiles.h), and K6 is a
+// 121-cell assembly per (env, agent):
+//   q      = area sums / (gx gy)                                   (map planes 3, 5 / 8, 9)
+//   F      = analytic: the footprint-indicator planes are unions of rectangles.  Along x the set of rectangles covering
+//            a row changes only at rectangle edges (slabs); in 1/11-cell units every overlap length is an integer, so
+//            R(F) = 0.5 + sum_slabs Wx(slab, bx) (Uown - Uother)(slab, by) / (2 gx gy) exactly
+//   fp     = R(footprint_img): the measurement bits of the agent's own tile (<= 2r x 2r one-bit cells), integer counts of
+//            the two measurement values per bin
+// ippm_area_sums is the streaming form (16-byte loads, 2 rows in flight) for maps that were written from outside.
+#include <algorithm>
 
-struct TabView {
-  const int32_t* bin0;    // [n] first output bin a source index overlaps
-  const float* w0;        // [n] weight into bin0 (already divided by the scale)
-  const float* w1;        // [n] weight into bin0+1 (0 if none)
-  const int32_t* bstart;  // [12] first source index whose bin0 >= b
-  int n;
+#include "ippm_tiles.h"
+
+#define FEAT2 (IPPM_FEAT * IPPM_FEAT)
+#define MAX_EDGES (2 * IPPM_MAX_AGENTS + 2)
+
+// 11-scaled overlap of the cell interval [a, b) with bin `bin` of an axis of n cells: an integer
+__device__ __forceinline__ int overlap11(int a, int b, int bin, int n) {
+  return max(0, min(11 * b, (bin + 1) * n) - max(11 * a, bin * n));
+}
+
+// ------------------------------------------------------------------------------------------------------
+// full recomputation of area sums: area[m] = sum nr nc f(map[m]) with f = sigmoid (log-odds maps) or identity
+// ------------------------------------------------------------------------------------------------------
+template <int VEC, bool SIGMOID>
+__global__ void __launch_bounds__(256)
+k_area_sums(const float* __restrict__ maps, double* __restrict__ area, int gx, int gy, int chunk_rows, int maps_per_env,
+            int slots_per_env, int slot0) {
+  const int m = blockIdx.y;
+  const int r0 = blockIdx.x * chunk_rows, r1 = min(gx, r0 + chunk_rows);
+  if (r0 >= r1) return;
+  const float* map = maps + (size_t)m * gx * gy;
+  double* out = area + (size_t)((m / maps_per_env) * slots_per_env + slot0 + m % maps_per_env) * FEAT2;
+  __shared__ double s_area[(IPPM_FEAT + 1) * IPPM_AREA_LD];
+  area_lds_clear(s_area);
+  const float inv_gx = __builtin_amdgcn_rcpf((float)gx), inv_gy = __builtin_amdgcn_rcpf((float)gy);
+  __syncthreads();
+  const RowGeom g = make_geom<VEC>(0, gy);
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int sub = lane >> g.shift, gl = lane & (g.lpr - 1);
+  const int stride = 4 * g.rpw;
+  constexpr int UNR = 2;
+  for (int gi = gl; gi < g.groups; gi += g.lpr) {
+    const int y = gi * VEC;
+    const AreaCols<VEC> ac = area_cols<VEC>(y, gy, inv_gy);
+    AreaAcc acc;
+    acc.init();
+    for (int row = r0 + wv * g.rpw + sub; row < r1; row += stride * UNR) {
+      CellVec<VEC> v[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int rr = row + u * stride;
+        if (rr < r1) v[u] = load_cells<VEC>(map + (size_t)rr * gy + y);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int rr = row + u * stride;
+        if (rr >= r1) continue;
+        float d[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) d[q] = SIGMOID ? ippm_sigmoid(v[u].v[q]) : v[u].v[q];
+        area_row<VEC>(acc, s_area, ac, rr, gx, inv_gx, d);
+      }
+    }
+    acc.flush(s_area, ac.cb);
+  }
+  __syncthreads();
+  area_lds_commit(s_area, out);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// shared pieces of the two feature kernels
+// ------------------------------------------------------------------------------------------------------
+struct RectList {  // in LDS
+  int r[IPPM_MAX_AGENTS][4];   // [yu,yd,xl,xr]
+  int kind[IPPM_MAX_AGENTS];   // 0 = not in the plane, 1 = "own" (value 1), 2 = "other"
+  int edges[MAX_EDGES];        // sorted x-edges of the participating rectangles
+  int n_edges;
+  int U[MAX_EDGES][IPPM_FEAT]; // per slab and column bin: 11-scaled measure of own columns minus (other \ own) columns
 };
 
-// Column-owner area reduction: thread `tid` owns columns tid, tid+nthr, ...; walks all rows.
-// SRC(row, col) -> value.  colsum: LDS [planes][11][n_cols]; out: LDS [planes][121].
-template <int PLANES, class SRC>
-__device__ void area_reduce(SRC src, const TabView rows, const TabView cols, float* colsum, float* out) {
-  const int n_rows = rows.n, n_cols = cols.n;
-  for (int col = threadIdx.x; col < n_cols; col += blockDim.x) {
-    float a0[PLANES], a1[PLANES];
-#pragma unroll
-    for (int p = 0; p < PLANES; ++p) { a0[p] = 0.f; a1[p] = 0.f; }
-    int cur = 0;
-    for (int r = 0; r < n_rows; ++r) {
-      const int b = rows.bin0[r];
-      while (b > cur) {
-#pragma unroll
-        for (int p = 0; p < PLANES; ++p) { colsum[(p * IPPM_FEAT + cur) * n_cols + col] = a0[p]; a0[p] = a1[p]; a1[p] = 0.f; }
-        ++cur;
+// R(F) of a footprint-indicator plane: F = 1 on "own", `other_val` on other \ own, 0.5 elsewhere; returns into out[121]
+// (other_val = 0 for the actor plane, 1 for the critic plane where every rectangle is an "other").
+__device__ void indicator_plane(RectList& L, int n, int gx, int gy, float other_val, float* out) {
+  const int tid = threadIdx.x;
+  // x-edges of the participating rectangles, rank-sorted in parallel (ties by index)
+  if (tid == 0) {
+    int m = 0;
+    for (int j = 0; j < n; ++j) m += L.kind[j] ? 2 : 0;
+    L.n_edges = m;
+  }
+  __syncthreads();
+  if (tid < 2 * n) {
+    const int j = tid >> 1;
+    if (L.kind[j]) {
+      const int v = L.r[j][2 + (tid & 1)];
+      int rank = 0;
+      for (int k = 0; k < 2 * n; ++k) {
+        if (!L.kind[k >> 1]) continue;
+        const int w = L.r[k >> 1][2 + (k & 1)];
+        rank += (w < v || (w == v && k < tid)) ? 1 : 0;
       }
-      const float w0 = rows.w0[r], w1 = rows.w1[r];
-      float v[PLANES];
-      src(r, col, v);
-#pragma unroll
-      for (int p = 0; p < PLANES; ++p) { a0[p] += w0 * v[p]; a1[p] += w1 * v[p]; }
-    }
-    while (cur < IPPM_FEAT) {
-#pragma unroll
-      for (int p = 0; p < PLANES; ++p) { colsum[(p * IPPM_FEAT + cur) * n_cols + col] = a0[p]; a0[p] = a1[p]; a1[p] = 0.f; }
-      ++cur;
+      L.edges[rank] = v;
     }
   }
   __syncthreads();
-  for (int o = threadIdx.x; o < PLANES * IPPM_FEAT * IPPM_FEAT; o += blockDim.x) {
-    const int p = o / (IPPM_FEAT * IPPM_FEAT), ox = (o / IPPM_FEAT) % IPPM_FEAT, oy = o % IPPM_FEAT;
-    const int i0 = oy > 0 ? max(cols.bstart[oy] - 1, 0) : 0;
-    const int i1 = cols.bstart[oy + 1];
-    const float* cs = colsum + (p * IPPM_FEAT + ox) * n_cols;
-    float acc = 0.f;
-    for (int i = i0; i < i1; ++i) {
-      const int b = cols.bin0[i];
-      const float wgt = b == oy ? cols.w0[i] : (b == oy - 1 ? cols.w1[i] : 0.f);
-      acc += wgt * cs[i];
+  const int n_slabs = max(L.n_edges - 1, 0);
+  // per (slab, column bin): signed column measure
+  for (int item = tid; item < n_slabs * IPPM_FEAT; item += blockDim.x) {
+    const int k = item / IPPM_FEAT, by = item % IPPM_FEAT;
+    const int xa = L.edges[k], xb = L.edges[k + 1];
+    int u = 0;
+    if (xb > xa) {
+      const int c0 = (by * gy) / 11, c1 = min(gy, ((by + 1) * gy + 10) / 11);
+      for (int y = c0; y < c1; ++y) {
+        const int nc = overlap11(y, y + 1, by, gy);
+        bool own = false, oth = false;
+        for (int j = 0; j < n; ++j) {
+          if (!L.kind[j]) continue;
+          const bool in = L.r[j][2] <= xa && xb <= L.r[j][3] && y >= L.r[j][0] && y < L.r[j][1];
+          own |= in && L.kind[j] == 1;
+          oth |= in && L.kind[j] == 2;
+        }
+        u += own ? nc : ((oth && other_val != 0.5f) ? (other_val > 0.5f ? nc : -nc) : 0);
+      }
     }
-    out[o] = acc;
+    L.U[k][by] = u;
+  }
+  __syncthreads();
+  const double norm = 0.5 / ((double)gx * (double)gy);
+  for (int o = tid; o < FEAT2; o += blockDim.x) {
+    const int bx = o / IPPM_FEAT, by = o % IPPM_FEAT;
+    long long acc = 0;
+    for (int k = 0; k < n_slabs; ++k) acc += (long long)overlap11(L.edges[k], L.edges[k + 1], bx, gx) * L.U[k][by];
+    out[o] = (float)(0.5 + norm * (double)acc);
   }
   __syncthreads();
 }
-
-struct RectSet {
-  int n;
-  int r[IPPM_MAX_AGENTS][4];  // [yu,yd,xl,xr]
-};
 
 // ------------------------------------------------------------------------------------------------------
 // actor observation [11,11,7] (actor/transformations.py:14-176)
 // ------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_actor_features(const ippm_config* __restrict__ c, const float* __restrict__ local, const uint8_t* __restrict__ code,
-                 const int32_t* __restrict__ rect, const int32_t* __restrict__ pos, const uint8_t* __restrict__ comm,
-                 TabView trows, TabView tcols, const int32_t* __restrict__ tab_i, const float* __restrict__ tab_f0,
-                 const float* __restrict__ tab_f1, const int32_t* __restrict__ fp_off, const int32_t* __restrict__ fp_n,
-                 int t, float* __restrict__ obs, unsigned long long* __restrict__ counters) {
-  extern __shared__ float smem[];
+k_actor_features(const ippm_config* __restrict__ c, const double* __restrict__ area, const uint8_t* __restrict__ code,
+                 const int32_t* __restrict__ rect, const int32_t* __restrict__ pos, const uint8_t* __restrict__ comm, int t,
+                 float* __restrict__ obs) {
   const int n = c->n_agents;
   const int e = blockIdx.x / n, i = blockIdx.x % n;
   const int gx = c->grid_x, gy = c->grid_y, S = c->tile_stride;
-  float* colsum = smem;                               // [2][11][gy] (reused as [1][11][2r] for the footprint image)
-  float* red = smem + 2 * IPPM_FEAT * max(gy, S);     // [2][121]
-  float* red_fp = red + 2 * IPPM_FEAT * IPPM_FEAT;    // [121]
-  __shared__ int s_rect[IPPM_MAX_AGENTS][4];
+  __shared__ RectList L;
   __shared__ int s_recv[IPPM_MAX_AGENTS];
   __shared__ int s_idx[IPPM_MAX_AGENTS][3];
-  if (threadIdx.x < n) {
-    const int j = threadIdx.x;
-    for (int q = 0; q < 4; ++q) s_rect[j][q] = rect[(size_t)(e * n + j) * 4 + q];
-    s_recv[j] = comm[(size_t)(e * n + i) * n + j];
+  __shared__ float s_F[FEAT2];
+  __shared__ int s_c1[FEAT2], s_call[FEAT2];  // footprint image: 11-scaled weight of the "occupied" cells / of all pasted cells
+  const int tid = threadIdx.x;
+  if (tid < n) {
+    const int j = tid;
+    for (int q = 0; q < 4; ++q) L.r[j][q] = rect[(size_t)(e * n + j) * 4 + q];
+    const int rcv = comm[(size_t)(e * n + i) * n + j];
+    s_recv[j] = rcv;
+    L.kind[j] = j == i ? 1 : (rcv ? 2 : 0);
     const int32_t* pj = pos + (size_t)(e * n + j) * 3;
     ippm_pos_to_index(c, pj[0], pj[1], pj[2], s_idx[j][0], s_idx[j][1], s_idx[j][2]);
   }
+  for (int o = tid; o < FEAT2; o += blockDim.x) { s_c1[o] = 0; s_call[o] = 0; }
   __syncthreads();
-  const float* map = local + (size_t)(e * n + i) * gx * gy;
-  // pass 1: plane q = R(local map), plane F = R(footprint indicator)
-  auto src_map = [&](int r, int col, float* v) {
-    v[0] = ippm_sigmoid(map[(size_t)r * gy + col]);  // maps hold log-odds; the resize averages probabilities
-    float f = 0.5f;
-    for (int j = 0; j < n; ++j) {
-      if (j == i || !s_recv[j]) continue;
-      if (r >= s_rect[j][2] && r < s_rect[j][3] && col >= s_rect[j][0] && col < s_rect[j][1]) f = 0.f;
-    }
-    if (r >= s_rect[i][2] && r < s_rect[i][3] && col >= s_rect[i][0] && col < s_rect[i][1]) f = 1.f;
-    v[1] = f;
-  };
-  area_reduce<2>(src_map, trows, tcols, colsum, red);
-  // pass 2: R(footprint_img): unclipped-size image, 0.5 with the measurement pasted at its border-aware offset
-  // (mappings.py:41-43,72-76; utils/utils.py:79-98)
+  // plane 6: 1 where the own measurement lies, 0 where a received other's does (own wins), 0.5 elsewhere (:62-83)
+  indicator_plane(L, n, gx, gy, 0.f, s_F);
+  // plane 4 input: R(footprint_img): the unclipped-size (2r x 2r) image, 0.5 with the measurement pasted at its
+  // border-aware offset (mappings.py:41-43,72-76; utils/utils.py:79-98)
   const int32_t* pi = pos + (size_t)(e * n + i) * 3;
   const int k = ippm_alt_index(c, pi[2]);
   int cl[4], fu[4];
@@ -116,33 +184,49 @@ k_actor_features(const ippm_config* __restrict__ c, const float* __restrict__ lo
   const int full_x = fu[3] - fu[2], full_y = fu[1] - fu[0];
   const int xoff = (cl[2] > fu[2]) ? full_x - hx : 0;
   const int yoff = (cl[0] > fu[0]) ? full_y - wy : 0;
-  const int vec = (gy & 3) == 0 ? 4 : 1;
+  const int vec = (gy & 3) == 0 && gy >= 4 * IPPM_FEAT ? 4 : 1;
   const uint8_t* cd = code + (size_t)(e * n + i) * ippm_tile_bytes(S, vec);
-  const int ycode0 = cl[0] - (cl[0] & ~3);
-  const float mv0 = c->meas_value[k][0], mv1 = c->meas_value[k][1];
-  TabView tfp;
-  tfp.n = fp_n[k];
-  tfp.bin0 = tab_i + fp_off[k];
-  tfp.w0 = tab_f0 + fp_off[k];
-  tfp.w1 = tab_f1 + fp_off[k];
-  tfp.bstart = tab_i + fp_off[k] + tfp.n;
-  auto src_fp = [&](int r, int col, float* v) {
-    const int u = r - xoff, w = col - yoff;
-    float val = 0.5f;
-    if (u >= 0 && u < hx && w >= 0 && w < wy) {
-      const int col = w + ycode0;
-      const uint32_t bit = vec == 4 ? (cd[(size_t)u * (S >> 2) + (col >> 2)] >> (col & 3)) & 1u : cd[(size_t)u * S + col];
-      val = bit ? mv1 : mv0;
+  const int ycode0 = cl[0] - (cl[0] & ~3);  // tile column of the first footprint cell
+  const int tile_cols = wy + ycode0;        // tile columns in use
+  const int n_groups = vec == 4 ? (tile_cols + 3) >> 2 : tile_cols;
+  const int per = vec == 4 ? 4 : 1;
+  for (int item = tid; item < IPPM_FEAT * n_groups; item += blockDim.x) {
+    const int a = item / n_groups, gcol = item % n_groups;
+    // image rows overlapping row bin a, restricted to the pasted rows [xoff, xoff + hx)
+    const int u0 = max((a * full_x) / 11, xoff), u1 = min(min(full_x, ((a + 1) * full_x + 10) / 11), xoff + hx);
+    int n1[4] = {0, 0, 0, 0}, nall = 0;
+    for (int ui = u0; ui < u1; ++ui) {
+      const int nr = overlap11(ui, ui + 1, a, full_x);
+      const uint32_t bits = vec == 4 ? cd[(size_t)(ui - xoff) * (S >> 2) + gcol] : cd[(size_t)(ui - xoff) * S + gcol];
+      nall += nr;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) n1[q] += ((bits >> q) & 1u) ? nr : 0;
     }
-    v[0] = val;
-  };
-  area_reduce<1>(src_fp, tfp, tfp, colsum, red_fp);
+    if (nall == 0) continue;
+    for (int q = 0; q < per; ++q) {
+      const int w = gcol * per + q - ycode0;  // footprint column of this tile cell
+      if (w < 0 || w >= wy) continue;
+      const int wi = w + yoff;                // image column
+      const int b0 = (11 * wi) / full_y;
+      const int ncA = min(11, (b0 + 1) * full_y - 11 * wi), ncB = 11 - ncA;
+      atomicAdd(&s_c1[a * IPPM_FEAT + b0], n1[q] * ncA);
+      atomicAdd(&s_call[a * IPPM_FEAT + b0], nall * ncA);
+      if (ncB) {  // (b0 + 1 <= 10 whenever the cell reaches into it)
+        atomicAdd(&s_c1[a * IPPM_FEAT + b0 + 1], n1[q] * ncB);
+        atomicAdd(&s_call[a * IPPM_FEAT + b0 + 1], nall * ncB);
+      }
+    }
+  }
+  __syncthreads();
   // assemble
   const float lo = c->clip_lo, hi = c->clip_hi;
+  const double mv0 = (double)c->meas_value[k][0] - 0.5, mv1 = (double)c->meas_value[k][1] - 0.5;
+  const double inv_img = 1.0 / ((double)full_x * (double)full_y), inv_map = 1.0 / ((double)gx * (double)gy);
   const int Z = c->space_z;
   const int ox = s_idx[i][0], oy = s_idx[i][1], oz = s_idx[i][2];
-  float* out = obs + (size_t)(e * n + i) * IPPM_FEAT * IPPM_FEAT * IPPM_ACTOR_PLANES;
-  for (int o = threadIdx.x; o < IPPM_FEAT * IPPM_FEAT; o += blockDim.x) {
+  const double* am = area + (size_t)(e * (n + 1) + i) * FEAT2;
+  float* out = obs + (size_t)(e * n + i) * FEAT2 * IPPM_ACTOR_PLANES;
+  for (int o = tid; o < FEAT2; o += blockDim.x) {
     const int a = o / IPPM_FEAT, b = o % IPPM_FEAT;
     float pm = 1.f;
     if (ox < 5 && a < 5 - ox) pm = 0.f;
@@ -154,7 +238,8 @@ k_actor_features(const ippm_config* __restrict__ c, const float* __restrict__ lo
       if (j == i || !s_recv[j]) continue;
       if (s_idx[j][0] - ox + 5 == a && s_idx[j][1] - oy + 5 == b) pm = (float)(s_idx[j][2] + 1) / (float)(Z + 1);
     }
-    const float q = red[o], f = red[IPPM_FEAT * IPPM_FEAT + o], fp = red_fp[o];
+    const float q = (float)(am[o] * inv_map);
+    const float fp = (float)(0.5 + (mv1 * (double)s_c1[o] + mv0 * (double)(s_call[o] - s_c1[o])) * inv_img);
     float* dst = out + (size_t)o * IPPM_ACTOR_PLANES;
     dst[0] = (float)(c->budget - t) / (float)c->budget;
     dst[1] = (float)(i + 1) / (float)n;
@@ -162,9 +247,8 @@ k_actor_features(const ippm_config* __restrict__ c, const float* __restrict__ lo
     dst[3] = ippm_weight(q) * ippm_entropy(q, lo, hi);
     dst[4] = ippm_weight(fp) * ippm_entropy(fp, lo, hi);
     dst[5] = ippm_clipf(q, lo, hi);
-    dst[6] = f;
+    dst[6] = s_F[o];
   }
-  if (counters && threadIdx.x == 0) atomicAdd(&counters[(blockIdx.x & (IPPM_COUNTER_SLOTS - 1)) * 8 + 5], (unsigned long long)gx * gy);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -172,62 +256,54 @@ k_actor_features(const ippm_config* __restrict__ c, const float* __restrict__ lo
 // global planes once and writes them for every agent
 // ------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_critic_features(const ippm_config* __restrict__ c, const float* __restrict__ global, const int32_t* __restrict__ rect,
+k_critic_features(const ippm_config* __restrict__ c, const double* __restrict__ area, const int32_t* __restrict__ rect,
                   const int32_t* __restrict__ pos_pre, const int32_t* __restrict__ action, const float* __restrict__ obs,
-                  TabView trows, TabView tcols, float* __restrict__ state, unsigned long long* __restrict__ counters) {
-  extern __shared__ float smem[];
+                  float* __restrict__ state) {
   const int n = c->n_agents;
   const int e = blockIdx.x;
   const int gx = c->grid_x, gy = c->grid_y;
-  float* colsum = smem;
-  float* red = smem + 2 * IPPM_FEAT * gy;
-  __shared__ int s_rect[IPPM_MAX_AGENTS][4];
+  __shared__ RectList L;
   __shared__ int s_idx[IPPM_MAX_AGENTS][3];
   __shared__ int s_act[IPPM_MAX_AGENTS];
-  if (threadIdx.x < n) {
-    const int j = threadIdx.x;
-    for (int q = 0; q < 4; ++q) s_rect[j][q] = rect[(size_t)(e * n + j) * 4 + q];
+  __shared__ float s_F[FEAT2];
+  const int tid = threadIdx.x;
+  if (tid < n) {
+    const int j = tid;
+    for (int q = 0; q < 4; ++q) L.r[j][q] = rect[(size_t)(e * n + j) * 4 + q];
+    L.kind[j] = 2;
     const int32_t* pj = pos_pre + (size_t)(e * n + j) * 3;
     ippm_pos_to_index(c, pj[0], pj[1], pj[2], s_idx[j][0], s_idx[j][1], s_idx[j][2]);
     s_act[j] = action[e * n + j];
   }
   __syncthreads();
-  const float* map = global + (size_t)e * gx * gy;
-  auto src_map = [&](int r, int col, float* v) {
-    v[0] = ippm_sigmoid(map[(size_t)r * gy + col]);
-    float f = 0.5f;
-    for (int j = 0; j < n; ++j)
-      if (r >= s_rect[j][2] && r < s_rect[j][3] && col >= s_rect[j][0] && col < s_rect[j][1]) f = 1.f;
-    v[1] = f;
-  };
-  area_reduce<2>(src_map, trows, tcols, colsum, red);
+  indicator_plane(L, n, gx, gy, 1.f, s_F);  // plane 10: 1 where any agent's measurement lies, else 0.5 (:91-108)
   const float lo = c->clip_lo, hi = c->clip_hi;
   const int Z = c->space_z, A = c->n_actions;
-  const int cellsf = IPPM_FEAT * IPPM_FEAT;
-  for (int w = threadIdx.x; w < n * cellsf; w += blockDim.x) {
-    const int i = w / cellsf, o = w % cellsf;
+  const double inv_map = 1.0 / ((double)gx * (double)gy);
+  const double* am = area + (size_t)(e * (n + 1) + n) * FEAT2;
+  for (int w = tid; w < n * FEAT2; w += blockDim.x) {
+    const int i = w / FEAT2, o = w % FEAT2;
     const int a = o / IPPM_FEAT, b = o % IPPM_FEAT;
-    float pm = 0.f, am = 0.f;
+    float pm = 0.f, am_ = 0.f;
     for (int j = 0; j < n; ++j) {
       if (s_idx[j][0] == a && s_idx[j][1] == b) {
         pm = (float)(s_idx[j][2] + 1) / (float)Z;
-        if (j != i) am = (float)(s_act[j] + 1) / (float)A;
+        if (j != i) am_ = (float)(s_act[j] + 1) / (float)A;
       }
     }
     // "other actions": later agents overwrite earlier ones on a shared cell, the own agent never writes
-    // (handled above: am only changes for j != i, in ascending j)
-    const float q = red[o], f = red[cellsf + o];
-    const float* src = obs + ((size_t)(e * n + i) * cellsf + o) * IPPM_ACTOR_PLANES;
-    float* dst = state + ((size_t)(e * n + i) * cellsf + o) * IPPM_CRITIC_PLANES;
+    // (handled above: am_ only changes for j != i, in ascending j)
+    const float q = (float)(am[o] * inv_map);
+    const float* src = obs + ((size_t)(e * n + i) * FEAT2 + o) * IPPM_ACTOR_PLANES;
+    float* dst = state + ((size_t)(e * n + i) * FEAT2 + o) * IPPM_CRITIC_PLANES;
 #pragma unroll
     for (int p = 0; p < IPPM_ACTOR_PLANES; ++p) dst[p] = src[p];
     dst[7] = pm;
     dst[8] = ippm_weight(q) * ippm_entropy(q, lo, hi);
     dst[9] = ippm_clipf(q, lo, hi);
-    dst[10] = f;
-    dst[11] = am;
+    dst[10] = s_F[o];
+    dst[11] = am_;
   }
-  if (counters && threadIdx.x == 0) atomicAdd(&counters[(blockIdx.x & (IPPM_COUNTER_SLOTS - 1)) * 8 + 5], (unsigned long long)gx * gy);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -256,20 +332,32 @@ k_reward_pair(const ippm_config* __restrict__ c, const float* __restrict__ befor
   if (threadIdx.x < 2) atomicAdd(&out[m * 2 + threadIdx.x], (double)(s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x]));
 }
 
+// ------------------------------------------------------------------------------------------------------
+// calculate_w_entropy on explicit probability arrays (utils/state.py:53-121): per element
+//   grid = clip(p, 1e-4, 0.9999) (get_shannon_entropy clips its argument in place), se = H(grid),
+//   weightings = w(target) with target = p itself ("reward"/"actor"/"global") or the given ground truth ("eval"),
+//   w_entropy = weightings * se
+// ------------------------------------------------------------------------------------------------------
+__global__ void k_entropy_maps(const ippm_config* __restrict__ c, const float* __restrict__ p, const float* __restrict__ target,
+                               float* __restrict__ w_entropy, float* __restrict__ weightings, float* __restrict__ se,
+                               float* __restrict__ grid, size_t n) {
+  const float lo = c->clip_lo, hi = c->clip_hi;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float v = p[i];
+    const float w = ippm_weight(target ? target[i] : v);
+    const float h = ippm_entropy(v, lo, hi);
+    if (w_entropy) w_entropy[i] = w * h;
+    if (weightings) weightings[i] = w;
+    if (se) se[i] = h;
+    if (grid) grid[i] = ippm_clipf(v, lo, hi);
+  }
+}
+
 // ======================================================================================================
 // host API
 // ======================================================================================================
 static inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
-
-static TabView make_view(const ippm_ctx* ctx, int off, int n) {
-  TabView t;
-  t.n = n;
-  t.bin0 = ctx->tab_bin0 + off;
-  t.w0 = ctx->tab_w0 + off;
-  t.w1 = ctx->tab_w1 + off;
-  t.bstart = ctx->tab_bin0 + off + n;
-  return t;
-}
+static inline int grid1(size_t n, int b = 256) { return (int)((n + b - 1) / b); }
 
 static int feature_checks(const ippm_ctx* ctx, const char* who) {
   const ippm_config& c = ctx->cfg;
@@ -285,30 +373,77 @@ static int feature_checks(const ippm_ctx* ctx, const char* who) {
   return 0;
 }
 
-extern "C" int ippm_actor_features(ippm_ctx* ctx, const float* local, const uint8_t* code, const int32_t* rect,
+static int launch_area_sums(const float* maps, double* area, int rows, int cols, int n_maps, int maps_per_env, int slots_per_env,
+                            int slot0, bool sigmoid, hipStream_t st) {
+  const int chunk_rows = 32;
+  dim3 grid((rows + chunk_rows - 1) / chunk_rows, n_maps), block(256);
+  const bool v4 = cols % 4 == 0 && cols >= 4 * IPPM_FEAT && (reinterpret_cast<uintptr_t>(maps) & 15) == 0;
+#define IPPM_AS(V, SG) \
+  hipLaunchKernelGGL((k_area_sums<V, SG>), grid, block, 0, st, maps, area, rows, cols, chunk_rows, maps_per_env, slots_per_env, slot0)
+  if (v4) { if (sigmoid) IPPM_AS(4, true); else IPPM_AS(4, false); }
+  else { if (sigmoid) IPPM_AS(1, true); else IPPM_AS(1, false); }
+#undef IPPM_AS
+  IPPM_LAUNCH_CHECK("area_sums");
+  return 0;
+}
+
+extern "C" int ippm_area_sums(ippm_ctx* ctx, const float* maps, double* area, int32_t n_maps, int32_t maps_per_env, int32_t slot0,
+                              void* stream) {
+  if (!ctx || !maps || !area) { ippm_set_error("ippm_area_sums: null argument"); return -1; }
+  const ippm_config& c = ctx->cfg;
+  if (c.grid_x < IPPM_FEAT || c.grid_y < IPPM_FEAT) { ippm_set_error("ippm_area_sums: grid smaller than 11x11"); return -2; }
+  if (maps_per_env < 1 || slot0 < 0 || slot0 + maps_per_env > c.n_agents + 1 || n_maps % maps_per_env != 0) {
+    ippm_set_error("ippm_area_sums: maps_per_env / slot0 do not fit the [E, N+1, 121] layout");
+    return -1;
+  }
+  if (n_maps <= 0) return 0;
+  // zero the addressed slots (contiguous only when a whole env's slots are rebuilt; do it per env otherwise)
+  const int per = c.n_agents + 1, envs = n_maps / maps_per_env;
+  if (maps_per_env == per) {
+    IPPM_HIP(hipMemsetAsync(area, 0, sizeof(double) * FEAT2 * (size_t)n_maps, S_(stream)));
+  } else {
+    IPPM_HIP(hipMemset2DAsync(area + (size_t)slot0 * FEAT2, sizeof(double) * FEAT2 * per, 0, sizeof(double) * FEAT2 * maps_per_env, envs,
+                              S_(stream)));
+  }
+  return launch_area_sums(maps, area, c.grid_x, c.grid_y, n_maps, maps_per_env, per, slot0, true, S_(stream));
+}
+
+__global__ void k_area_scale(const double* __restrict__ src, float* __restrict__ dst, double scale, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (float)(src[i] * scale);
+}
+
+extern "C" int ippm_area_resize(ippm_ctx* ctx, const float* src, int32_t rows, int32_t cols, float* dst, double* scratch,
+                                int32_t n_arrays, void* stream) {
+  if (!ctx || !src || !dst || !scratch) { ippm_set_error("ippm_area_resize: null argument"); return -1; }
+  if (rows < IPPM_FEAT || cols < IPPM_FEAT) { ippm_set_error("ippm_area_resize: source smaller than 11x11"); return -2; }
+  if (n_arrays <= 0) return 0;
+  IPPM_HIP(hipMemsetAsync(scratch, 0, sizeof(double) * FEAT2 * (size_t)n_arrays, S_(stream)));
+  if (int rc = launch_area_sums(src, scratch, rows, cols, n_arrays, 1, 1, 0, false, S_(stream))) return rc;
+  hipLaunchKernelGGL(k_area_scale, dim3(grid1((size_t)n_arrays * FEAT2)), dim3(256), 0, S_(stream), scratch, dst,
+                     1.0 / ((double)rows * (double)cols), n_arrays * FEAT2);
+  IPPM_LAUNCH_CHECK("area_scale");
+  return 0;
+}
+
+extern "C" int ippm_actor_features(ippm_ctx* ctx, const double* area, const uint8_t* code, const int32_t* rect,
                                    const int32_t* pos, const uint8_t* comm, int32_t t, float* obs, int32_t n_envs,
                                    void* stream) {
-  if (!ctx || !local || !code || !rect || !pos || !comm || !obs) { ippm_set_error("ippm_actor_features: null argument"); return -1; }
+  if (!ctx || !area || !code || !rect || !pos || !comm || !obs) { ippm_set_error("ippm_actor_features: null argument"); return -1; }
   if (int rc = feature_checks(ctx, "ippm_actor_features")) return rc;
-  const ippm_config& c = ctx->cfg;
-  const size_t lds = sizeof(float) * (2 * IPPM_FEAT * (size_t)std::max(c.grid_y, c.tile_stride) + 3 * IPPM_FEAT * IPPM_FEAT);
-  IPPM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_actor_features), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_actor_features, dim3(n_envs * c.n_agents), dim3(256), lds, S_(stream), ctx->dcfg, local, code, rect, pos,
-                     comm, make_view(ctx, ctx->off_rows, c.grid_x), make_view(ctx, ctx->off_cols, c.grid_y), ctx->tab_bin0,
-                     ctx->tab_w0, ctx->tab_w1, ctx->d_fp_off, ctx->d_fp_n, t, obs, ctx->dcounters);
+  if (n_envs <= 0) return 0;
+  hipLaunchKernelGGL(k_actor_features, dim3(n_envs * ctx->cfg.n_agents), dim3(256), 0, S_(stream), ctx->dcfg, area, code, rect, pos,
+                     comm, t, obs);
   IPPM_LAUNCH_CHECK("actor_features");
   return 0;
 }
 
-extern "C" int ippm_critic_features(ippm_ctx* ctx, const float* global, const int32_t* rect, const int32_t* pos_pre,
+extern "C" int ippm_critic_features(ippm_ctx* ctx, const double* area, const int32_t* rect, const int32_t* pos_pre,
                                     const int32_t* action, const float* obs, float* state, int32_t n_envs, void* stream) {
-  if (!ctx || !global || !rect || !pos_pre || !action || !obs || !state) { ippm_set_error("ippm_critic_features: null argument"); return -1; }
+  if (!ctx || !area || !rect || !pos_pre || !action || !obs || !state) { ippm_set_error("ippm_critic_features: null argument"); return -1; }
   if (int rc = feature_checks(ctx, "ippm_critic_features")) return rc;
-  const ippm_config& c = ctx->cfg;
-  const size_t lds = sizeof(float) * (2 * IPPM_FEAT * (size_t)c.grid_y + 2 * IPPM_FEAT * IPPM_FEAT);
-  IPPM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_critic_features), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_critic_features, dim3(n_envs), dim3(256), lds, S_(stream), ctx->dcfg, global, rect, pos_pre, action, obs,
-                     make_view(ctx, ctx->off_rows, c.grid_x), make_view(ctx, ctx->off_cols, c.grid_y), state, ctx->dcounters);
+  if (n_envs <= 0) return 0;
+  hipLaunchKernelGGL(k_critic_features, dim3(n_envs), dim3(256), 0, S_(stream), ctx->dcfg, area, rect, pos_pre, action, obs, state);
   IPPM_LAUNCH_CHECK("critic_features");
   return 0;
 }
@@ -316,11 +451,22 @@ extern "C" int ippm_critic_features(ippm_ctx* ctx, const float* global, const in
 extern "C" int ippm_reward_from_maps(ippm_ctx* ctx, const float* before, const float* after, double* sums, float* reward,
                                      int32_t n_maps, void* stream) {
   if (!ctx || !before || !after || !sums) { ippm_set_error("ippm_reward_from_maps: null argument"); return -1; }
+  if (n_maps <= 0) return 0;
   IPPM_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * n_maps, S_(stream)));
   const size_t cells = (size_t)ctx->cfg.grid_x * ctx->cfg.grid_y;
   const int gxb = (int)std::min<size_t>(32, (cells + 255) / 256);
   hipLaunchKernelGGL(k_reward_pair, dim3(gxb, n_maps), dim3(256), 0, S_(stream), ctx->dcfg, before, after, sums);
   IPPM_LAUNCH_CHECK("reward_pair");
   (void)reward;
+  return 0;
+}
+
+extern "C" int ippm_entropy_maps(ippm_ctx* ctx, const float* prob, const float* target, float* w_entropy, float* weightings,
+                                 float* se, float* grid, int64_t n, void* stream) {
+  if (!ctx || !prob) { ippm_set_error("ippm_entropy_maps: null argument"); return -1; }
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_entropy_maps, dim3(std::min(4096, grid1((size_t)n))), dim3(256), 0, S_(stream), ctx->dcfg, prob, target,
+                     w_entropy, weightings, se, grid, (size_t)n);
+  IPPM_LAUNCH_CHECK("entropy_maps");
   return 0;
 }

@@ -42,29 +42,17 @@
 #define SUM_ACCD 4
 #define SUM_ACCT 5
 
-struct ResizeTab {           // area-average weights of one source length -> 11 bins (each source index
-  const int32_t* bin0;       // overlaps at most two bins when n_src >= 11)
-  const float* w0;
-  const float* w1;
-  int32_t n;
-};
-
 struct ippm_ctx {
   ippm_config cfg;           // host copy
   ippm_config* dcfg;         // device copy
   unsigned long long* dcounters;  // device, IPPM_COUNTER_SLOTS x 8 words (summed into ippm_counters on read)
-  // K6 tables (device): rows (gx), cols (gy), and one per altitude level for the 2r x 2r footprint image
-  int32_t* tab_bin0;
-  float* tab_w0;
-  float* tab_w1;
-  int32_t off_rows, off_cols, off_fp[IPPM_MAX_Z];
-  int32_t n_fp[IPPM_MAX_Z];
-  int32_t* d_fp_off;         // device copies of off_fp / n_fp
-  int32_t* d_fp_n;
   int vec;                   // 4 when grid_y % 4 == 0 (aligned float4 path), else 1
 };
 
 void ippm_set_error(const std::string& msg);
+// k_plan for local (global_maps == 0) or global fusion plans; step_small.hip
+int ippm_launch_plan(ippm_ctx* ctx, const int32_t* rect, const int32_t* pos, const uint8_t* comm, int32_t* ws, int global_maps,
+                     int n_envs, int agent_sel, hipStream_t st);
 int ippm_check_hip(hipError_t err, const char* what);
 #define IPPM_HIP(call)                                       \
   do {                                                       \
@@ -92,7 +80,20 @@ __device__ __forceinline__ float ippm_clipf(float x, float lo, float hi) { retur
 
 // Maps are stored as float32 LOG-ODDS L = ln(p/(1-p)) (DESIGN.md "log-odds storage"): the reference's
 // clip(p, 1e-4, 0.9999) is clamp(L, -lc, +lc) with lc = ln(0.9999/0.0001), its Bayes update is an add.
-__device__ __forceinline__ float ippm_clampl(float l, float lc) { return fminf(fmaxf(l, -lc), lc); }
+// (v_med3_f32: one instruction; fminf(fmaxf()) costs five, three of them NaN canonicalisations)
+__device__ __forceinline__ float ippm_clampl(float l, float lc) { return __builtin_amdgcn_fmed3f(l, -lc, lc); }
+// Per-cell selects on bit masks without compare/select pairs and without ever becoming branches: ippm_bitmask = v_bfe_i32
+// (0 or ~0, hidden from the optimiser so that it is not folded back into a select or hoisted into a saved-exec branch),
+// ippm_blend = v_bfi_b32.
+__device__ __forceinline__ uint32_t ippm_bitmask(uint32_t bits, int q) {
+  uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)bits, q, 1);
+  asm volatile("" : "+v"(m));
+  return m;
+}
+__device__ __forceinline__ float ippm_blend(uint32_t m, float a, float b) {  // m ? a : b, m = 0 or ~0
+  return __uint_as_float((__float_as_uint(a) & m) | (__float_as_uint(b) & ~m));
+}
+__device__ __forceinline__ float ippm_masked(uint32_t m, float a) { return __uint_as_float(__float_as_uint(a) & m); }  // m ? a : +0
 
 // p = 1 - 1/(1+e^L) evaluated as 1/(1+e^-L): accurate relative to p (and e^L-small p) in float32
 __device__ __forceinline__ float ippm_sigmoid(float l) {
@@ -179,6 +180,21 @@ __device__ __forceinline__ void ippm_footprint_rect(const ippm_config* c, int px
   clipped[3] = min(max(xr, 0), gx1);
 }
 
+
+// reward of one env from the sums K5 accumulated (utils/reward.py:25-40,74-82); rolls the running weighted entropy T forward
+__device__ __forceinline__ void ippm_reward_finalize_env(const ippm_config* __restrict__ c, double* __restrict__ sums,
+                                                         float* __restrict__ reward, int e) {
+  double* s = sums + (size_t)e * 8;
+  const double s1 = s[SUM_ACC1];
+  const double s2 = s[SUM_T] + s[SUM_ACCD];
+  s[SUM_S1] = s1;
+  s[SUM_S2] = s2;
+  s[SUM_T] += s[SUM_ACCT];
+  s[SUM_ACC1] = 0; s[SUM_ACCD] = 0; s[SUM_ACCT] = 0;
+  const double cells = (double)c->grid_x * (double)c->grid_y;
+  reward[e * 2] = (float)(22.0 * (s1 / s2) - 0.5);        // utils/reward.py:38-40
+  reward[e * 2 + 1] = (float)(10.0 * (s1 / cells) - 0.17);  // utils/reward.py:37
+}
 
 // ---- legacy NumPy MT19937: first outputs of RandomState(seed) and the masked-rejection bounded draw ----
 #define MT_NOUT 16

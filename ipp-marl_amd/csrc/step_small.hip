@@ -1,0 +1,417 @@
+// Small-state kernels of an env step (gfx950): comm matrix, fusion planning, K1 mask/act/move.
+//
+// None of this touches a map; it is a few hundred bytes per env and pure latency.  Round 1 ran it as five launches per
+// step (plan(global), comm+plan(local), K1, reward finalize, each 5-18 us with 4-11 us gaps).  Here one wavefront per env
+// does all of it in ONE launch (k_plan_step): lanes = agents for the comm rows and the plans, lanes = actions for the
+// mask work of K1, the agent loop of K1 stays serial (agent i is masked against the already-moved j < i).
+#include "ippm_internal.h"
+
+// ======================================================================================================
+// comm matrix
+// ======================================================================================================
+// row i of the comm matrix of env e: bit j set <=> agent i hears agent j (communication_log.py:39-58); also stored as bytes.
+// pos_e = the env's [N,3] positions (global memory or LDS)
+__device__ __forceinline__ uint32_t comm_row(const ippm_config* __restrict__ c, const int64_t* __restrict__ episode,
+                                             const int32_t* pos_e, const float* __restrict__ comm_range,
+                                             const double* __restrict__ draws, uint8_t* __restrict__ comm, int t, int e, int i) {
+  const int n = c->n_agents;
+  const int32_t* pi = pos_e + i * 3;
+  const double range = comm_range ? (double)comm_range[e] : c->comm_range;
+  const int64_t ep = episode ? episode[e] : 0;
+  const uint32_t k0 = (uint32_t)c->philox_seed, k1 = (uint32_t)(c->philox_seed >> 32);
+  const bool lossy = c->failure_rate > 0.0;  // u >= 0 always passes otherwise: the draw (one per ordered pair in the reference) is moot
+  uint32_t row = 0;
+  for (int j = 0; j < n; ++j) {
+    const int32_t* pj = pos_e + j * 3;
+    long long dx = pi[0] - pj[0], dy = pi[1] - pj[1], dz = pi[2] - pj[2];
+    long long d2 = dx * dx + dy * dy + dz * dz;
+    double u = 1.0;
+    if (lossy) {
+      if (draws) u = draws[(size_t)(e * n + i) * n + j];
+      else {
+        Philox4 ph = ippm_philox((uint32_t)j, (uint32_t)ep, ippm_stream_word((uint32_t)i, (uint32_t)t, IPPM_DOMAIN_COMM),
+                                 (uint32_t)(ep >> 32), k0, k1);
+        u = (double)ph.v[0] * (1.0 / 4294967296.0);
+      }
+    }
+    bool ok = d2 == 0;
+    if (d2 > 0) {
+      double dist = sqrt((double)d2);
+      if (dist <= range && u >= c->failure_rate) ok = true;
+    }
+    comm[(size_t)(e * n + i) * n + j] = ok ? 1 : 0;
+    row |= ok ? (1u << j) : 0u;
+  }
+  return row;
+}
+
+__global__ void k_comm(const ippm_config* __restrict__ c, const int64_t* __restrict__ episode,
+                       const int32_t* __restrict__ pos, const float* __restrict__ comm_range,
+                       const double* __restrict__ draws, uint8_t* __restrict__ comm, int t, int n_envs) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = c->n_agents;
+  if (tid >= n_envs * n) return;
+  const int e = tid / n;
+  comm_row(c, episode, pos + (size_t)e * n * 3, comm_range, draws, comm, t, e, tid % n);
+}
+
+// ======================================================================================================
+// fusion planning (one lane per map): builds the ordered op list of K4 / K5 and maintains the
+// deferred-clamp state (the reference's full-grid input clip, applied only where it can matter)
+// ======================================================================================================
+__device__ __forceinline__ void plan_push(int32_t* w, int& nops, int type, int src, int alt, const int32_t* r,
+                                          int& x0, int& x1, int& y0, int& y1) {
+  if (r[3] <= r[2] || r[1] <= r[0]) return;
+  int32_t* op = w + WS_OPS + nops * OP_WORDS;
+  op[OP_TYPE] = type; op[OP_SRC] = src; op[OP_ALT] = alt;
+  op[OP_YU] = r[0]; op[OP_YD] = r[1]; op[OP_XL] = r[2]; op[OP_XR] = r[3];
+  x0 = min(x0, r[2]); x1 = max(x1, r[3]); y0 = min(y0, r[0]); y1 = max(y1, r[1]);
+  ++nops;
+}
+
+// plans map i of env e (i == n: the global map); recv = agents whose measurements map i receives this step
+__device__ __forceinline__ void plan_map(const ippm_config* __restrict__ c, const int32_t* __restrict__ rect,
+                                         const int32_t* pos_e, uint32_t recv, int32_t* __restrict__ ws,
+                                         int global_maps, int e, int i) {
+  const int n = c->n_agents;
+  int32_t* w = ws + (size_t)(e * (n + 1) + i) * IPPM_WS_WORDS;
+  int nops = 0, x0 = 1 << 30, x1 = -1, y0 = 1 << 30, y1 = -1;
+  int last_src = -1;
+  for (int j = 0; j < n; ++j) {
+    bool take = global_maps ? true : (j != i && ((recv >> j) & 1u) != 0);
+    if (take) last_src = j;
+  }
+  int32_t* hdr = w + WS_PLAN;
+  if (last_src < 0) {  // nothing received: the map is untouched; carry possible out-of-range regions forward
+    if (!global_maps && w[WS_FLAG_S]) {
+      const int32_t* ri = rect + (size_t)(e * n + i) * 4;
+      if (w[WS_FLAG_A]) {
+        w[WS_RECT_A + 0] = min(w[WS_RECT_A + 0], ri[0]); w[WS_RECT_A + 1] = max(w[WS_RECT_A + 1], ri[1]);
+        w[WS_RECT_A + 2] = min(w[WS_RECT_A + 2], ri[2]); w[WS_RECT_A + 3] = max(w[WS_RECT_A + 3], ri[3]);
+      } else {
+        for (int q = 0; q < 4; ++q) w[WS_RECT_A + q] = ri[q];
+      }
+      w[WS_FLAG_A] = 1;
+      w[WS_FLAG_S] = 0;
+    }
+    hdr[PL_NOPS] = 0;
+    return;
+  }
+  if (w[WS_FLAG_A]) plan_push(w, nops, 0, -1, 0, w + WS_RECT_A, x0, x1, y0, y1);
+  if (!global_maps && w[WS_FLAG_S]) plan_push(w, nops, 0, -1, 0, rect + (size_t)(e * n + i) * 4, x0, x1, y0, y1);
+  int last_op = -1;
+  for (int j = 0; j < n; ++j) {
+    bool take = global_maps ? true : (j != i && ((recv >> j) & 1u) != 0);
+    if (!take) continue;
+    const int32_t* rj = rect + (size_t)(e * n + j) * 4;
+    int before = nops;
+    plan_push(w, nops, 1, j, ippm_alt_index(c, pos_e[j * 3 + 2]), rj, x0, x1, y0, y1);
+    if (j == last_src) {
+      last_op = nops > before ? nops - 1 : -1;  // an empty last footprint leaves no unclamped outputs
+      for (int q = 0; q < 4; ++q) w[WS_RECT_A + q] = rj[q];
+    }
+  }
+  w[WS_FLAG_A] = 0;  // set again by the fusion kernel if the last op leaves out-of-range values
+  w[WS_FLAG_S] = 0;
+  hdr[PL_NOPS] = nops;
+  hdr[PL_X0] = x0; hdr[PL_X1] = x1; hdr[PL_Y0] = y0; hdr[PL_Y1] = y1;
+  hdr[PL_LAST] = last_op;
+}
+
+__global__ void k_plan(const ippm_config* __restrict__ c, const int32_t* __restrict__ rect,
+                       const int32_t* __restrict__ pos, const uint8_t* __restrict__ comm, int32_t* __restrict__ ws,
+                       int global_maps, int n_envs, int agent_sel) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = c->n_agents;
+  const int per = (global_maps || agent_sel >= 0) ? 1 : n;
+  if (tid >= n_envs * per) return;
+  const int e = tid / per;
+  const int i = global_maps ? n : (agent_sel >= 0 ? agent_sel : tid % n);
+  uint32_t recv = 0;
+  if (!global_maps)
+    for (int j = 0; j < n; ++j) recv |= comm[(size_t)(e * n + i) * n + j] ? (1u << j) : 0u;
+  plan_map(c, rect, pos + (size_t)e * n * 3, recv, ws, global_maps, e, i);
+}
+
+// ======================================================================================================
+// K1: action mask + collision mask + action choice + move
+// ======================================================================================================
+__device__ __forceinline__ void action_offset(int A, int a, int s, int& dx, int& dy, int& dz) {
+  dx = dy = dz = 0;
+  if (A == 4) {
+    if (a == 0) dx = -s; else if (a == 1) dy = -s; else if (a == 2) dy = s; else dx = s;
+  } else if (A == 6) {
+    if (a == 0) dz = s; else if (a == 1) dx = -s; else if (a == 2) dy = -s; else if (a == 3) dy = s;
+    else if (a == 4) dx = s; else dz = -s;
+  } else if (A == 9) {
+    dx = (a / 3 - 1) * s; dy = (a % 3 - 1) * s;
+  } else {  // 27: layer 0 = +z (action_space.py:249-303)
+    int layer = a / 9, c9 = a % 9;
+    dz = (1 - layer) * s; dx = (c9 / 3 - 1) * s; dy = (c9 % 3 - 1) * s;
+  }
+}
+
+// AgentActionSpace.get_action_mask for one action (action_space.py:25-196)
+__device__ __forceinline__ bool action_in_bounds(const ippm_config* c, int a, int px, int py, int pz) {
+  const int A = c->n_actions, s = c->spacing;
+  const int max_alt = c->min_altitude + (c->space_z - 1) * s;
+  int dx, dy, dz;
+  action_offset(A, a, s, dx, dy, dz);
+  const int nx = px + dx, ny = py + dy, nz = pz + dz;
+  bool ok = nx >= 0 && nx <= c->x_dim_m && ny >= 0 && ny <= c->y_dim_m;
+  if (A == 6 || A == 27) ok = ok && nz >= c->min_altitude && nz <= max_alt;
+  if ((A == 9 || A == 27) && dx == 0 && dy == 0 && dz == 0) ok = false;
+  return ok;
+}
+__device__ __forceinline__ uint32_t boundary_mask(const ippm_config* c, int px, int py, int pz) {
+  uint32_t m = 0;
+  for (int a = 0; a < c->n_actions; ++a) m |= action_in_bounds(c, a, px, py, pz) ? (1u << a) : 0u;
+  return m;
+}
+
+// actions zeroed when an already-moved agent sits at lattice offset (dx,dy,dz) (action_space.py:309-589)
+__device__ __forceinline__ uint32_t collision_bits(int A, int dx, int dy, int dz) {
+  if (A == 4) {
+    if (dx == -1 && dy == 0) return 1u; if (dx == 0 && dy == -1) return 2u;
+    if (dx == 0 && dy == 1) return 4u; if (dx == 1 && dy == 0) return 8u;
+    return 0;
+  }
+  if (A == 6) {
+    if (dx == 0 && dy == 0) return (1u << 0) | (1u << 5);
+    if (dx == -1 && dy == 0) return 1u << 1; if (dx == 0 && dy == -1) return 1u << 2;
+    if (dx == 0 && dy == 1) return 1u << 3; if (dx == 1 && dy == 0) return 1u << 4;
+    return 0;
+  }
+  if (dx < -1 || dx > 1 || dy < -1 || dy > 1) return 0;
+  int c9 = (dx + 1) * 3 + (dy + 1);
+  if (A == 9) return (dx == 0 && dy == 0) ? 0u : (1u << c9);
+  if (dz < -1 || dz > 1 || (dx == 0 && dy == 0 && dz == 0)) return 0;
+  if (dx == 0 && dy == 0) return (1u << 4) | (1u << 22);
+  return (1u << c9) | (1u << (c9 + 9)) | (1u << (c9 + 18));
+}
+
+// the order-dependent zeroing rules of apply_collision_mask for one moved agent
+__device__ __forceinline__ uint32_t collide(int A, uint32_t m, uint32_t z) {
+  if (!z) return m;
+  if (A == 6) return __popc(m) > 1 ? (m & ~z) : m;
+  if (A == 9) { m &= ~z; return m == 0 ? z : m; }
+  return m & ~z;
+}
+
+// stand-alone mask query of the drop-in AgentActionSpace (get_action_mask / apply_collision_mask)
+__global__ void k_action_mask(const ippm_config* __restrict__ c, const int32_t* __restrict__ pos,
+                              const int32_t* __restrict__ others, const int32_t* __restrict__ n_others, int max_others,
+                              const uint8_t* __restrict__ mask_in, uint8_t* __restrict__ mask_out,
+                              int32_t* __restrict__ next_pos, int batch) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  const int A = c->n_actions;
+  const int px = pos[b * 3], py = pos[b * 3 + 1], pz = pos[b * 3 + 2];
+  if (next_pos) {  // AgentActionSpace.action_to_position for every action (action_space.py:198-307)
+    for (int a = 0; a < A; ++a) {
+      int dx, dy, dz;
+      action_offset(A, a, c->spacing, dx, dy, dz);
+      int32_t* o = next_pos + ((size_t)b * A + a) * 3;
+      o[0] = px + dx; o[1] = py + dy; o[2] = pz + dz;
+    }
+  }
+  uint32_t m = 0;
+  if (mask_in) { for (int q = 0; q < A; ++q) m |= (mask_in[(size_t)b * A + q] ? 1u : 0u) << q; }
+  else m = boundary_mask(c, px, py, pz);
+  int ix, iy, iz;
+  ippm_pos_to_index(c, px, py, pz, ix, iy, iz);
+  const int no = n_others ? n_others[b] : 0;
+  for (int j = 0; j < no; ++j) {
+    const int32_t* o = others + ((size_t)b * max_others + j) * 3;
+    int jx, jy, jz;
+    ippm_pos_to_index(c, o[0], o[1], o[2], jx, jy, jz);
+    m = collide(A, m, collision_bits(A, jx - ix, jy - iy, jz - iz));
+  }
+  for (int q = 0; q < A; ++q) mask_out[(size_t)b * A + q] = (m >> q) & 1u;
+}
+
+// K1 for one env by one wavefront (blockDim.x == 64).  s_pos: the env's positions in LDS, updated in place.
+// get_action_mask -> apply_collision_mask -> action choice -> action_to_position (action_space.py:25-589,
+// actor/network.py:90-96, coma_wrapper.py:97-104)
+__device__ void k1_env(const ippm_config* __restrict__ c, int64_t ep, int32_t* s_pos, const float* __restrict__ probs_e,
+                       const int32_t* __restrict__ action_in_e, int policy, int t, uint8_t* __restrict__ mask_e,
+                       int32_t* __restrict__ action_e, int32_t* __restrict__ fault_e) {
+  const int n = c->n_agents, A = c->n_actions, s = c->spacing;
+  const int lane = threadIdx.x;
+  const uint32_t k0 = (uint32_t)c->philox_seed, k1 = (uint32_t)(c->philox_seed >> 32);
+  int flt = 0;
+  for (int i = 0; i < n; ++i) {
+    const int px = s_pos[i * 3], py = s_pos[i * 3 + 1], pz = s_pos[i * 3 + 2];
+    // lanes = actions: one ballot gives the boundary mask
+    const uint32_t bmask = (uint32_t)__ballot(lane < A && action_in_bounds(c, lane, px, py, pz));
+    uint32_t m = bmask;
+    int ix, iy, iz;
+    ippm_pos_to_index(c, px, py, pz, ix, iy, iz);
+    for (int j = 0; j < i; ++j) {  // s_pos[j] already holds agent j's post-move position
+      int jx, jy, jz;
+      ippm_pos_to_index(c, s_pos[j * 3], s_pos[j * 3 + 1], s_pos[j * 3 + 2], jx, jy, jz);
+      m = collide(A, m, collision_bits(A, jx - ix, jy - iy, jz - iz));
+    }
+    int a = -1;
+    if (m == 0) {
+      flt |= 1 << i;  // the reference's torch.multinomial raises on an all-zero distribution
+    } else if (policy == 0) {
+      a = action_in_e[i];
+    } else if (policy == 1) {
+      Philox4 ph = ippm_philox(0u, (uint32_t)ep, ippm_stream_word((uint32_t)i, (uint32_t)t, IPPM_DOMAIN_ACTION),
+                               (uint32_t)(ep >> 32), k0, k1);
+      const int kth = (int)__umulhi(ph.v[0], (uint32_t)__popc(m));
+      // the kth valid action: the lane whose bit is set and has kth set bits below it
+      const bool mine = lane < A && ((m >> lane) & 1u) && __popc(m & ((1u << lane) - 1u)) == kth;
+      a = __ffsll((unsigned long long)__ballot(mine)) - 1;
+    } else {
+      const float* pr = probs_e + (size_t)i * A;
+      if (policy == 3) {  // eval: argmax of probs*mask (first maximum)
+        float best = -1.f;
+        for (int q = 0; q < A; ++q) {
+          float v = ((m >> q) & 1u) ? pr[q] : 0.f;
+          if (v > best) { best = v; a = q; }
+        }
+      } else {  // train: inverse CDF over probs*mask, sequential float32 sums without FMA contraction
+        float total = 0.f;
+        for (int q = 0; q < A; ++q) total = __fadd_rn(total, ((m >> q) & 1u) ? pr[q] : 0.f);
+        Philox4 ph = ippm_philox(0u, (uint32_t)ep, ippm_stream_word((uint32_t)i, (uint32_t)t, IPPM_DOMAIN_ACTION),
+                                 (uint32_t)(ep >> 32), k0, k1);
+        const float u = (float)(ph.v[0] >> 8) * (1.0f / 16777216.0f);
+        const float target = __fmul_rn(u, total);
+        float acc = 0.f;
+        int lastv = -1;
+        for (int q = 0; q < A && a < 0; ++q) {
+          float v = ((m >> q) & 1u) ? pr[q] : 0.f;
+          if (v > 0.f) { lastv = q; acc = __fadd_rn(acc, v); if (acc > target) a = q; }
+        }
+        if (a < 0) a = lastv;
+        if (a < 0) flt |= 1 << i;
+      }
+    }
+    if (a < 0 || a >= A) a = bmask ? __ffs(bmask) - 1 : 0;  // keep the state sane: first boundary-valid action
+    int dx, dy, dz;
+    action_offset(A, a, s, dx, dy, dz);
+    __syncthreads();  // every lane has read agent i's old position
+    if (lane == 0) {
+      s_pos[i * 3] = px + dx; s_pos[i * 3 + 1] = py + dy; s_pos[i * 3 + 2] = pz + dz;
+      action_e[i] = a;
+    }
+    if (lane < A) mask_e[(size_t)i * A + lane] = (m >> lane) & 1u;
+    __syncthreads();
+  }
+  if (fault_e && lane == 0) *fault_e = flt;
+}
+
+// ======================================================================================================
+// k_plan_step: everything small of an env step in one launch, one wavefront per env
+//   IPPM_STEP_COMM   comm matrix + local-fusion plans (lanes = agents)
+//   IPPM_STEP_GLOBAL global-fusion plan (lane n)
+//   IPPM_STEP_MOVE   K1 on the same positions, then the footprints of the NEW positions into rect_next, so that K3
+//                    starts with its rectangle in hand instead of a pos -> lattice index -> centre table chain
+// comm and the plans read the pre-move positions (LDS copy taken before K1 writes anything).
+// ======================================================================================================
+__global__ void __launch_bounds__(64)
+k_plan_step(const ippm_config* __restrict__ c, const int64_t* __restrict__ episode, int32_t* __restrict__ pos,
+            const float* __restrict__ comm_range, const double* __restrict__ draws, uint8_t* __restrict__ comm,
+            const int32_t* __restrict__ rect, int32_t* __restrict__ ws, int t, int flags, const float* __restrict__ probs,
+            const int32_t* __restrict__ action_in, int policy, uint8_t* __restrict__ mask, int32_t* __restrict__ action,
+            int32_t* __restrict__ fault, int32_t* __restrict__ rect_next, int agent_sel) {
+  const int e = blockIdx.x, lane = threadIdx.x;
+  const int n = c->n_agents, A = c->n_actions;
+  __shared__ int32_t s_pos[IPPM_MAX_AGENTS * 3];
+  int32_t* pg = pos + (size_t)e * n * 3;
+  if (lane < n * 3) s_pos[lane] = pg[lane];
+  __syncthreads();
+  if ((flags & IPPM_STEP_COMM) && lane < n) {
+    const uint32_t recv = comm_row(c, episode, s_pos, comm_range, draws, comm, t, e, lane);
+    if (agent_sel < 0 || agent_sel == lane) plan_map(c, rect, s_pos, recv, ws, 0, e, lane);
+  }
+  if ((flags & IPPM_STEP_GLOBAL) && lane == n) plan_map(c, rect, s_pos, 0u, ws, 1, e, n);
+  if (flags & IPPM_STEP_MOVE) {
+    __syncthreads();
+    k1_env(c, episode ? episode[e] : 0, s_pos, probs ? probs + (size_t)e * n * A : nullptr,
+           action_in ? action_in + (size_t)e * n : nullptr, policy, t, mask + (size_t)e * n * A, action + (size_t)e * n,
+           fault ? fault + e : nullptr);
+    if (lane < n * 3) pg[lane] = s_pos[lane];
+    if (rect_next && lane < n) {
+      int cl[4];
+      ippm_footprint_rect(c, s_pos[lane * 3], s_pos[lane * 3 + 1], s_pos[lane * 3 + 2], cl, nullptr);
+      int32_t* r = rect_next + (size_t)(e * n + lane) * 4;
+      r[0] = cl[0]; r[1] = cl[1]; r[2] = cl[2]; r[3] = cl[3];
+    }
+  }
+}
+
+// ======================================================================================================
+// host API
+// ======================================================================================================
+static inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int grid1(size_t n, int b = 256) { return (int)((n + b - 1) / b); }
+
+int ippm_launch_plan(ippm_ctx* ctx, const int32_t* rect, const int32_t* pos, const uint8_t* comm, int32_t* ws, int global_maps,
+                     int n_envs, int agent_sel, hipStream_t st) {
+  const int maps = (global_maps || agent_sel >= 0) ? n_envs : n_envs * ctx->cfg.n_agents;
+  if (maps <= 0) return 0;
+  hipLaunchKernelGGL(k_plan, dim3(grid1(maps, 64)), dim3(64), 0, st, ctx->dcfg, rect, pos, comm, ws, global_maps, n_envs, agent_sel);
+  IPPM_LAUNCH_CHECK("plan");
+  return 0;
+}
+
+extern "C" int ippm_comm_matrix(ippm_ctx* ctx, const int64_t* episode, const int32_t* pos, const float* comm_range,
+                                const double* draws, uint8_t* comm, int32_t t, int32_t n_envs, void* stream) {
+  if (!ctx || !pos || !comm) { ippm_set_error("ippm_comm_matrix: null argument"); return -1; }
+  if (!draws && !episode) { ippm_set_error("ippm_comm_matrix: Philox draws need the episode ids"); return -1; }
+  if (n_envs <= 0) return 0;
+  hipLaunchKernelGGL(k_comm, dim3(grid1((size_t)n_envs * ctx->cfg.n_agents)), dim3(256), 0, S_(stream), ctx->dcfg, episode,
+                     pos, comm_range, draws, comm, t, n_envs);
+  IPPM_LAUNCH_CHECK("comm");
+  return 0;
+}
+
+extern "C" int ippm_plan_step(ippm_ctx* ctx, const int64_t* episode, int32_t* pos, const float* comm_range, const double* draws,
+                              uint8_t* comm, const int32_t* rect, int32_t* ws, int32_t t, int32_t flags, const float* probs,
+                              const int32_t* action_in, int32_t policy, uint8_t* mask, int32_t* action, int32_t* fault,
+                              int32_t* rect_next, int32_t n_envs, void* stream) {
+  if (!ctx || !pos) { ippm_set_error("ippm_plan_step: null argument"); return -1; }
+  if ((flags & (IPPM_STEP_COMM | IPPM_STEP_GLOBAL | IPPM_STEP_MOVE)) == 0 || (flags & ~7)) { ippm_set_error("ippm_plan_step: bad flags"); return -1; }
+  if ((flags & IPPM_STEP_COMM) && (!comm || !rect || !ws)) { ippm_set_error("ippm_plan_step: comm/plan needs comm, rect, ws"); return -1; }
+  if ((flags & IPPM_STEP_COMM) && !draws && !episode) { ippm_set_error("ippm_plan_step: Philox draws need the episode ids"); return -1; }
+  if ((flags & IPPM_STEP_GLOBAL) && (!rect || !ws)) { ippm_set_error("ippm_plan_step: global plan needs rect, ws"); return -1; }
+  if (flags & IPPM_STEP_MOVE) {
+    if (!mask || !action) { ippm_set_error("ippm_plan_step: move needs mask, action"); return -1; }
+    if (policy == 0 && !action_in) { ippm_set_error("ippm_plan_step: policy 0 needs action_in"); return -1; }
+    if ((policy == 2 || policy == 3) && !probs) { ippm_set_error("ippm_plan_step: policy 2/3 needs probs"); return -1; }
+    if ((policy == 1 || policy == 2) && !episode) { ippm_set_error("ippm_plan_step: sampling needs episode ids"); return -1; }
+    if (policy < 0 || policy > 3) { ippm_set_error("ippm_plan_step: unknown policy"); return -1; }
+  }
+  if (n_envs <= 0) return 0;
+  hipLaunchKernelGGL(k_plan_step, dim3(n_envs), dim3(64), 0, S_(stream), ctx->dcfg, episode, pos, comm_range, draws, comm, rect, ws,
+                     t, flags, probs, action_in, policy, mask, action, fault, rect_next, -1);
+  IPPM_LAUNCH_CHECK("plan_step");
+  return 0;
+}
+
+extern "C" int ippm_action_mask(ippm_ctx* ctx, const int32_t* pos, const int32_t* others, const int32_t* n_others,
+                                int32_t max_others, const uint8_t* mask_in, uint8_t* mask_out, int32_t* next_pos, int32_t batch,
+                                void* stream) {
+  if (!ctx || !pos || !mask_out) { ippm_set_error("ippm_action_mask: null argument"); return -1; }
+  if (n_others && !others) { ippm_set_error("ippm_action_mask: n_others without others"); return -1; }
+  if (batch <= 0) return 0;
+  hipLaunchKernelGGL(k_action_mask, dim3(grid1(batch, 64)), dim3(64), 0, S_(stream), ctx->dcfg, pos, others, n_others, max_others,
+                     mask_in, mask_out, next_pos, batch);
+  IPPM_LAUNCH_CHECK("action_mask");
+  return 0;
+}
+
+extern "C" int ippm_mask_act_move(ippm_ctx* ctx, const int64_t* episode, int32_t* pos, const float* probs,
+                                  const int32_t* action_in, int32_t policy, int32_t t, uint8_t* mask, int32_t* action,
+                                  int32_t* fault, int32_t n_envs, void* stream) {
+  if (!ctx || !pos || !mask || !action) { ippm_set_error("ippm_mask_act_move: null argument"); return -1; }
+  if (policy == 0 && !action_in) { ippm_set_error("ippm_mask_act_move: policy 0 needs action_in"); return -1; }
+  if ((policy == 2 || policy == 3) && !probs) { ippm_set_error("ippm_mask_act_move: policy 2/3 needs probs"); return -1; }
+  if ((policy == 1 || policy == 2) && !episode) { ippm_set_error("ippm_mask_act_move: sampling needs episode ids"); return -1; }
+  if (policy < 0 || policy > 3) { ippm_set_error("ippm_mask_act_move: unknown policy"); return -1; }
+  return ippm_plan_step(ctx, episode, pos, nullptr, nullptr, nullptr, nullptr, nullptr, t, IPPM_STEP_MOVE, probs, action_in, policy,
+                        mask, action, fault, nullptr, n_envs, stream);
+}

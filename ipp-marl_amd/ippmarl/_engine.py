@@ -37,14 +37,15 @@ class Measurement(np.ndarray):
 
 class EpisodeEngine:
     def __init__(self, params: Dict, episode: int, device: str = "cuda:0", philox_seed: int = _ENGINE_SEED):
-        self.env = VecEnv(params, 1, device=device, philox_seed=philox_seed)
+        # maps of this engine can be replaced from outside (set_local / set_global): the K6 area sums are rebuilt on demand
+        self.env = VecEnv(params, 1, device=device, philox_seed=philox_seed, track_area=False)
         self.d = self.env.d
         self.episode = int(episode)
         env = self.env
         env.episode.fill_(self.episode)
         # truth, start cells, per-episode comm range, prior maps, workspace -- but no sensing yet (agents do that)
         env.ctx.call("ippm_reset_episode", env._p(env.episode), env._p(env.pos), env._p(env.truth), env._p(env.local),
-                     env._p(env.glob), env._p(env.split_pct), env._p(env.comm_range), env._p(env.ws), env._p(env.sums), 1,
+                     env._p(env.glob), env._p(env.split_pct), env._p(env.comm_range), env._p(env.ws), env._p(env.sums), None, 1,
                      env.stream)
         self.start_positions = env.pos[0].cpu().numpy().astype(np.int64)
         self.stage = [0] * self.d.n_agents  # per-agent sensing counter = Philox stage

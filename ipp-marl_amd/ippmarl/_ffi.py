@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IPPMARL_LIB", os.path.join(_HERE, "..", "lib", "libippmarl.so"))
 WS_WORDS = 160
 FEAT, ACTOR_PLANES, CRITIC_PLANES = 11, 7, 12
+STEP_COMM, STEP_GLOBAL, STEP_MOVE = 1, 2, 4   # ippm_plan_step flags
 
 
 class IppmConfig(C.Structure):
@@ -53,11 +54,19 @@ PROTOTYPES = {
     "ippm_ctx_destroy": [P],
     "ippm_sync": [P, P],
     "ippm_read_counters": [P, C.POINTER(IppmCounters), C.c_int, P],
-    "ippm_reset_episode": [P, P, P, P, P, P, P, P, P, P, I32, P],
+    "ippm_reset_episode": [P, P, P, P, P, P, P, P, P, P, P, I32, P],
     "ippm_logodds_to_prob": [P, P, P, I64, P],
     "ippm_prob_to_logodds": [P, P, P, I64, P],
     "ippm_footprint": [P, P, P, P, I32, P],
+    "ippm_stream_copy": [P, P, P, I64, P],
     "ippm_sense_update": [P, P, P, P, P, P, P, P, P, I32, I32, I32, P],
+    "ippm_sense_step": [P, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, P],
+    "ippm_plan_step": [P, P, P, P, P, P, P, P, I32, I32, P, P, I32, P, P, P, P, I32, P],
+    "ippm_fuse_step": [P, P, P, P, P, P, P, I32, P],
+    "ippm_reward_finalize": [P, P, P, I32, P],
+    "ippm_area_sums": [P, P, P, I32, I32, I32, P],
+    "ippm_area_resize": [P, P, I32, I32, P, P, I32, P],
+    "ippm_entropy_maps": [P, P, P, P, P, P, P, I64, P],
     "ippm_comm_matrix": [P, P, P, P, P, P, I32, I32, P],
     "ippm_fuse_local": [P, P, P, P, P, P, P, I32, I32, P],
     "ippm_comm_fuse_local": [P, P, P, P, P, P, P, P, P, P, I32, I32, P],

@@ -17,7 +17,8 @@ def get_network_input(t, global_information, accumulated_map_knowledge, batch_me
     actions = torch.tensor([[int(batch_memory.get(-1, j, "action")) for j in range(n)]], dtype=torch.int32, device=dev)
     obs = torch.stack([batch_memory.get(-1, j, "observation").to(dev).float() for j in range(n)])[None].contiguous()
     state = torch.empty(1, n, 11, 11, 12, dtype=torch.float32, device=dev)
-    env.ctx.call("ippm_critic_features", _ffi.ptr(env.glob), _ffi.ptr(rect_pre), _ffi.ptr(pos_pre), _ffi.ptr(actions), _ffi.ptr(obs),
+    env.rebuild_area(local=False, glob=True)   # the engine's maps can be replaced from outside: sums from scratch
+    env.ctx.call("ippm_critic_features", _ffi.ptr(env.area), _ffi.ptr(rect_pre), _ffi.ptr(pos_pre), _ffi.ptr(actions), _ffi.ptr(obs),
                  _ffi.ptr(state), 1, env.stream)
     out = state[0, agent_id].clone()
     batch_memory.insert(-1, agent_id, state=out)

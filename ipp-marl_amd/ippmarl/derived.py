@@ -118,7 +118,8 @@ class DerivedConstants:
     # ---- packed byte planes (mirror of ippm_internal.h) ---------------------------------------------------------
     @property
     def vec(self) -> int:
-        return 4 if self.grid_y % 4 == 0 else 1
+        # mirror of ippm_ctx_create: 16-byte lane groups need a multiple-of-4 width and at least 4 cells per feature bin
+        return 4 if self.grid_y % 4 == 0 and self.grid_y >= 44 else 1
 
     @property
     def truth_bytes(self) -> int:

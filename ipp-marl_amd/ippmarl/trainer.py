@@ -184,28 +184,43 @@ class COMATrainer:
         return history
 
     # ------------------------------------------------------------------------------------------------
-    def map_metrics(self):
-        """Per-env evaluation metrics of the fused global maps (coma_test.py:84-97,177-196; IG_baseline.py:84-97): mean
-        entropy over the target cells (weights from the ground truth) and F1 of the target class at p > 0.5."""
+    def map_metrics(self, glob: Optional[torch.Tensor] = None):
+        """Per-env evaluation metrics of fused global maps (default: the env's; coma_test.py:84-97,177-196;
+        IG_baseline.py:84-97): mean entropy over the target cells (weights from the ground truth) and F1 of the target
+        class at p > 0.5."""
         env = self.env
+        glob = env.glob if glob is None else glob
         ent = torch.zeros(self.E, dtype=torch.float64, device=self.device)
-        env.ctx.call("ippm_weighted_entropy", env._p(env.glob), env._p(env.truth), 1, _ffi.ptr(ent), self.E, env.stream)
+        env.ctx.call("ippm_weighted_entropy", env._p(glob), env._p(env.truth), 1, _ffi.ptr(ent), self.E, env.stream)
         counts = torch.zeros(self.E, 3, dtype=torch.int64, device=self.device)
-        env.ctx.call("ippm_f1_counts", env._p(env.glob), env._p(env.truth), 1, 0.0, _ffi.ptr(counts), self.E, env.stream)
+        env.ctx.call("ippm_f1_counts", env._p(glob), env._p(env.truth), 1, 0.0, _ffi.ptr(counts), self.E, env.stream)
         tp, fp, fn = counts[:, 0].double(), counts[:, 1].double(), counts[:, 2].double()
         target = (tp + fn).clamp_min(1)
         f1 = torch.where(2 * tp + fp + fn > 0, 2 * tp / (2 * tp + fp + fn).clamp_min(1), torch.zeros_like(tp))
         return ent / target, f1
 
+    def global_map_with_pending(self) -> torch.Tensor:
+        """The global maps with the measurements of the CURRENT positions fused in, as log-odds [E,gx,gy], without touching
+        the env.  The env's own global fusion (K5) lags the sensing by one step (it fuses what was published
+        before the move); the deployment scripts score the map after fusing the fresh measurements
+        (coma_test.py:150-196: ``fuse_map(current_global_map, maps2communicate_list)`` of the new positions)."""
+        env = self.env
+        glob, ws, sums = env.glob.clone(), env.ws.clone(), env.sums.clone()
+        reward = torch.empty_like(env.reward)
+        env.ctx.call("ippm_fuse_global_reward", _ffi.ptr(glob), env._p(env.code), env._p(env.rect), env._p(env.pos), _ffi.ptr(ws),
+                     _ffi.ptr(sums), _ffi.ptr(reward), self.E, env.stream)
+        return glob
+
     def evaluate(self, waves: int = 1) -> Dict[str, object]:
         """Greedy (argmax) deployment of the current actor, the reference's coma_test loop for E envs at once: mean return and
-        the per-step curves of target entropy and F1 (index 0 = before the first step)."""
+        the per-step curves of target entropy and F1.  Index 0 = the prior map, index t+1 = the map holding every
+        measurement up to and including the sensing of step t (coma_test.py:84-97,150-196)."""
         returns, ent_curves, f1_curves = [], [], []
         for _ in range(waves):
             env = self.env
             eps_ids = episode_ids(self.first_episode, self.wave, self.E, self.rank, self.world)
             env.reset(eps_ids)
-            e0, f0 = self.map_metrics()
+            e0, f0 = self.map_metrics()   # reset senses at the start cells, the global map is still the prior
             ents, f1s = [e0.mean().item()], [f0.mean().item()]
             ret = torch.zeros(self.E, device=self.device)
             for t in range(self.T):
@@ -214,7 +229,7 @@ class COMATrainer:
                     probs, _ = self.actor(obs.view(self.E * self.N, 11, 11, 7), self.eps)
                 reward, _, _ = env.steps(t, policy=POLICY_ARGMAX, probs=probs.view(self.E, self.N, self.A))
                 ret += reward[:, 0]
-                e, f = self.map_metrics()
+                e, f = self.map_metrics(self.global_map_with_pending())
                 ents.append(e.mean().item())
                 f1s.append(f.mean().item())
             self.wave += 1

@@ -27,8 +27,28 @@ from .derived import DerivedConstants
 POLICY_EXPLICIT, POLICY_UNIFORM, POLICY_SAMPLE, POLICY_ARGMAX = 0, 1, 2, 3
 
 
+class _Bracket:
+    """HIP-event bracket around one kernel launch on the current stream (only while ``env.profile`` is set)."""
+
+    def __init__(self, env, name):
+        self.env, self.name = env, name
+
+    def __enter__(self):
+        if self.env.profile:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if self.env.profile:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            self.env.events.setdefault(self.name, []).append((self.a, b))
+        return False
+
+
 class VecEnv:
-    def __init__(self, params: Dict, n_envs: int, device: str = "cuda:0", philox_seed: int = 3, terrain: str = "split"):
+    def __init__(self, params: Dict, n_envs: int, device: str = "cuda:0", philox_seed: int = 3, terrain: str = "split",
+                 track_area: bool = True):
         if not torch.cuda.is_available():
             raise _ffi.IppmError("VecEnv needs an AMD GPU (HIP): there is no CPU path for the env step")
         self.params = params
@@ -44,6 +64,7 @@ class VecEnv:
         self.pos = z(E, N, 3, dtype=torch.int32)
         self.pos_pre = z(E, N, 3, dtype=torch.int32)
         self.rect = z(E, N, 4, dtype=torch.int32)
+        self.rect_next = z(E, N, 4, dtype=torch.int32)                # footprints of the post-move positions (K1 -> K3)
         self.truth = z(E, d.truth_bytes, dtype=torch.uint8)           # bit-packed ground truth (1 bit per cell)
         # beliefs are stored as float32 log-odds (0 = prior 0.5); posterior_local()/posterior_global() export p
         self.local = z(E, N, d.grid_x, d.grid_y, dtype=torch.float32)
@@ -58,6 +79,12 @@ class VecEnv:
         self.sums = z(E, 8, dtype=torch.float64)
         self.reward = z(E, 2, dtype=torch.float32)
         self.split_pct = z(E, 2, dtype=torch.int32)
+        # 11x11 area sums of every map (slot N = global): the input of the K6 feature builders.  track_area=True: K3 / K4 /
+        # K5 keep them up to date as they write maps (the batched training path); False: rebuilt by a streaming pass right
+        # before the features are needed (env-only stepping never needs them; the single-env drop-in engine, whose maps
+        # can be replaced from outside, uses this mode).
+        self.track_area = bool(track_area)
+        self.area = z(E, N + 1, _ffi.FEAT * _ffi.FEAT, dtype=torch.float64)
         self.obs = None
         self.state = None
         self.t = 0
@@ -67,12 +94,9 @@ class VecEnv:
             raise ValueError(f"unknown terrain {terrain!r}")
         self.terrain = terrain
         self._field = None
-        # K5 (global fusion + reward) only reads what K3 of the previous step wrote and touches no array K4 / K6 /
-        # the actor use, so it runs on a side stream concurrently with them (both are latency-bound kernels with
-        # spare occupancy); steps() joins before K1.
-        self.overlap = True
-        self.side = torch.cuda.Stream(device=self.device)
-        self._k5_done = None
+        self._pending_t = None   # step whose fusion (K4 + K5) build_observations has already launched
+        self.profile = False     # bracket the big kernels with HIP events (bench.py's roofline legs)
+        self.events: Dict[str, list] = {}
 
     # ------------------------------------------------------------------------------------------------
     @property
@@ -81,6 +105,10 @@ class VecEnv:
 
     def _p(self, t):
         return _ffi.ptr(t)
+
+    @property
+    def _area_arg(self):
+        return self._p(self.area) if self.track_area else None
 
     def state_bytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in vars(self).values() if isinstance(t, torch.Tensor))
@@ -109,6 +137,15 @@ class VecEnv:
         self.ctx.call("ippm_footprint", self._p(pos), self._p(rect), self._p(full), self.E, self.stream)
         return rect, full
 
+    def rebuild_area(self, local: bool = True, glob: bool = True):
+        """Area sums from scratch (streaming pass over the maps): after maps were written from outside, or when the env
+        does not track them."""
+        N = self.d.n_agents
+        if local:
+            self.ctx.call("ippm_area_sums", self._p(self.local), self._p(self.area), self.E * N, N, 0, self.stream)
+        if glob:
+            self.ctx.call("ippm_area_sums", self._p(self.glob), self._p(self.area), self.E, 1, N, self.stream)
+
     # ------------------------------------------------------------------------------------------------
     def reset(self, episodes, truth: Optional[torch.Tensor] = None, start_positions: Optional[torch.Tensor] = None,
               flips: Optional[torch.Tensor] = None, terrain: Optional[str] = None):
@@ -123,8 +160,8 @@ class VecEnv:
         self.ctx.call("ippm_reset_episode", self._p(self.episode), self._p(self.pos),
                       self._p(self.truth) if truth is None and terrain == "split" else None, self._p(self.local),
                       self._p(self.glob),
-                      self._p(self.split_pct), self._p(self.comm_range), self._p(self.ws), self._p(self.sums), self.E,
-                      self.stream)
+                      self._p(self.split_pct), self._p(self.comm_range), self._p(self.ws), self._p(self.sums), self._area_arg,
+                      self.E, self.stream)
         if truth is not None:
             packed = d.pack_truth(torch.as_tensor(truth).cpu().numpy().reshape(self.E, d.grid_x, d.grid_y))
             self.truth.copy_(torch.from_numpy(packed).to(self.device))
@@ -139,70 +176,69 @@ class VecEnv:
         if start_positions is not None:
             self.pos.copy_(torch.as_tensor(start_positions).to(self.device, torch.int32))
         self.t = 0
+        self._pending_t = None
         self.sense(stage=0, flips=flips)
 
-    def sense(self, stage: int, flips: Optional[torch.Tensor] = None, agent: int = -1):
-        """K3 at the current positions (stage 0 = start sensing, t+1 = sensing of step t)."""
-        self.ctx.call("ippm_sense_update", self._p(self.episode), self._p(self.pos), self._p(self.truth), self._p(self.local),
-                      self._p(flips), self._p(self.code), self._p(self.rect), self._p(self.ws), stage, agent, self.E,
-                      self.stream)
+    def sense(self, stage: int, flips: Optional[torch.Tensor] = None, agent: int = -1, close_step: bool = False):
+        """K3 at the current positions (stage 0 = start sensing, t+1 = sensing of step t).  ``close_step``: this is the K3
+        that ends a batched step -- it takes the footprints K1 projected (rect_next) and completes the step's reward."""
+        with _Bracket(self, "sense"):
+            self.ctx.call("ippm_sense_step", self._p(self.episode), self._p(self.pos), self._p(self.truth), self._p(self.local),
+                          self._p(flips), self._p(self.code), self._p(self.rect_next) if close_step else None, self._p(self.rect),
+                          self._p(self.ws), self._area_arg, self._p(self.sums) if close_step else None,
+                          self._p(self.reward) if close_step else None, stage, agent, self.E, self.stream)
 
     def comm_matrix(self, t: int, comm_draws: Optional[torch.Tensor] = None):
         self.ctx.call("ippm_comm_matrix", self._p(self.episode), self._p(self.pos), self._p(self.comm_range),
                       self._p(comm_draws), self._p(self.comm), t, self.E, self.stream)
 
     def fuse_local(self, agent: int = -1):
+        """Stand-alone K4 (drop-in Agent.receive_messages); does not track the area sums."""
         self.ctx.call("ippm_fuse_local", self._p(self.local), self._p(self.code), self._p(self.rect), self._p(self.pos),
                       self._p(self.comm), self._p(self.ws), agent, self.E, self.stream)
 
-    def _launch_k5(self, stream_ptr):
-        self.ctx.call("ippm_fuse_global_reward", self._p(self.glob), self._p(self.code), self._p(self.rect), self._p(self.pos),
-                      self._p(self.ws), self._p(self.sums), self._p(self.reward), self.E, stream_ptr)
+    def _plan_step(self, t: int, flags: int, comm_draws=None, policy: int = 0, probs=None, actions=None):
+        self.ctx.call("ippm_plan_step", self._p(self.episode), self._p(self.pos), self._p(self.comm_range), self._p(comm_draws),
+                      self._p(self.comm), self._p(self.rect), self._p(self.ws), t, flags, self._p(probs), self._p(actions), policy,
+                      self._p(self.mask), self._p(self.action), self._p(self.fault), self._p(self.rect_next), self.E, self.stream)
 
-    def build_observations(self, t: int, comm_draws: Optional[torch.Tensor] = None, features: bool = True):
-        """comm matrix -> local fusion (K4) -> actor observation [E,N,11,11,7] (K6).  With ``overlap`` the global
-        fusion of the same published measurements (K5, logically the first thing steps() does) is started on the side
-        stream here."""
-        if self.overlap:
-            main = torch.cuda.current_stream(self.device)
-            self.side.wait_stream(main)
-            self._launch_k5(self.side.cuda_stream)
-            self._k5_done = self.side.record_event()
-        # comm matrix + local fusion (one planning kernel for both: ippm_comm_fuse_local)
-        self.ctx.call("ippm_comm_fuse_local", self._p(self.episode), self._p(self.pos), self._p(self.comm_range), self._p(comm_draws),
-                      self._p(self.comm), self._p(self.local), self._p(self.code), self._p(self.rect), self._p(self.ws), t, self.E,
-                      self.stream)
-        if not features:
-            return None
+    def _fuse_step(self):
+        with _Bracket(self, "fuse"):
+            self.ctx.call("ippm_fuse_step", self._p(self.local), self._p(self.glob), self._p(self.code), self._p(self.ws),
+                          self._p(self.sums), self._area_arg, self.E, self.stream)
+
+    def _actor_features(self, t: int):
         if self.obs is None:
             self.obs = torch.empty(self.E, self.d.n_agents, _ffi.FEAT, _ffi.FEAT, _ffi.ACTOR_PLANES, dtype=torch.float32,
                                    device=self.device)
-        self.ctx.call("ippm_actor_features", self._p(self.local), self._p(self.code), self._p(self.rect), self._p(self.pos),
-                      self._p(self.comm), t, self._p(self.obs), self.E, self.stream)
+        if not self.track_area:
+            self.rebuild_area(local=True, glob=False)
+        with _Bracket(self, "actor_features"):
+            self.ctx.call("ippm_actor_features", self._p(self.area), self._p(self.code), self._p(self.rect), self._p(self.pos),
+                          self._p(self.comm), t, self._p(self.obs), self.E, self.stream)
         return self.obs
+
+    def build_observations(self, t: int, comm_draws: Optional[torch.Tensor] = None, features: bool = True):
+        """comm matrix + fusion plans -> local fusion (K4) and global fusion (K5) of the published measurements in one
+        launch -> actor observation [E,N,11,11,7] (K6).  The global fusion is logically the first thing steps() does; it
+        only reads what the previous K3 wrote and nothing here reads the global map, so it shares K4's launch."""
+        if self._pending_t is not None:
+            raise _ffi.IppmError(f"build_observations({t}) called twice without steps({self._pending_t}): the measurements of a "
+                                 "step can be fused only once")
+        self._plan_step(t, _ffi.STEP_COMM | _ffi.STEP_GLOBAL, comm_draws)
+        self._fuse_step()
+        self._pending_t = t
+        return self._actor_features(t) if features else None
 
     def build_features_only(self, t: int):
         """K6 actor features from the current device state (used by the drop-in transformations)."""
-        if self.obs is None:
-            self.obs = torch.empty(self.E, self.d.n_agents, _ffi.FEAT, _ffi.FEAT, _ffi.ACTOR_PLANES, dtype=torch.float32,
-                                   device=self.device)
-        self.ctx.call("ippm_actor_features", self._p(self.local), self._p(self.code), self._p(self.rect), self._p(self.pos),
-                      self._p(self.comm), t, self._p(self.obs), self.E, self.stream)
-        return self.obs
-
-    def _fuse_act_move(self, t: int, policy: int, probs, actions):
-        """K5 (or its join) + K1: everything of steps() that precedes the critic features and the sensing."""
-        if self._k5_done is not None:   # started by build_observations on the side stream
-            torch.cuda.current_stream(self.device).wait_event(self._k5_done)
-            self._k5_done = None
-        else:
-            self._launch_k5(self.stream)
-        self.ctx.call("ippm_mask_act_move", self._p(self.episode), self._p(self.pos), self._p(probs), self._p(actions), policy, t,
-                      self._p(self.mask), self._p(self.action), self._p(self.fault), self.E, self.stream)
+        return self._actor_features(t)
 
     def steps(self, t: int, policy: int = POLICY_UNIFORM, probs: Optional[torch.Tensor] = None,
-              actions: Optional[torch.Tensor] = None, flips: Optional[torch.Tensor] = None, features: bool = True):
-        """K5 (global fusion + reward of the measurements published this step), K1, critic features, K3.
+              actions: Optional[torch.Tensor] = None, flips: Optional[torch.Tensor] = None, features: bool = True,
+              comm_draws: Optional[torch.Tensor] = None):
+        """Global fusion + reward of the measurements published this step (K5; already launched by build_observations),
+        K1, critic features, K3.
 
         Returns (reward [E,2] = (relative, absolute), done: bool, state [E,N,11,11,12] or None)."""
         d = self.d
@@ -212,7 +248,16 @@ class VecEnv:
             probs = probs.to(torch.float32).contiguous()
         if actions is not None:
             actions = actions.to(self.device, torch.int32).contiguous()
-        self._fuse_act_move(t, policy, probs, actions)
+        if self._pending_t is None:   # stepping without observations (env-only): plans + K1 share one launch
+            if policy in (POLICY_SAMPLE, POLICY_ARGMAX):
+                raise _ffi.IppmError("a learned policy needs build_observations() before steps()")
+            self._plan_step(t, _ffi.STEP_COMM | _ffi.STEP_GLOBAL | _ffi.STEP_MOVE, comm_draws, policy, probs, actions)
+            self._fuse_step()
+        else:
+            if self._pending_t != t:
+                raise _ffi.IppmError(f"steps({t}) after build_observations({self._pending_t})")
+            self._plan_step(t, _ffi.STEP_MOVE, None, policy, probs, actions)
+        self._pending_t = None
         state = None
         if features:
             if self.obs is None:
@@ -220,11 +265,14 @@ class VecEnv:
             if self.state is None:
                 self.state = torch.empty(self.E, d.n_agents, _ffi.FEAT, _ffi.FEAT, _ffi.CRITIC_PLANES, dtype=torch.float32,
                                          device=self.device)
+            if not self.track_area:
+                self.rebuild_area(local=False, glob=True)
             # rect still holds the pre-move (published) footprints: K3 below overwrites it
-            self.ctx.call("ippm_critic_features", self._p(self.glob), self._p(self.rect), self._p(self.pos_pre),
-                          self._p(self.action), self._p(self.obs), self._p(self.state), self.E, self.stream)
+            with _Bracket(self, "critic_features"):
+                self.ctx.call("ippm_critic_features", self._p(self.area), self._p(self.rect), self._p(self.pos_pre),
+                              self._p(self.action), self._p(self.obs), self._p(self.state), self.E, self.stream)
             state = self.state
-        self.sense(stage=t + 1, flips=flips)
+        self.sense(stage=t + 1, flips=flips, close_step=True)
         self.t = t + 1
         return self.reward, t == d.budget, state
 
@@ -248,18 +296,19 @@ class VecEnv:
 
     # ---- hipGraph replay of the launch-bound part of a random-policy step ------------------------------------
     def capture_step_graphs(self, policy: int = POLICY_UNIFORM):
-        """Captures, for every t of an episode, the fixed launch sequence {K5 on the side stream || comm + K4} -> K1
-        into a hipGraph (the per-step arguments t / stage are baked in, all arrays are fixed device buffers).  The
-        sensing kernel K3 stays an ordinary launch so that callers can bracket it with events."""
+        """Captures, for every t of an episode, the fixed launch pair {comm + plans + K1} -> {K4 + K5} into a hipGraph (the
+        per-step arguments t / stage are baked in, all arrays are fixed device buffers).  The sensing kernel K3 stays an
+        ordinary launch so that callers can bracket it with events."""
         graphs = []
         torch.cuda.synchronize(self.device)
-        saved = {k: getattr(self, k).clone() for k in ("local", "glob", "ws", "sums", "pos", "comm", "mask", "action", "fault", "reward")}
+        saved = {k: getattr(self, k).clone() for k in ("local", "glob", "ws", "sums", "pos", "comm", "mask", "action", "fault", "reward",
+                                                       "area", "rect_next")}
         capture_stream = torch.cuda.Stream(device=self.device)
         for t in range(self.d.budget + 1):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=capture_stream):
-                self.build_observations(t, features=False)
-                self._fuse_act_move(t, policy, None, None)
+                self._plan_step(t, _ffi.STEP_COMM | _ffi.STEP_GLOBAL | _ffi.STEP_MOVE, None, policy, None, None)
+                self._fuse_step()
             graphs.append(g)
         torch.cuda.synchronize(self.device)
         for k, v in saved.items():   # capture does not execute, but keep the state untouched in any case
@@ -268,13 +317,22 @@ class VecEnv:
         return graphs
 
     def step_graphed(self, t: int):
-        """One random-policy env step: graph replay (comm, K4, K5, K1) + K3."""
+        """One random-policy env step: graph replay (comm, plans, K1, K4, K5) + K3."""
         self._graphs[t].replay()
-        self.sense(stage=t + 1)
+        self.sense(stage=t + 1, close_step=True)
         self.t = t + 1
         return self.reward, t == self.d.budget
 
     # ------------------------------------------------------------------------------------------------
+    def event_times_us(self, clear: bool = True) -> Dict[str, Dict[str, float]]:
+        """{kernel: {"launches", "avg_us"}} of the brackets recorded while ``profile`` was set (synchronises)."""
+        torch.cuda.synchronize(self.device)
+        out = {k: {"launches": len(v), "avg_us": 1e3 * sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1)}
+               for k, v in self.events.items()}
+        if clear:
+            self.events = {}
+        return out
+
     def counters(self, reset: bool = False) -> dict:
         return self.ctx.counters(self.stream, reset)
 

@@ -377,7 +377,7 @@ def test_td_lambda_and_advantage_kernels(golden):
 
 
 def test_graph_replay_matches_eager():
-    """hipGraph replay of {K5 || comm+K4} -> K1 gives bit-identical state to the eager launch sequence."""
+    """hipGraph replay of {comm + plans + K1} -> {K4 + K5} gives bit-identical state to the eager launch sequence."""
     from ippmarl.vec_env import POLICY_UNIFORM
     params = make_params("small")
     a, b = _env(params, 16), _env(params, 16)
@@ -411,9 +411,48 @@ def test_fused_comm_and_plan_equals_separate_calls():
         b.fuse_local()
         assert torch.equal(a.comm, b.comm) and torch.equal(a.local, b.local) and torch.equal(a.ws[:, :-1], b.ws[:, :-1]), t
         a.steps(t, policy=POLICY_UNIFORM, features=False)
-        b._k5_done = None
-        b.steps(t, policy=POLICY_UNIFORM, features=False)
-        assert torch.equal(a.pos, b.pos) and torch.equal(a.glob, b.glob), t
+        # b: the stand-alone K5 entry point (plan + fusion + finalize), then K1 and K3 through the step's own kernels
+        b.ctx.call("ippm_fuse_global_reward", b._p(b.glob), b._p(b.code), b._p(b.rect), b._p(b.pos), b._p(b.ws), b._p(b.sums),
+                   b._p(b.reward), b.E, b.stream)
+        rb = b.reward.clone()
+        b.ctx.call("ippm_mask_act_move", b._p(b.episode), b._p(b.pos), None, None, POLICY_UNIFORM, t, b._p(b.mask), b._p(b.action),
+                   b._p(b.fault), b.E, b.stream)
+        b.sense(stage=t + 1)
+        assert torch.equal(a.pos, b.pos) and torch.equal(a.glob, b.glob) and torch.equal(a.local, b.local), t
+        assert torch.equal(a.reward, rb) and torch.equal(a.rect, b.rect), t
+
+
+@pytest.mark.parametrize("name,over,n_envs", [("small", {}, 6), ("c2", {}, 3), ("default", {"experiment__missions__n_agents": 3}, 2),
+                                              ("small", {"experiment__constraints__num_actions": 27, "experiment__missions__n_agents": 9}, 2)])
+def test_tracked_area_sums_equal_a_streaming_recomputation(name, over, n_envs):
+    """The 11x11 area sums K3 / K4 / K5 maintain incrementally (K6's only view of the maps) against ippm_area_sums' full
+    streaming pass over the same maps after every step, and the streaming pass against NumPy (exact area weights)."""
+    from ippmarl import _ffi
+    from ippmarl.vec_env import POLICY_UNIFORM
+    params = make_params(name, **over)
+    env = _env(params, n_envs, philox_seed=11)
+    d = env.d
+    N, G = d.n_agents, d.grid_x * d.grid_y
+    env.reset(np.arange(40, 40 + n_envs))
+    fresh = torch.zeros_like(env.area)
+
+    def check(tag):
+        env.ctx.call("ippm_area_sums", env._p(env.local), _ffi.ptr(fresh), env.E * N, N, 0, env.stream)
+        env.ctx.call("ippm_area_sums", env._p(env.glob), _ffi.ptr(fresh), env.E, 1, N, env.stream)
+        got, want = env.area.cpu().numpy() / G, fresh.cpu().numpy() / G
+        np.testing.assert_allclose(got, want, rtol=0, atol=3e-7, err_msg=tag)   # area averages lie in [0, 1]
+
+    check("reset")
+    for t in range(d.budget + 1):
+        env.build_observations(t, features=False)
+        check(f"fusion of step {t}")
+        env.steps(t, policy=POLICY_UNIFORM, features=False)
+        check(f"sensing of step {t}")
+    # the streaming pass itself against the exact area average of the exported probabilities
+    W = O.area_weights(d.grid_x, 11), O.area_weights(d.grid_y, 11)
+    p = env.posterior_local().cpu().numpy().astype(np.float64)
+    want = np.einsum("ax,enxy,by->enab", W[0], p, W[1])
+    np.testing.assert_allclose(fresh[:, :N].cpu().numpy().reshape(env.E, N, 11, 11) / G, want, rtol=0, atol=3e-7)
 
 
 def test_c_abi_error_paths():
@@ -424,7 +463,7 @@ def test_c_abi_error_paths():
     lib = _ffi.load_library()
     d = DerivedConstants(make_params("small"))
     # rejected configurations
-    for mutate, needle in ((lambda c: setattr(c, "prior", 0.3), "prior"), (lambda c: setattr(c, "n_agents", 40), "n_agents"),
+    for mutate, needle in ((lambda c: setattr(c, "prior", 1.5), "prior"), (lambda c: setattr(c, "n_agents", 40), "n_agents"),
                            (lambda c: setattr(c, "n_actions", 5), "num_actions"), (lambda c: setattr(c, "tile_stride", 8), "tile_stride")):
         cfg = _ffi.make_config(d)
         mutate(cfg)
