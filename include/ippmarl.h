@@ -203,15 +203,20 @@ int ippm_fuse_global_reward(ippm_ctx* ctx, float* global, const uint8_t* code, c
  *                     rect_next int32 [E,N,4] (optional) = the clipped footprints of the NEW positions for ippm_sense_step.
  *                     Only policies that do not depend on this step's observations (0 explicit, 1 uniform) can share a call
  *                     with COMM/GLOBAL; a learned policy calls MOVE separately after the actor.
+ *   work (optional, int32 [ippm_work_words()]): with COMM | GLOBAL the kernel also lists the non-empty work items of the
+ *   step's fusion (map, run of rows) for ippm_fuse_step.
  * ippm_fuse_step: K4 for all local maps and K5 for all global maps from the plans above, in one launch; keeps `area`
- *   (optional) up to date; leaves the reward sums open (ippm_sense_step or ippm_reward_finalize completes them).
+ *   (optional) up to date; leaves the reward sums open (ippm_sense_step or ippm_reward_finalize completes them).  With the
+ *   `work` list of the same step's ippm_plan_step a fixed number of resident wavefronts strides over exactly the non-empty
+ *   items; without it (NULL) the grid enumerates every (map, run) pair.
  * ippm_reward_finalize: reward[e] = (22*S1/S2 - 0.5, 10*S1/(gx*gy) - 0.17) from the accumulated sums (utils/reward.py:25-40). */
 int ippm_plan_step(ippm_ctx* ctx, const int64_t* episode, int32_t* pos, const float* comm_range, const double* draws,
                    uint8_t* comm, const int32_t* rect, int32_t* ws, int32_t t, int32_t flags, const float* probs,
                    const int32_t* action_in, int32_t policy, uint8_t* mask, int32_t* action, int32_t* fault,
-                   int32_t* rect_next, int32_t n_envs, void* stream);
+                   int32_t* rect_next, int32_t* work, int32_t n_envs, void* stream);
 int ippm_fuse_step(ippm_ctx* ctx, float* local, float* global, const uint8_t* code, int32_t* ws, double* sums, double* area,
-                   int32_t n_envs, void* stream);
+                   const int32_t* work, int32_t n_envs, void* stream);
+int ippm_work_words(ippm_ctx* ctx, int32_t n_envs, int64_t* words); /* length of `work` in int32 words for n_envs envs */
 int ippm_reward_finalize(ippm_ctx* ctx, double* sums, float* reward, int32_t n_envs, void* stream);
 
 /* Full-grid weighted entropy sum(w(p) H(p)) per map (utils/state.py:53-121, "reward" mode); n_maps maps of

@@ -33,8 +33,12 @@ __device__ __forceinline__ int lane_i(int v, int lane) { return __builtin_amdgcn
 __device__ __forceinline__ float lane_f(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 
 struct OpTable {   // lane o holds op o of the plan (zeros beyond the plan: an empty rectangle that never covers anything)
-  int yu, yd, xl, xr, src;
+  int yu, yd;
+  int cs;          // uniform part of the op's code byte offsets (see walk_slab); out of range for ops without bits
   float lm0, lm1;  // log-odds of the two measurement values of a fuse op (0, 0 for a clamp-only op)
+};
+struct SlabTable { // lane s holds slab s of the plan
+  int xa, xb, active, hull;
 };
 
 typedef unsigned ippm_u4 __attribute__((ext_vector_type(4)));
@@ -46,9 +50,7 @@ struct WaveCtx {   // what a wave needs while it walks its rows
   __amdgpu_buffer_rsrc_t map;    // this map: gx * gy floats
   __amdgpu_buffer_rsrc_t code;   // the whole code tensor (lanes outside an op's columns may point anywhere inside it)
   double* s_area;
-  int code_env;                  // byte offset of this env's tiles in `code`
-  int TB;
-  int gx, gy, S, row_bytes;
+  int gx, gy, row_bytes;
   float lc, wt, lp, inv_gx, inv_gy;
   int lane;
   int last_op;
@@ -108,10 +110,9 @@ __device__ __forceinline__ void walk_slab(const WaveCtx& w, const OpTable& t, Wa
   int cshift[NA];      // uniform part of a slot's code byte offset; a huge value (-> out of range, reads 0) for slots without bits
   float lm0[NA], lm1[NA];
   float lpk[NA];       // SHIFT: logit(prior) for the slots that are messages
-  unsigned fm = 0;     // slots that carry a measurement
   int keep_slot = -1;  // slot of the plan's last op: its outputs stay unclamped
-  // Slots beyond the set come FIRST: an empty slot still clips (like every op of the reference), which is a no-op ahead of
-  // the first real op but would wrongly clip the last op's outputs behind it.
+  // Spare slots come FIRST: an empty slot still clips (like every op of the reference), which is a no-op ahead of the
+  // first real op but would wrongly clip the last op's outputs behind it.
   unsigned rem = set;
   const int pad = NA - __popc(set);
 #pragma unroll
@@ -120,18 +121,13 @@ __device__ __forceinline__ void walk_slab(const WaveCtx& w, const OpTable& t, Wa
     rem = k < pad ? rem : (rem & (rem - 1u));
     yu[k] = lane_i(t.yu, idx); yd[k] = lane_i(t.yd, idx);
     lm0[k] = lane_f(t.lm0, idx); lm1[k] = lane_f(t.lm1, idx);
-    const bool isf = idx < 32 && ((w.fusemask >> idx) & 1u);
+    cshift[k] = lane_i(t.cs, idx);
     const bool rin = !SHIFT || (idx < 32 && ((rowin >> idx) & 1u));
-    if (SHIFT && !rin) { yu[k] = 0; yd[k] = 0; }  // a message whose footprint misses these rows: shift only
-    fm |= isf ? (1u << k) : 0u;
-    lpk[k] = SHIFT && isf ? w.lp : 0.f;
-    // byte of cell group (row, y) in the op's tile: tile base + (row - xl) * row_bytes + (y - (yu & ~3)) / VEC'
-    const int y0 = yu[k] & ~3;
-    cshift[k] = isf && rin ? w.code_env + lane_i(t.src, idx) * w.TB - lane_i(t.xl, idx) * w.row_bytes - (VEC == 4 ? (y0 >> 2) : y0)
-                           : 0x7F000000;
+    if (SHIFT && !rin) { yu[k] = 0; yd[k] = 0; cshift[k] = 0x7F000000; }  // a message whose footprint misses these rows: shift only
+    lpk[k] = SHIFT && k >= pad ? w.lp : 0.f;
     keep_slot = (idx == w.last_op) ? k : keep_slot;
   }
-  const RowGeom g = make_geom<VEC>(ya, yb);
+  const RowGeom g = fit_geom<VEC>(ya, yb, xe - x, 1);
   const int sub = w.lane >> g.shift, gl = w.lane & (g.lpr - 1);
   // contiguous row block of my sub-row
   const int block = (xe - x + g.rpw - 1) >> (6 - g.shift);
@@ -148,7 +144,7 @@ __device__ __forceinline__ void walk_slab(const WaveCtx& w, const OpTable& t, Wa
 #pragma unroll
       for (int q = 0; q < VEC; ++q) mq |= ((unsigned)(y + q - yu[k]) < (unsigned)(yd[k] - yu[k])) ? (1u << q) : 0u;
       cm[k] = mq;
-      const unsigned inm = SHIFT ? (((fm >> k) & 1u) ? QM : 0u) : mq;
+      const unsigned inm = SHIFT ? (k >= pad ? QM : 0u) : mq;
       touched |= inm;
       ops_here += __popc(inm);
       keepm = (k == keep_slot) ? mq : keepm;
@@ -161,13 +157,18 @@ __device__ __forceinline__ void walk_slab(const WaveCtx& w, const OpTable& t, Wa
     const int ycode = VEC == 4 ? (y >> 2) : y;
     const int ybyte = y * 4, gybyte = w.gy * 4;
     float amax = 0.f;
+#ifdef IPPM_X_NOROWS
+    amax = (float)(cshift[0] + cm[0] + cm[NA - 1]) + lm0[0] + lm1[NA - 1] + (float)keepm;
+    for (int row0 = rs; row0 < rs; row0 += FU) {
+#else
     for (int row0 = rs; row0 < re; row0 += FU) {
+#endif
       // issue every load of FU rows (map cells + one measurement-code byte per slot) before any use
       CellVec<VEC> mvu[FU];
       uint32_t cwu[FU][NA];
 #pragma unroll
       for (int u = 0; u < FU; ++u) {
-        const int row = min(row0 + u, re - 1);  // a lane past its block's end re-reads the last row and writes nothing
+        const int row = min(row0 + u, re - 1);  // past the block's end: the last row again (its results are dropped below)
         mvu[u] = buf_load_cells<VEC>(w.map, row * gybyte + ybyte);
         const int rowoff = row * w.row_bytes + ycode;
 #pragma unroll
@@ -175,8 +176,10 @@ __device__ __forceinline__ void walk_slab(const WaveCtx& w, const OpTable& t, Wa
       }
 #pragma unroll
       for (int u = 0; u < FU; ++u) {
+        // no branch on the row's validity: a row past the block's end stores out of range (dropped by the buffer's bounds
+        // check) and enters the sums with weight 0
+        const bool valid = u == 0 || row0 + u < re;
         const int row = row0 + u;
-        if (row >= re) continue;
         CellVec<VEC>& mv = mvu[u];
         float L[VEC], bsave[VEC];
 #pragma unroll
@@ -185,6 +188,7 @@ __device__ __forceinline__ void walk_slab(const WaveCtx& w, const OpTable& t, Wa
         // grid (mappings.py:110-111), then adds the measurement's log-odds inside its footprint.  So every cell this lane
         // holds may be clipped at every op, covered or not (for an uncovered cell that is the reference's own full-grid
         // clip; the deferred-clamp plan guarantees it is a no-op there); only the addend is masked to the footprint.
+#ifndef IPPM_X_NOCHAIN
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
           const uint32_t cw = cwu[u][k];
@@ -194,6 +198,9 @@ __device__ __forceinline__ void walk_slab(const WaveCtx& w, const OpTable& t, Wa
             L[q] = ippm_clampl(L[q], w.lc) + (SHIFT ? lm - lpk[k] : lm);
           }
         }
+#else
+        for (int k = 0; k < NA; ++k) L[0] += __uint_as_float(cwu[u][k]);
+#endif
         // outputs of the plan's last op stay unclamped (its rectangle is remembered as possibly out of range); every other
         // cell was clipped again by a later op of the reference
         float d[VEC];
@@ -202,23 +209,33 @@ __device__ __forceinline__ void walk_slab(const WaveCtx& w, const OpTable& t, Wa
           const float a = ippm_blend(ippm_bitmask(keepm, q), L[q], ippm_clampl(L[q], w.lc));
           amax = fmaxf(amax, fabsf(a));
           mv.v[q] = a;
-          if (TRACK) d[q] = sigmoid_diff(a, bsave[q]);
+          if (TRACK) d[q] = valid ? sigmoid_diff(a, bsave[q]) : 0.f;
         }
-        buf_store_cells<VEC>(w.map, row * gybyte + ybyte, mv);
-        if (TRACK) area_row<VEC>(acc, w.s_area, ac, row, w.gx, w.inv_gx, d);
+        buf_store_cells<VEC>(w.map, valid ? row * gybyte + ybyte : 0x7FFFFFF0, mv);
+        if (TRACK) area_row<VEC>(acc, w.s_area, ac, min(row, re - 1), w.gx, w.inv_gx, d);
+#ifndef IPPM_X_NOREWARD
         if (w.is_global) {
           // information-gain terms (utils/reward.py:68-82); a cell that received no measurement contributes exact zeros
-          // (same weight, and the entropy clips its argument)
+          // (same weight, and the entropy clips its argument).  Rows whose cells all have weight 0 before and after
+          // (believed free, still believed free) skip the entropies: wave-uniform on spatially coherent terrain.
+          float wa[VEC], wb[VEC], wsum = 0.f;
 #pragma unroll
           for (int q = 0; q < VEC; ++q) {
-            const float b = bsave[q], a = mv.v[q];
-            const float wa = ippm_weight_l(a, w.wt), wb = ippm_weight_l(b, w.wt);
-            const float hb = ippm_entropy_l(b, w.lc), ha = ippm_entropy_l(a, w.lc);
-            acc_out.a1 += wa * (hb - ha);
-            acc_out.aD += (wa - wb) * hb;
-            acc_out.aT += wa * ha - wb * hb;
+            wa[q] = valid ? ippm_weight_l(mv.v[q], w.wt) : 0.f;
+            wb[q] = valid ? ippm_weight_l(bsave[q], w.wt) : 0.f;
+            wsum += wa[q] + wb[q];
+          }
+          if (__any(wsum != 0.f)) {
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+              const float hb = ippm_entropy_l(bsave[q], w.lc), ha = ippm_entropy_l(mv.v[q], w.lc);
+              acc_out.a1 += wa[q] * (hb - ha);
+              acc_out.aD += (wa[q] - wb[q]) * hb;
+              acc_out.aT += wa[q] * ha - wb[q] * hb;
+            }
           }
         }
+#endif
       }
     }
     acc_out.exceed |= amax > w.lc;
@@ -229,58 +246,96 @@ __device__ __forceinline__ void walk_slab(const WaveCtx& w, const OpTable& t, Wa
   }
 }
 
-// NAMAX = plan-size class of the launch (6 / 10 / 18): the row loops compiled in are those for <= NAMAX active ops
+#ifndef IPPM_FU_SMALL
+#define IPPM_FU_SMALL 2  // rows in flight per lane in the row loops for 1-2 active ops
+#endif
+#ifndef IPPM_FU_MID
+#define IPPM_FU_MID 2    // ... for 3-4 active ops
+#endif
+#ifndef IPPM_FU_BIG
+#define IPPM_FU_BIG 1    // ... for more
+#endif
+
+// One work item = (map, run of `wave_rows` consecutive rows of the map's op hull), done by one wavefront.
+// NAMAX = plan-size class of the launch (6 / 10 / 18): the row loops compiled in are those for <= NAMAX active ops.
 template <int VEC, bool TRACK, int NAMAX>
-__global__ void __launch_bounds__(256)
-k_fuse_rows(const ippm_config* __restrict__ c, float* __restrict__ local, float* __restrict__ global,
-            const uint8_t* __restrict__ code, const int32_t* __restrict__ plan_ro, int32_t* __restrict__ ws,
-            double* __restrict__ sums, double* __restrict__ area, unsigned long long* __restrict__ counters,
-            int wave_rows, int chunks, int min_ops, int local_units, int agent_sel, int n_envs_total) {
+__device__ __forceinline__ void fuse_item(const ippm_config* __restrict__ c, float* __restrict__ local, float* __restrict__ global,
+                                          const uint8_t* __restrict__ code, const int32_t* __restrict__ plan_ro,
+                                          int32_t* __restrict__ ws, double* __restrict__ sums, double* __restrict__ area,
+                                          unsigned long long* __restrict__ counters, double* s_area, int wave_rows, int min_ops,
+                                          int n_envs_total, int e, int slot, int chunk, int cslot) {
   const int n = c->n_agents;
-  const int unit = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
-  // units [0, local_units) are local maps ((e,i), or (e, agent_sel)), the rest global maps
-  const bool is_global = unit >= local_units;
-  int e, slot;
-  if (is_global) { e = unit - local_units; slot = n; }
-  else if (agent_sel >= 0) { e = unit; slot = agent_sel; }
-  else { e = unit / n; slot = unit % n; }
+  const bool is_global = slot == n;
   const size_t wbase = (size_t)(e * (n + 1) + slot) * IPPM_WS_WORDS;
+  const int lane = threadIdx.x & 63;
+  // Preamble = ONE memory round trip: the header (scalar) and the op table (lane o = op o; lane l also fetches plan edge l)
+  // are requested before anything is waited for; nothing here depends on a loaded value.
   const int32_t* __restrict__ hdr = plan_ro + wbase + WS_PLAN;
-  const int nops = hdr[PL_NOPS];
-  if (nops > NAMAX || nops < min_ops) return;  // (another launch handles other plan sizes; 0 ops: nothing to do)
+  const int nops = hdr[PL_NOPS], X0 = hdr[PL_X0], X1 = hdr[PL_X1], last_op = hdr[PL_LAST];
+  const int4 oa = *reinterpret_cast<const int4*>(plan_ro + wbase + WS_OPS + min(lane, IPPM_MAX_OPS - 1) * OP_WORDS);
+  const int4 ob = *reinterpret_cast<const int4*>(plan_ro + wbase + WS_OPS + min(lane, IPPM_MAX_OPS - 1) * OP_WORDS + 4);
+  int edge = plan_ro[wbase + WS_OPS + min(lane >> 1, IPPM_MAX_OPS - 1) * OP_WORDS + ((lane & 1) ? OP_XR : OP_XL)];
+  const int gx = c->grid_x, gy = c->grid_y, S = c->tile_stride;
   const bool shift = c->logit_prior != 0.f;
-  const int gx = c->grid_x, gy = c->grid_y;
-  const int X0 = shift ? 0 : hdr[PL_X0], X1 = shift ? gx : hdr[PL_X1];
-  if (X0 + chunk * 4 * wave_rows >= X1) return;
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int r0 = X0 + (chunk * 4 + wv) * wave_rows, r1 = min(X1, r0 + wave_rows);
-  // op table: lane o loads op o
+  if (nops > NAMAX || nops < min_ops) return;  // (another launch handles other plan sizes; 0 ops: nothing to do)
+  const int r0 = X0 + chunk * wave_rows, r1 = min(X1, r0 + wave_rows);
+  if (r0 >= r1) return;
+  const int row_bytes = VEC == 4 ? (S >> 2) : S;
+  const int TB = (int)ippm_tile_bytes(S, VEC);
   OpTable t;
+  int t_xl, t_xr;
   unsigned fusemask;
   {
+    // op record: {type, src, lm0, yu | yd, xl, xr, lm1}
     const bool on = lane < nops;
-    const int32_t* p = plan_ro + wbase + WS_OPS + (on ? lane : 0) * OP_WORDS;
-    const bool isf = on && p[OP_TYPE] != 0;
-    const int alt = on ? p[OP_ALT] : 0;
-    t.yu = on ? p[OP_YU] : 0; t.yd = on ? p[OP_YD] : 0; t.xl = on ? p[OP_XL] : 0; t.xr = on ? p[OP_XR] : 0;
-    t.src = isf ? p[OP_SRC] : 0;
-    t.lm0 = isf ? c->logit_meas[alt][0] : 0.f;
-    t.lm1 = isf ? c->logit_meas[alt][1] : 0.f;
+    const bool isf = on && oa.x != 0;
+    t.yu = on ? oa.w : 0; t.yd = on ? ob.x : 0;
+    t_xl = on ? ob.y : 0; t_xr = on ? ob.z : 0;
+    t.lm0 = isf ? __int_as_float(oa.z) : 0.f;
+    t.lm1 = isf ? __int_as_float(ob.w) : 0.f;
+    // byte of cell group (row, y) in the op's tile = tile base + (row - xl) * row_bytes + (y - (yu & ~3)) / cells per byte
+    //                                              = (row * row_bytes + y / cells per byte)  +  cs
+    const int y0 = oa.w & ~3;
+    t.cs = isf ? (e * n + oa.y) * TB - ob.y * row_bytes - (VEC == 4 ? (y0 >> 2) : y0) : 0x7F000000;
     fusemask = (unsigned)__ballot(isf);
   }
-  __shared__ double s_area[TRACK ? (IPPM_FEAT + 1) * IPPM_AREA_LD : 1];
+  // ---- slab table, built by the whole wavefront at once: the ops are rectangles, so along x the set of ops covering a row
+  // changes only at rectangle edges.  Lane l holds edge l (xl / xr of op l >> 1; prior != 0.5 adds the grid's borders),
+  // ranks it among all edges (ties by lane), the edges are permuted into sorted order, and lane s then owns slab
+  // [sorted s, sorted s+1) and collects the ops covering it.
+  const int n_edges = 2 * nops + (shift ? 2 : 0);
+  if (shift && lane >= 2 * nops) edge = lane == 2 * nops ? 0 : gx;
+  int rank = 0;
+  for (int j = 0; j < n_edges; ++j) {
+    const int ej = lane_i(edge, j);
+    rank += (ej < edge || (ej == edge && j < lane)) ? 1 : 0;
+  }
+  const int sorted = __builtin_amdgcn_ds_permute((lane < n_edges ? rank : lane) << 2, edge);  // lane `rank` receives my edge
+  SlabTable st;
+  st.xa = sorted;
+  st.xb = __builtin_amdgcn_ds_bpermute(min(lane + 1, 63) << 2, sorted);
+  if (lane + 1 >= n_edges) st.xb = st.xa;  // no slab behind the last edge
+  st.active = 0;
+  int hya = gy, hyb = 0;
+  for (int o = 0; o < nops; ++o) {
+    const int oxl = lane_i(t_xl, o), oxr = lane_i(t_xr, o), oyu = lane_i(t.yu, o), oyd = lane_i(t.yd, o);
+    const bool in = oxl <= st.xa && st.xa < oxr && st.xb > st.xa;
+    st.active |= in ? (1 << o) : 0;
+    hya = in ? min(hya, oyu) : hya;
+    hyb = in ? max(hyb, oyd) : hyb;
+  }
+  st.hull = hya | (hyb << 16);
+  const int nslabs = max(n_edges - 1, 0);
   WaveCtx w;
-  w.gx = gx; w.gy = gy; w.S = c->tile_stride;
-  w.row_bytes = VEC == 4 ? (w.S >> 2) : w.S;
-  w.TB = (int)ippm_tile_bytes(w.S, VEC);
+  w.gx = gx; w.gy = gy;
+  w.row_bytes = row_bytes;
   w.map = IPPM_RSRC(is_global ? global + (size_t)e * gx * gy : local + (size_t)(e * n + slot) * gx * gy, (size_t)gx * gy * 4);
-  w.code = IPPM_RSRC(code, (size_t)n_envs_total * n * w.TB);
-  w.code_env = e * n * w.TB;
+  w.code = IPPM_RSRC(code, (size_t)n_envs_total * n * TB);
   w.s_area = s_area;
   w.lc = c->logit_clip; w.wt = c->logit_weight_thr; w.lp = c->logit_prior;
   w.inv_gx = w.inv_gy = 0.f;
   w.lane = lane;
-  w.last_op = hdr[PL_LAST];
+  w.last_op = last_op;
   w.fusemask = fusemask;
   w.is_global = is_global;
   if (TRACK) {
@@ -292,41 +347,33 @@ k_fuse_rows(const ippm_config* __restrict__ c, float* __restrict__ local, float*
   WaveAcc acc;
   acc.exceed = false; acc.a1 = acc.aD = acc.aT = 0.f; acc.cells = acc.opcells = 0;
 
-  int x = r0;
-  while (x < r1) {
-    // ---- slab [x, xe): the ops covering row x, the first row where that set changes, the column hull (all uniform) ----
-    unsigned active = 0;
-    int xe = r1, ya = 1 << 30, yb = 0;
-    for (int o = 0; o < nops; ++o) {
-      const int oxl = lane_i(t.xl, o), oxr = lane_i(t.xr, o);
-      const bool inr = oxl <= x && x < oxr;
-      if (inr) {
-        active |= 1u << o;
-        xe = min(xe, oxr);
-        ya = min(ya, lane_i(t.yu, o));
-        yb = max(yb, lane_i(t.yd, o));
-      } else if (oxl > x) {
-        xe = min(xe, oxl);
-      }
-    }
+  // slabs that intersect my rows [r0, r1): the table is sorted, the first one is found with one ballot
+  int s = __popcll(__ballot(lane < nslabs && st.xb <= r0));
+  for (; s < nslabs; ++s) {
+    const int sxa = lane_i(st.xa, s), sxb = lane_i(st.xb, s);
+    if (sxa >= r1) break;
+    const int x = max(sxa, r0), xe = min(sxb, r1);
+    const unsigned active = (unsigned)lane_i(st.active, s);
+    if (x >= xe) continue;
     if (shift) {
       // every message of the plan takes part in every row; lanes span the whole width
       const int na = __popc(fusemask);
       if (na == 0) break;
-      if (NAMAX <= 6 || na <= 6) walk_slab<VEC, TRACK, true, (NAMAX < 6 ? NAMAX : 6), 2>(w, t, acc, fusemask, active, x, xe, 0, gy);
-      else walk_slab<VEC, TRACK, true, NAMAX, 2>(w, t, acc, fusemask, active, x, xe, 0, gy);
+      if (NAMAX <= 6 || na <= 6) walk_slab<VEC, TRACK, true, (NAMAX < 6 ? NAMAX : 6), 1>(w, t, acc, fusemask, active, x, xe, 0, gy);
+      else walk_slab<VEC, TRACK, true, NAMAX, 1>(w, t, acc, fusemask, active, x, xe, 0, gy);
     } else if (active != 0) {
-      // the row loop compiled for this many ops; the small ones keep 4 rows in flight per lane
+      const int hull = lane_i(st.hull, s);
+      const int ya = hull & 0xFFFF, yb = hull >> 16;
+      // the row loop compiled for this many ops
       const int na = __popc(active);
-      if (na == 1) walk_slab<VEC, TRACK, false, 1, 4>(w, t, acc, active, 0u, x, xe, ya, yb);
-      else if (na == 2) walk_slab<VEC, TRACK, false, 2, 4>(w, t, acc, active, 0u, x, xe, ya, yb);
-      else if (na == 3) walk_slab<VEC, TRACK, false, 3, 2>(w, t, acc, active, 0u, x, xe, ya, yb);
-      else if (na == 4) walk_slab<VEC, TRACK, false, 4, 2>(w, t, acc, active, 0u, x, xe, ya, yb);
-      else if (NAMAX <= 6 || na <= 6) walk_slab<VEC, TRACK, false, (NAMAX < 6 ? NAMAX : 6), 2>(w, t, acc, active, 0u, x, xe, ya, yb);
-      else if (NAMAX <= 10 || na <= 10) walk_slab<VEC, TRACK, false, (NAMAX < 10 ? NAMAX : 10), 2>(w, t, acc, active, 0u, x, xe, ya, yb);
-      else walk_slab<VEC, TRACK, false, NAMAX, 2>(w, t, acc, active, 0u, x, xe, ya, yb);
+      if (na == 1) walk_slab<VEC, TRACK, false, 1, IPPM_FU_SMALL>(w, t, acc, active, 0u, x, xe, ya, yb);
+      else if (na == 2) walk_slab<VEC, TRACK, false, 2, IPPM_FU_SMALL>(w, t, acc, active, 0u, x, xe, ya, yb);
+      else if (na == 3) walk_slab<VEC, TRACK, false, 3, IPPM_FU_MID>(w, t, acc, active, 0u, x, xe, ya, yb);
+      else if (na == 4) walk_slab<VEC, TRACK, false, 4, IPPM_FU_MID>(w, t, acc, active, 0u, x, xe, ya, yb);
+      else if (NAMAX <= 6 || na <= 6) walk_slab<VEC, TRACK, false, (NAMAX < 6 ? NAMAX : 6), IPPM_FU_BIG>(w, t, acc, active, 0u, x, xe, ya, yb);
+      else if (NAMAX <= 10 || na <= 10) walk_slab<VEC, TRACK, false, (NAMAX < 10 ? NAMAX : 10), IPPM_FU_BIG>(w, t, acc, active, 0u, x, xe, ya, yb);
+      else walk_slab<VEC, TRACK, false, NAMAX, IPPM_FU_BIG>(w, t, acc, active, 0u, x, xe, ya, yb);
     }
-    x = xe;
   }
   if (__any(acc.exceed) && lane == 0) ws[wbase + WS_FLAG_A] = 1;
   // wave reduction of the reward terms and work counters: one atomic per wavefront and quantity
@@ -338,14 +385,54 @@ k_fuse_rows(const ippm_config* __restrict__ c, float* __restrict__ local, float*
       if (is_global && sums && v != 0.f) atomicAdd(&sums[(size_t)e * 8 + SUM_ACC1 + lane], (double)v);
     } else if (lane < 5 && counters) {
       const float v = lane == 3 ? fc : fo;
-      const int cslot = (blockIdx.x * 4 + wv) & (IPPM_COUNTER_SLOTS - 1);
-      if (v > 0.f) atomicAdd(&counters[cslot * 8 + (is_global ? 3 : 1) + (lane - 3)], (unsigned long long)v);
+      if (v > 0.f) atomicAdd(&counters[(cslot & (IPPM_COUNTER_SLOTS - 1)) * 8 + (is_global ? 3 : 1) + (lane - 3)], (unsigned long long)v);
     }
     if (TRACK) {
       __syncthreads();
       area_lds_commit(s_area, area + (size_t)(e * (n + 1) + slot) * IPPM_FEAT * IPPM_FEAT);
+      __syncthreads();
     }
   }
+}
+
+// Workgroup = one wavefront.  Two ways to hand out the work items:
+//   work == NULL : the grid enumerates (map, run) pairs, most of which turn out empty (maps that received nothing, runs
+//                  beyond the hull) -- the stand-alone entry points use this;
+//   work != NULL : `work` = {count, items...} written by the plan kernel holds exactly the non-empty items
+//                  (item = map << 8 | run); the launch is a fixed number of wavefronts that stride over the list, so no slot
+//                  is ever spent on an empty item and no "round" of short-lived workgroups has to drain before the next.
+#ifndef IPPM_FUSE_WAVES
+#define IPPM_FUSE_WAVES 4
+#endif
+template <int VEC, bool TRACK, int NAMAX>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(IPPM_FUSE_WAVES, 8)))
+k_fuse_rows(const ippm_config* __restrict__ c, float* __restrict__ local, float* __restrict__ global,
+            const uint8_t* __restrict__ code, const int32_t* __restrict__ plan_ro, int32_t* __restrict__ ws,
+            double* __restrict__ sums, double* __restrict__ area, unsigned long long* __restrict__ counters,
+            const int32_t* __restrict__ work, int wave_rows, int chunks, int min_ops, int local_units, int agent_sel,
+            int n_envs_total, int shard_cap) {
+  __shared__ double s_area[TRACK ? (IPPM_FEAT + 1) * IPPM_AREA_LD : 1];
+  const int n = c->n_agents;
+  if (work) {  // gridDim.x is a multiple of IPPM_WORK_SHARDS: wavefront b serves shard b % SHARDS
+    const int shard = blockIdx.x % IPPM_WORK_SHARDS;
+    const int count = work[shard];
+    const int32_t* items = work + IPPM_WORK_HEADER + (size_t)shard * shard_cap;
+    for (int i = blockIdx.x / IPPM_WORK_SHARDS; i < count; i += gridDim.x / IPPM_WORK_SHARDS) {
+      const int item = items[i];
+      const int m = item >> 8;
+      fuse_item<VEC, TRACK, NAMAX>(c, local, global, code, plan_ro, ws, sums, area, counters, s_area, wave_rows, min_ops, n_envs_total,
+                                   m / (n + 1), m % (n + 1), item & 0xFF, i);
+    }
+    return;
+  }
+  const int unit = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+  // units [0, local_units) are local maps ((e,i), or (e, agent_sel)), the rest global maps
+  int e, slot;
+  if (unit >= local_units) { e = unit - local_units; slot = n; }
+  else if (agent_sel >= 0) { e = unit; slot = agent_sel; }
+  else { e = unit / n; slot = unit % n; }
+  fuse_item<VEC, TRACK, NAMAX>(c, local, global, code, plan_ro, ws, sums, area, counters, s_area, wave_rows, min_ops, n_envs_total, e, slot,
+                               chunk, blockIdx.x);
 }
 
 __global__ void k_reward_finalize(const ippm_config* __restrict__ c, double* __restrict__ sums,
@@ -365,20 +452,28 @@ static int env_int(const char* name, int dflt) {  // tuning knob; the default is
   return v && *v ? atoi(v) : dflt;
 }
 
+int ippm_fuse_wave_rows(const ippm_ctx* ctx) {  // rows per work item; plan (work list) and fusion must agree
+  const int dflt = 32;
+  return std::min(ctx->cfg.grid_x, std::max((ctx->cfg.grid_x + 255) / 256, env_int("IPPM_FUSE_WAVE_ROWS", dflt)));
+}
+
 // One launch per plan-size class (<= 6 ops, 7..10, 11..18); each returns immediately for plans it does not own.
-// local_units / global_units: how many local / global maps.
+// local_units / global_units: how many local / global maps; work: the plan kernel's item list (NULL: enumerate).
 static int launch_fuse(ippm_ctx* ctx, float* local, float* global, const uint8_t* code, int32_t* ws, double* sums, double* area,
-                       int local_units, int global_units, int agent_sel, int n_envs_total, hipStream_t st) {
+                       const int32_t* work, int local_units, int global_units, int agent_sel, int n_envs_total, hipStream_t st) {
   const ippm_config& c = ctx->cfg;
   const int units = local_units + global_units;
   if (units <= 0) return 0;
   const int max_ops = c.n_agents + 1;  // local: 2 clamp-only ops + N-1 messages; global: 1 clamp-only op + N messages
-  const int wave_rows = std::max(1, env_int("IPPM_FUSE_WAVE_ROWS", 16));  // rows per wavefront; a workgroup covers 4x that
-  const int chunks = (c.grid_x + 4 * wave_rows - 1) / (4 * wave_rows);
-  dim3 grid((unsigned)units * chunks), block(256);
+  const int wave_rows = ippm_fuse_wave_rows(ctx);
+  const int chunks = (c.grid_x + wave_rows - 1) / wave_rows;
+  // resident wavefronts of the persistent form: CUs x SIMDs x waves per SIMD the kernel's registers allow
+  const int persist = std::max(64, env_int("IPPM_FUSE_PERSIST", 12288));
+  const int pgrid = std::max(IPPM_WORK_SHARDS, std::min(persist, units * chunks) / IPPM_WORK_SHARDS * IPPM_WORK_SHARDS);
+  dim3 grid(work ? (unsigned)pgrid : (unsigned)units * chunks), block(64);
 #define IPPM_FUSE(V, T, NA, MINOPS)                                                                                  \
   hipLaunchKernelGGL((k_fuse_rows<V, T, NA>), grid, block, 0, st, ctx->dcfg, local, global, code, ws, ws, sums, area, \
-                     ctx->dcounters, wave_rows, chunks, MINOPS, local_units, agent_sel, n_envs_total)
+                     ctx->dcounters, work, wave_rows, chunks, MINOPS, local_units, agent_sel, n_envs_total, ippm_work_shard_cap(ctx, n_envs_total))
 #define IPPM_FUSE_ALL(V, T)                    \
   do {                                         \
     IPPM_FUSE(V, T, 6, 1);                     \
@@ -400,7 +495,7 @@ extern "C" int ippm_fuse_local(ippm_ctx* ctx, float* local, const uint8_t* code,
   if (agent_sel >= ctx->cfg.n_agents) { ippm_set_error("ippm_fuse_local: agent_sel out of range"); return -1; }
   if (int rc = ippm_launch_plan(ctx, rect, pos, comm, ws, 0, n_envs, agent_sel, S_(stream))) return rc;
   const int maps = agent_sel >= 0 ? n_envs : n_envs * ctx->cfg.n_agents;
-  return launch_fuse(ctx, local, nullptr, code, ws, nullptr, nullptr, maps, 0, agent_sel, n_envs, S_(stream));
+  return launch_fuse(ctx, local, nullptr, code, ws, nullptr, nullptr, nullptr, maps, 0, agent_sel, n_envs, S_(stream));
 }
 
 extern "C" int ippm_comm_fuse_local(ippm_ctx* ctx, const int64_t* episode, const int32_t* pos, const float* comm_range,
@@ -409,9 +504,9 @@ extern "C" int ippm_comm_fuse_local(ippm_ctx* ctx, const int64_t* episode, const
   if (!ctx || !pos || !comm || !local || !code || !rect || !ws) { ippm_set_error("ippm_comm_fuse_local: null argument"); return -1; }
   if (!draws && !episode) { ippm_set_error("ippm_comm_fuse_local: Philox draws need the episode ids"); return -1; }
   if (int rc = ippm_plan_step(ctx, episode, const_cast<int32_t*>(pos), comm_range, draws, comm, rect, ws, t, IPPM_STEP_COMM, nullptr,
-                              nullptr, 0, nullptr, nullptr, nullptr, nullptr, n_envs, stream))
+                              nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, n_envs, stream))
     return rc;
-  return launch_fuse(ctx, local, nullptr, code, ws, nullptr, nullptr, n_envs * ctx->cfg.n_agents, 0, -1, n_envs, S_(stream));
+  return launch_fuse(ctx, local, nullptr, code, ws, nullptr, nullptr, nullptr, n_envs * ctx->cfg.n_agents, 0, -1, n_envs, S_(stream));
 }
 
 extern "C" int ippm_reward_finalize(ippm_ctx* ctx, double* sums, float* reward, int32_t n_envs, void* stream) {
@@ -430,12 +525,17 @@ extern "C" int ippm_fuse_global_reward(ippm_ctx* ctx, float* global, const uint8
     return -1;
   }
   if (int rc = ippm_launch_plan(ctx, rect, pos, nullptr, ws, 1, n_envs, -1, S_(stream))) return rc;
-  if (int rc = launch_fuse(ctx, nullptr, global, code, ws, sums, nullptr, 0, n_envs, -1, n_envs, S_(stream))) return rc;
+  if (int rc = launch_fuse(ctx, nullptr, global, code, ws, sums, nullptr, nullptr, 0, n_envs, -1, n_envs, S_(stream))) return rc;
   return ippm_reward_finalize(ctx, sums, reward, n_envs, stream);
 }
 
 extern "C" int ippm_fuse_step(ippm_ctx* ctx, float* local, float* global, const uint8_t* code, int32_t* ws, double* sums,
-                              double* area, int32_t n_envs, void* stream) {
+                              double* area, const int32_t* work, int32_t n_envs, void* stream) {
   if (!ctx || !local || !global || !code || !ws || !sums) { ippm_set_error("ippm_fuse_step: null argument"); return -1; }
-  return launch_fuse(ctx, local, global, code, ws, sums, area, n_envs * ctx->cfg.n_agents, n_envs, -1, n_envs, S_(stream));
+  if (env_int("IPPM_FUSE_SPLIT", 0)) {  // measurement aid: K4 and K5 as two launches, so that a kernel trace shows them apart
+    if (int rc = launch_fuse(ctx, local, global, code, ws, sums, area, nullptr, n_envs * ctx->cfg.n_agents, 0, -1, n_envs, S_(stream))) return rc;
+    return launch_fuse(ctx, local, global, code, ws, sums, area, nullptr, 0, n_envs, -1, n_envs, S_(stream));
+  }
+  return launch_fuse(ctx, local, global, code, ws, sums, area, env_int("IPPM_FUSE_NOWORK", 0) ? nullptr : work,
+                     n_envs * ctx->cfg.n_agents, n_envs, -1, n_envs, S_(stream));
 }

@@ -8,9 +8,9 @@
 #include "ippmarl.h"
 
 // ---- workspace layout: int32 [E, N+1, IPPM_WS_WORDS]; slot N of an env is its global map ------------
-// words 0..7  : persistent deferred-clamp state (DESIGN.md "deferred clamp")
-// words 8..15 : plan header written by the plan kernels
-// words 16..  : op list, 8 words per op
+// words 0..7     : persistent deferred-clamp state (DESIGN.md "deferred clamp")
+// words 8..15    : plan header written by the plan kernels
+// words 16..159  : op list, 8 words per op
 // IPPM_WS_WORDS (160) comes from ippmarl.h
 #define WS_FLAG_A 0   // region A may hold values outside [clip_lo, clip_hi]
 #define WS_RECT_A 1   // .. 1..4 = [yu,yd,xl,xr]
@@ -26,11 +26,12 @@
 #define OP_WORDS 8
 #define OP_TYPE 0     // 0 = clamp only, 1 = fuse measurement
 #define OP_SRC 1      // source agent j of the measurement
-#define OP_ALT 2      // altitude index of j
+#define OP_LM0 2      // float bits: log-odds of the two measurement values at j's altitude (0 for a clamp-only op)
 #define OP_YU 3
 #define OP_YD 4
 #define OP_XL 5
 #define OP_XR 6
+#define OP_LM1 7
 #define IPPM_MAX_OPS (IPPM_MAX_AGENTS + 2)
 #define IPPM_COUNTER_SLOTS 64  // work counters are spread over 64 slots to keep atomics off one address
 
@@ -51,6 +52,12 @@ struct ippm_ctx {
 
 void ippm_set_error(const std::string& msg);
 // k_plan for local (global_maps == 0) or global fusion plans; step_small.hip
+// Fusion work list (int32, caller-owned, ippm_work_words() long): IPPM_WORK_SHARDS counters, then per shard a region of
+// items (map << 8 | run of rows); env e appends to shard e % IPPM_WORK_SHARDS, so no counter sees more than E/16 atomics.
+#define IPPM_WORK_SHARDS 16
+#define IPPM_WORK_HEADER 16
+int ippm_fuse_wave_rows(const ippm_ctx* ctx);          // rows per work item (fuse.hip)
+int ippm_work_shard_cap(const ippm_ctx* ctx, int n_envs);  // items a shard can hold
 int ippm_launch_plan(ippm_ctx* ctx, const int32_t* rect, const int32_t* pos, const uint8_t* comm, int32_t* ws, int global_maps,
                      int n_envs, int agent_sel, hipStream_t st);
 int ippm_check_hip(hipError_t err, const char* what);

@@ -26,6 +26,26 @@ __device__ __forceinline__ RowGeom make_geom(int ya, int yb) {
   g.rpw = 64 >> g.shift;
   return g;
 }
+// Same, but the lanes per row are chosen (8, 16, 32 or 64) to minimise the wavefront-row instructions needed for a segment
+// of `rows` rows handled by `row_slots_per_lane_row` = 64/lpr sub-rows: a 90-cell footprint is 23-24 groups, which fills
+// 72-75 % of a 32-lane row but 96-100 % of three passes with 8 lanes (8 rows per instruction, 128-byte row segments).
+template <int VEC>
+__device__ __forceinline__ RowGeom fit_geom(int ya, int yb, int rows, int waves) {
+  RowGeom g;
+  g.y0 = ya & ~(VEC - 1);
+  g.groups = (yb - g.y0 + VEC - 1) / VEC;
+  int best_shift = 6, best_cost = 1 << 30;
+#pragma unroll
+  for (int sh = 6; sh >= 3; --sh) {  // ties go to the wider row (longer contiguous segments)
+    const int lpr = 1 << sh, slots = (64 >> sh) * waves;
+    const int cost = ((g.groups + lpr - 1) >> sh) * ((rows + slots - 1) / slots);
+    if (cost < best_cost) { best_cost = cost; best_shift = sh; }
+  }
+  g.shift = best_shift;
+  g.lpr = 1 << g.shift;
+  g.rpw = 64 >> g.shift;
+  return g;
+}
 
 template <int VEC>
 struct CellVec {

@@ -59,18 +59,22 @@ __global__ void k_comm(const ippm_config* __restrict__ c, const int64_t* __restr
 // fusion planning (one lane per map): builds the ordered op list of K4 / K5 and maintains the
 // deferred-clamp state (the reference's full-grid input clip, applied only where it can matter)
 // ======================================================================================================
-__device__ __forceinline__ void plan_push(int32_t* w, int& nops, int type, int src, int alt, const int32_t* r,
-                                          int& x0, int& x1, int& y0, int& y1) {
+__device__ __forceinline__ void plan_push(const ippm_config* __restrict__ c, int32_t* w, int& nops, int type, int src, int alt,
+                                          const int32_t* r, int& x0, int& x1, int& y0, int& y1) {
   if (r[3] <= r[2] || r[1] <= r[0]) return;
   int32_t* op = w + WS_OPS + nops * OP_WORDS;
-  op[OP_TYPE] = type; op[OP_SRC] = src; op[OP_ALT] = alt;
+  op[OP_TYPE] = type; op[OP_SRC] = src;
+  // the measurement's log-odds ride in the op record: the fusion kernel needs no dependent table lookup
+  op[OP_LM0] = type ? __float_as_int(c->logit_meas[alt][0]) : 0;
+  op[OP_LM1] = type ? __float_as_int(c->logit_meas[alt][1]) : 0;
   op[OP_YU] = r[0]; op[OP_YD] = r[1]; op[OP_XL] = r[2]; op[OP_XR] = r[3];
   x0 = min(x0, r[2]); x1 = max(x1, r[3]); y0 = min(y0, r[0]); y1 = max(y1, r[1]);
   ++nops;
 }
 
-// plans map i of env e (i == n: the global map); recv = agents whose measurements map i receives this step
-__device__ __forceinline__ void plan_map(const ippm_config* __restrict__ c, const int32_t* __restrict__ rect,
+// plans map i of env e (i == n: the global map); recv = agents whose measurements map i receives this step.
+// Returns the number of rows of the plan's hull (0: nothing to fuse).
+__device__ __forceinline__ int plan_map(const ippm_config* __restrict__ c, const int32_t* __restrict__ rect,
                                          const int32_t* pos_e, uint32_t recv, int32_t* __restrict__ ws,
                                          int global_maps, int e, int i) {
   const int n = c->n_agents;
@@ -82,6 +86,7 @@ __device__ __forceinline__ void plan_map(const ippm_config* __restrict__ c, cons
     if (take) last_src = j;
   }
   int32_t* hdr = w + WS_PLAN;
+  const int whole = c->logit_prior != 0.f;
   if (last_src < 0) {  // nothing received: the map is untouched; carry possible out-of-range regions forward
     if (!global_maps && w[WS_FLAG_S]) {
       const int32_t* ri = rect + (size_t)(e * n + i) * 4;
@@ -95,17 +100,17 @@ __device__ __forceinline__ void plan_map(const ippm_config* __restrict__ c, cons
       w[WS_FLAG_S] = 0;
     }
     hdr[PL_NOPS] = 0;
-    return;
+    return 0;
   }
-  if (w[WS_FLAG_A]) plan_push(w, nops, 0, -1, 0, w + WS_RECT_A, x0, x1, y0, y1);
-  if (!global_maps && w[WS_FLAG_S]) plan_push(w, nops, 0, -1, 0, rect + (size_t)(e * n + i) * 4, x0, x1, y0, y1);
+  if (w[WS_FLAG_A]) plan_push(c, w, nops, 0, -1, 0, w + WS_RECT_A, x0, x1, y0, y1);
+  if (!global_maps && w[WS_FLAG_S]) plan_push(c, w, nops, 0, -1, 0, rect + (size_t)(e * n + i) * 4, x0, x1, y0, y1);
   int last_op = -1;
   for (int j = 0; j < n; ++j) {
     bool take = global_maps ? true : (j != i && ((recv >> j) & 1u) != 0);
     if (!take) continue;
     const int32_t* rj = rect + (size_t)(e * n + j) * 4;
     int before = nops;
-    plan_push(w, nops, 1, j, ippm_alt_index(c, pos_e[j * 3 + 2]), rj, x0, x1, y0, y1);
+    plan_push(c, w, nops, 1, j, ippm_alt_index(c, pos_e[j * 3 + 2]), rj, x0, x1, y0, y1);
     if (j == last_src) {
       last_op = nops > before ? nops - 1 : -1;  // an empty last footprint leaves no unclamped outputs
       for (int q = 0; q < 4; ++q) w[WS_RECT_A + q] = rj[q];
@@ -114,8 +119,10 @@ __device__ __forceinline__ void plan_map(const ippm_config* __restrict__ c, cons
   w[WS_FLAG_A] = 0;  // set again by the fusion kernel if the last op leaves out-of-range values
   w[WS_FLAG_S] = 0;
   hdr[PL_NOPS] = nops;
+  if (whole && nops > 0) { x0 = 0; x1 = c->grid_x; y0 = 0; y1 = c->grid_y; }
   hdr[PL_X0] = x0; hdr[PL_X1] = x1; hdr[PL_Y0] = y0; hdr[PL_Y1] = y1;
   hdr[PL_LAST] = last_op;
+  return nops > 0 ? x1 - x0 : 0;
 }
 
 __global__ void k_plan(const ippm_config* __restrict__ c, const int32_t* __restrict__ rect,
@@ -316,18 +323,37 @@ k_plan_step(const ippm_config* __restrict__ c, const int64_t* __restrict__ episo
             const float* __restrict__ comm_range, const double* __restrict__ draws, uint8_t* __restrict__ comm,
             const int32_t* __restrict__ rect, int32_t* __restrict__ ws, int t, int flags, const float* __restrict__ probs,
             const int32_t* __restrict__ action_in, int policy, uint8_t* __restrict__ mask, int32_t* __restrict__ action,
-            int32_t* __restrict__ fault, int32_t* __restrict__ rect_next, int agent_sel) {
+            int32_t* __restrict__ fault, int32_t* __restrict__ rect_next, int agent_sel, int32_t* __restrict__ work,
+            int wave_rows, int shard_cap) {
   const int e = blockIdx.x, lane = threadIdx.x;
   const int n = c->n_agents, A = c->n_actions;
   __shared__ int32_t s_pos[IPPM_MAX_AGENTS * 3];
   int32_t* pg = pos + (size_t)e * n * 3;
   if (lane < n * 3) s_pos[lane] = pg[lane];
   __syncthreads();
+  int hull_rows = 0;
   if ((flags & IPPM_STEP_COMM) && lane < n) {
     const uint32_t recv = comm_row(c, episode, s_pos, comm_range, draws, comm, t, e, lane);
-    if (agent_sel < 0 || agent_sel == lane) plan_map(c, rect, s_pos, recv, ws, 0, e, lane);
+    if (agent_sel < 0 || agent_sel == lane) hull_rows = plan_map(c, rect, s_pos, recv, ws, 0, e, lane);
   }
-  if ((flags & IPPM_STEP_GLOBAL) && lane == n) plan_map(c, rect, s_pos, 0u, ws, 1, e, n);
+  if ((flags & IPPM_STEP_GLOBAL) && lane == n) hull_rows = plan_map(c, rect, s_pos, 0u, ws, 1, e, n);
+  if (work && (flags & (IPPM_STEP_COMM | IPPM_STEP_GLOBAL))) {
+    // work items of this env's plans: one reservation per wavefront (exclusive scan of the lanes' item counts)
+    const int items = (hull_rows + wave_rows - 1) / wave_rows;
+    int before = 0, total = 0;
+    for (int j = 0; j <= n; ++j) {
+      const int v = __builtin_amdgcn_readlane(items, j);
+      before += j < lane ? v : 0;
+      total += v;
+    }
+    const int shard = e % IPPM_WORK_SHARDS;
+    int base = 0;
+    if (lane == 0 && total > 0) base = atomicAdd(&work[shard], total);
+    base = __builtin_amdgcn_readfirstlane(base);
+    int32_t* dst = work + IPPM_WORK_HEADER + (size_t)shard * shard_cap + base + before;
+    if (lane <= n)
+      for (int k = 0; k < items; ++k) dst[k] = ((e * (n + 1) + lane) << 8) | k;
+  }
   if (flags & IPPM_STEP_MOVE) {
     __syncthreads();
     k1_env(c, episode ? episode[e] : 0, s_pos, probs ? probs + (size_t)e * n * A : nullptr,
@@ -369,10 +395,22 @@ extern "C" int ippm_comm_matrix(ippm_ctx* ctx, const int64_t* episode, const int
   return 0;
 }
 
+int ippm_work_shard_cap(const ippm_ctx* ctx, int n_envs) {
+  const int wave_rows = ippm_fuse_wave_rows(ctx);
+  const int chunks = (ctx->cfg.grid_x + wave_rows - 1) / wave_rows;
+  return ((n_envs + IPPM_WORK_SHARDS - 1) / IPPM_WORK_SHARDS) * (ctx->cfg.n_agents + 1) * chunks;
+}
+
+extern "C" int ippm_work_words(ippm_ctx* ctx, int32_t n_envs, int64_t* words) {
+  if (!ctx || !words || n_envs < 0) { ippm_set_error("ippm_work_words: bad argument"); return -1; }
+  *words = IPPM_WORK_HEADER + (int64_t)IPPM_WORK_SHARDS * ippm_work_shard_cap(ctx, n_envs);
+  return 0;
+}
+
 extern "C" int ippm_plan_step(ippm_ctx* ctx, const int64_t* episode, int32_t* pos, const float* comm_range, const double* draws,
                               uint8_t* comm, const int32_t* rect, int32_t* ws, int32_t t, int32_t flags, const float* probs,
                               const int32_t* action_in, int32_t policy, uint8_t* mask, int32_t* action, int32_t* fault,
-                              int32_t* rect_next, int32_t n_envs, void* stream) {
+                              int32_t* rect_next, int32_t* work, int32_t n_envs, void* stream) {
   if (!ctx || !pos) { ippm_set_error("ippm_plan_step: null argument"); return -1; }
   if ((flags & (IPPM_STEP_COMM | IPPM_STEP_GLOBAL | IPPM_STEP_MOVE)) == 0 || (flags & ~7)) { ippm_set_error("ippm_plan_step: bad flags"); return -1; }
   if ((flags & IPPM_STEP_COMM) && (!comm || !rect || !ws)) { ippm_set_error("ippm_plan_step: comm/plan needs comm, rect, ws"); return -1; }
@@ -386,8 +424,17 @@ extern "C" int ippm_plan_step(ippm_ctx* ctx, const int64_t* episode, int32_t* po
     if (policy < 0 || policy > 3) { ippm_set_error("ippm_plan_step: unknown policy"); return -1; }
   }
   if (n_envs <= 0) return 0;
+  const bool plans = (flags & (IPPM_STEP_COMM | IPPM_STEP_GLOBAL)) != 0;
+  if (work && plans) {
+    if ((flags & (IPPM_STEP_COMM | IPPM_STEP_GLOBAL)) != (IPPM_STEP_COMM | IPPM_STEP_GLOBAL)) {
+      ippm_set_error("ippm_plan_step: the work list is built for local and global plans together");
+      return -1;
+    }
+    IPPM_HIP(hipMemsetAsync(work, 0, sizeof(int32_t) * IPPM_WORK_SHARDS, S_(stream)));
+  }
   hipLaunchKernelGGL(k_plan_step, dim3(n_envs), dim3(64), 0, S_(stream), ctx->dcfg, episode, pos, comm_range, draws, comm, rect, ws,
-                     t, flags, probs, action_in, policy, mask, action, fault, rect_next, -1);
+                     t, flags, probs, action_in, policy, mask, action, fault, rect_next, -1, plans ? work : nullptr,
+                     ippm_fuse_wave_rows(ctx), ippm_work_shard_cap(ctx, n_envs));
   IPPM_LAUNCH_CHECK("plan_step");
   return 0;
 }
@@ -413,5 +460,5 @@ extern "C" int ippm_mask_act_move(ippm_ctx* ctx, const int64_t* episode, int32_t
   if ((policy == 1 || policy == 2) && !episode) { ippm_set_error("ippm_mask_act_move: sampling needs episode ids"); return -1; }
   if (policy < 0 || policy > 3) { ippm_set_error("ippm_mask_act_move: unknown policy"); return -1; }
   return ippm_plan_step(ctx, episode, pos, nullptr, nullptr, nullptr, nullptr, nullptr, t, IPPM_STEP_MOVE, probs, action_in, policy,
-                        mask, action, fault, nullptr, n_envs, stream);
+                        mask, action, fault, nullptr, nullptr, n_envs, stream);
 }

@@ -61,9 +61,10 @@ PROTOTYPES = {
     "ippm_stream_copy": [P, P, P, I64, P],
     "ippm_sense_update": [P, P, P, P, P, P, P, P, P, I32, I32, I32, P],
     "ippm_sense_step": [P, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, P],
-    "ippm_plan_step": [P, P, P, P, P, P, P, P, I32, I32, P, P, I32, P, P, P, P, I32, P],
-    "ippm_fuse_step": [P, P, P, P, P, P, P, I32, P],
+    "ippm_plan_step": [P, P, P, P, P, P, P, P, I32, I32, P, P, I32, P, P, P, P, P, I32, P],
+    "ippm_fuse_step": [P, P, P, P, P, P, P, P, I32, P],
     "ippm_reward_finalize": [P, P, P, I32, P],
+    "ippm_work_words": [P, I32, P],
     "ippm_area_sums": [P, P, P, I32, I32, I32, P],
     "ippm_area_resize": [P, P, I32, I32, P, P, I32, P],
     "ippm_entropy_maps": [P, P, P, P, P, P, P, I64, P],

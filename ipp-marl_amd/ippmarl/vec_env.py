@@ -79,6 +79,11 @@ class VecEnv:
         self.sums = z(E, 8, dtype=torch.float64)
         self.reward = z(E, 2, dtype=torch.float32)
         self.split_pct = z(E, 2, dtype=torch.int32)
+        # work list of a step's fusion: the plan kernel lists the non-empty (map, run of rows) items, the fusion kernel's
+        # resident wavefronts stride over them
+        words = np.zeros(1, dtype=np.int64)
+        self.ctx.call("ippm_work_words", E, words.ctypes.data)
+        self.work = z(int(words[0]), dtype=torch.int32)
         # 11x11 area sums of every map (slot N = global): the input of the K6 feature builders.  track_area=True: K3 / K4 /
         # K5 keep them up to date as they write maps (the batched training path); False: rebuilt by a streaming pass right
         # before the features are needed (env-only stepping never needs them; the single-env drop-in engine, whose maps
@@ -200,12 +205,13 @@ class VecEnv:
     def _plan_step(self, t: int, flags: int, comm_draws=None, policy: int = 0, probs=None, actions=None):
         self.ctx.call("ippm_plan_step", self._p(self.episode), self._p(self.pos), self._p(self.comm_range), self._p(comm_draws),
                       self._p(self.comm), self._p(self.rect), self._p(self.ws), t, flags, self._p(probs), self._p(actions), policy,
-                      self._p(self.mask), self._p(self.action), self._p(self.fault), self._p(self.rect_next), self.E, self.stream)
+                      self._p(self.mask), self._p(self.action), self._p(self.fault), self._p(self.rect_next), self._p(self.work), self.E,
+                      self.stream)
 
     def _fuse_step(self):
         with _Bracket(self, "fuse"):
             self.ctx.call("ippm_fuse_step", self._p(self.local), self._p(self.glob), self._p(self.code), self._p(self.ws),
-                          self._p(self.sums), self._area_arg, self.E, self.stream)
+                          self._p(self.sums), self._area_arg, self._p(self.work), self.E, self.stream)
 
     def _actor_features(self, t: int):
         if self.obs is None:

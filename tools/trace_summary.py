@@ -1,0 +1,16 @@
+#!/usr/bin/env python
+"""Per-(kernel, grid size) duration table from rocprofv3's rocpd sqlite output: python tools/trace_summary.py <db> [min_us]"""
+import sqlite3
+import sys
+
+import pandas as pd
+
+pd.set_option("display.width", 250)
+db = sqlite3.connect(sys.argv[1])
+df = pd.read_sql("select * from kernels", db)
+name = [c for c in df.columns if c in ("name", "kernel_name")][0]
+df["us"] = (df["end"] - df["start"]) / 1e3
+grid = "grid_size" if "grid_size" in df.columns else [c for c in df.columns if "grid" in c][0]
+df["k"] = df[name].str.replace("void ", "").str.slice(0, 44)
+g = df.groupby(["k", grid])["us"].agg(["count", "mean", "min", "max", "sum"]).sort_values("sum", ascending=False)
+print(g[g["sum"] > (float(sys.argv[2]) if len(sys.argv) > 2 else 50)].round(1).to_string())
