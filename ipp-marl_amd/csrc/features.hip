@@ -77,18 +77,32 @@ k_area_sums(const float* __restrict__ maps, double* __restrict__ area, int gx, i
 }
 
 // ------------------------------------------------------------------------------------------------------
-// shared pieces of the two feature kernels
+// shared pieces of the two feature kernels (workgroups of K6_THREADS threads)
 // ------------------------------------------------------------------------------------------------------
+#define K6_THREADS 128
+#define BIN_WORDS 4  // a column bin spans at most ceil(gy/11) + 1 cells: 128-cell masks cover grids up to 1397 cells wide
+
 struct RectList {  // in LDS
   int r[IPPM_MAX_AGENTS][4];   // [yu,yd,xl,xr]
   int kind[IPPM_MAX_AGENTS];   // 0 = not in the plane, 1 = "own" (value 1), 2 = "other"
   int edges[MAX_EDGES];        // sorted x-edges of the participating rectangles
   int n_edges;
-  int U[MAX_EDGES][IPPM_FEAT]; // per slab and column bin: 11-scaled measure of own columns minus (other \ own) columns
+  int U[MAX_EDGES][IPPM_FEAT]; // per slab and column bin: 11-scaled signed column measure
 };
 
-// R(F) of a footprint-indicator plane: F = 1 on "own", `other_val` on other \ own, 0.5 elsewhere; returns into out[121]
-// (other_val = 0 for the actor plane, 1 for the critic plane where every rectangle is an "other").
+// bits [lo, hi) of a 128-bit mask held in BIN_WORDS 32-bit words
+__device__ __forceinline__ void mask_range(uint32_t* m, int lo, int hi) {
+#pragma unroll
+  for (int w = 0; w < BIN_WORDS; ++w) {
+    const int a = max(lo - 32 * w, 0), b = min(hi - 32 * w, 32);
+    m[w] = b > a ? ((b - a == 32 ? 0xFFFFFFFFu : ((1u << (b - a)) - 1u)) << a) : 0u;
+  }
+}
+
+// R(F) of a footprint-indicator plane: F = 1 on "own", `other_val` (0 or 1) on other \ own, 0.5 elsewhere; into out[121].
+// Along x the set of rectangles covering a row changes only at rectangle edges (slabs); per (slab, column bin) the covered
+// cells of the bin are a bit mask (interval arithmetic, no per-cell loop), weighted 11 per cell except the bin's two
+// fractional border cells.  Everything is integer until the final scale.
 __device__ void indicator_plane(RectList& L, int n, int gx, int gy, float other_val, float* out) {
   const int tid = threadIdx.x;
   // x-edges of the participating rectangles, rank-sorted in parallel (ties by index)
@@ -113,24 +127,32 @@ __device__ void indicator_plane(RectList& L, int n, int gx, int gy, float other_
   }
   __syncthreads();
   const int n_slabs = max(L.n_edges - 1, 0);
-  // per (slab, column bin): signed column measure
+  const int sign_other = other_val > 0.5f ? 1 : -1;
   for (int item = tid; item < n_slabs * IPPM_FEAT; item += blockDim.x) {
     const int k = item / IPPM_FEAT, by = item % IPPM_FEAT;
     const int xa = L.edges[k], xb = L.edges[k + 1];
     int u = 0;
     if (xb > xa) {
-      const int c0 = (by * gy) / 11, c1 = min(gy, ((by + 1) * gy + 10) / 11);
-      for (int y = c0; y < c1; ++y) {
-        const int nc = overlap11(y, y + 1, by, gy);
-        bool own = false, oth = false;
-        for (int j = 0; j < n; ++j) {
-          if (!L.kind[j]) continue;
-          const bool in = L.r[j][2] <= xa && xb <= L.r[j][3] && y >= L.r[j][0] && y < L.r[j][1];
-          own |= in && L.kind[j] == 1;
-          oth |= in && L.kind[j] == 2;
-        }
-        u += own ? nc : ((oth && other_val != 0.5f) ? (other_val > 0.5f ? nc : -nc) : 0);
+      const int c0 = (by * gy) / 11, c1 = min(gy, ((by + 1) * gy + 10) / 11);  // cells of the bin: bit i = cell c0 + i
+      uint32_t own[BIN_WORDS], oth[BIN_WORDS], t[BIN_WORDS];
+#pragma unroll
+      for (int w = 0; w < BIN_WORDS; ++w) { own[w] = 0; oth[w] = 0; }
+      for (int j = 0; j < n; ++j) {
+        if (!L.kind[j] || !(L.r[j][2] <= xa && xb <= L.r[j][3])) continue;
+        mask_range(t, max(L.r[j][0], c0) - c0, min(L.r[j][1], c1) - c0);
+#pragma unroll
+        for (int w = 0; w < BIN_WORDS; ++w) { if (L.kind[j] == 1) own[w] |= t[w]; else oth[w] |= t[w]; }
       }
+      const int last = c1 - 1 - c0;
+      const int w_first = overlap11(c0, c0 + 1, by, gy), w_last = overlap11(c1 - 1, c1, by, gy);
+      int cnt_own = 0, cnt_oth = 0;
+#pragma unroll
+      for (int w = 0; w < BIN_WORDS; ++w) { oth[w] &= ~own[w]; cnt_own += __popc(own[w]); cnt_oth += __popc(oth[w]); }
+      auto bit = [&](const uint32_t* m, int i) { return (int)((m[i >> 5] >> (i & 31)) & 1u); };
+      // every covered cell weighs 11, except the bin's first and last cell (fractional overlap with the bin)
+      int so = 11 * cnt_own - (11 - w_first) * bit(own, 0), sn = 11 * cnt_oth - (11 - w_first) * bit(oth, 0);
+      if (last > 0) { so -= (11 - w_last) * bit(own, last); sn -= (11 - w_last) * bit(oth, last); }
+      u = so + sign_other * sn;
     }
     L.U[k][by] = u;
   }
@@ -146,21 +168,30 @@ __device__ void indicator_plane(RectList& L, int n, int gx, int gy, float other_
 }
 
 // ------------------------------------------------------------------------------------------------------
-// actor observation [11,11,7] (actor/transformations.py:14-176)
+// actor observation [11,11,7] (actor/transformations.py:14-176): one workgroup per (env, agent).  Every global load (the
+// agent's code tile, its map's area sums, rectangles, positions, comm row) is issued up front: one memory round trip.
 // ------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(K6_THREADS)
 k_actor_features(const ippm_config* __restrict__ c, const double* __restrict__ area, const uint8_t* __restrict__ code,
                  const int32_t* __restrict__ rect, const int32_t* __restrict__ pos, const uint8_t* __restrict__ comm, int t,
                  float* __restrict__ obs) {
   const int n = c->n_agents;
   const int e = blockIdx.x / n, i = blockIdx.x % n;
   const int gx = c->grid_x, gy = c->grid_y, S = c->tile_stride;
+  extern __shared__ uint32_t s_tile[];  // the agent's code tile
   __shared__ RectList L;
   __shared__ int s_recv[IPPM_MAX_AGENTS];
   __shared__ int s_idx[IPPM_MAX_AGENTS][3];
   __shared__ float s_F[FEAT2];
   __shared__ int s_c1[FEAT2], s_call[FEAT2];  // footprint image: 11-scaled weight of the "occupied" cells / of all pasted cells
   const int tid = threadIdx.x;
+  const int vec = (gy & 3) == 0 && gy >= 4 * IPPM_FEAT ? 4 : 1;
+  const int tile_bytes = (int)ippm_tile_bytes(S, vec);
+  // up-front loads
+  const uint32_t* cd32 = reinterpret_cast<const uint32_t*>(code + (size_t)(e * n + i) * tile_bytes);
+  for (int q = tid; q < tile_bytes / 4; q += blockDim.x) s_tile[q] = cd32[q];
+  const double* am = area + (size_t)(e * (n + 1) + i) * FEAT2;
+  const double a_mine = tid < FEAT2 ? am[tid] : 0.0;
   if (tid < n) {
     const int j = tid;
     for (int q = 0; q < 4; ++q) L.r[j][q] = rect[(size_t)(e * n + j) * 4 + q];
@@ -184,8 +215,7 @@ k_actor_features(const ippm_config* __restrict__ c, const double* __restrict__ a
   const int full_x = fu[3] - fu[2], full_y = fu[1] - fu[0];
   const int xoff = (cl[2] > fu[2]) ? full_x - hx : 0;
   const int yoff = (cl[0] > fu[0]) ? full_y - wy : 0;
-  const int vec = (gy & 3) == 0 && gy >= 4 * IPPM_FEAT ? 4 : 1;
-  const uint8_t* cd = code + (size_t)(e * n + i) * ippm_tile_bytes(S, vec);
+  const uint8_t* cd = reinterpret_cast<const uint8_t*>(s_tile);
   const int ycode0 = cl[0] - (cl[0] & ~3);  // tile column of the first footprint cell
   const int tile_cols = wy + ycode0;        // tile columns in use
   const int n_groups = vec == 4 ? (tile_cols + 3) >> 2 : tile_cols;
@@ -197,7 +227,7 @@ k_actor_features(const ippm_config* __restrict__ c, const double* __restrict__ a
     int n1[4] = {0, 0, 0, 0}, nall = 0;
     for (int ui = u0; ui < u1; ++ui) {
       const int nr = overlap11(ui, ui + 1, a, full_x);
-      const uint32_t bits = vec == 4 ? cd[(size_t)(ui - xoff) * (S >> 2) + gcol] : cd[(size_t)(ui - xoff) * S + gcol];
+      const uint32_t bits = vec == 4 ? cd[(ui - xoff) * (S >> 2) + gcol] : cd[(ui - xoff) * S + gcol];
       nall += nr;
 #pragma unroll
       for (int q = 0; q < 4; ++q) n1[q] += ((bits >> q) & 1u) ? nr : 0;
@@ -224,9 +254,9 @@ k_actor_features(const ippm_config* __restrict__ c, const double* __restrict__ a
   const double inv_img = 1.0 / ((double)full_x * (double)full_y), inv_map = 1.0 / ((double)gx * (double)gy);
   const int Z = c->space_z;
   const int ox = s_idx[i][0], oy = s_idx[i][1], oz = s_idx[i][2];
-  const double* am = area + (size_t)(e * (n + 1) + i) * FEAT2;
   float* out = obs + (size_t)(e * n + i) * FEAT2 * IPPM_ACTOR_PLANES;
-  for (int o = tid; o < FEAT2; o += blockDim.x) {
+  if (tid < FEAT2) {
+    const int o = tid;
     const int a = o / IPPM_FEAT, b = o % IPPM_FEAT;
     float pm = 1.f;
     if (ox < 5 && a < 5 - ox) pm = 0.f;
@@ -238,7 +268,7 @@ k_actor_features(const ippm_config* __restrict__ c, const double* __restrict__ a
       if (j == i || !s_recv[j]) continue;
       if (s_idx[j][0] - ox + 5 == a && s_idx[j][1] - oy + 5 == b) pm = (float)(s_idx[j][2] + 1) / (float)(Z + 1);
     }
-    const float q = (float)(am[o] * inv_map);
+    const float q = (float)(a_mine * inv_map);
     const float fp = (float)(0.5 + (mv1 * (double)s_c1[o] + mv0 * (double)(s_call[o] - s_c1[o])) * inv_img);
     float* dst = out + (size_t)o * IPPM_ACTOR_PLANES;
     dst[0] = (float)(c->budget - t) / (float)c->budget;
@@ -255,7 +285,7 @@ k_actor_features(const ippm_config* __restrict__ c, const double* __restrict__ a
 // critic state [11,11,12] (critic/transformations.py:17-132): one workgroup per env builds the shared
 // global planes once and writes them for every agent
 // ------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(K6_THREADS)
 k_critic_features(const ippm_config* __restrict__ c, const double* __restrict__ area, const int32_t* __restrict__ rect,
                   const int32_t* __restrict__ pos_pre, const int32_t* __restrict__ action, const float* __restrict__ obs,
                   float* __restrict__ state) {
@@ -266,7 +296,10 @@ k_critic_features(const ippm_config* __restrict__ c, const double* __restrict__ 
   __shared__ int s_idx[IPPM_MAX_AGENTS][3];
   __shared__ int s_act[IPPM_MAX_AGENTS];
   __shared__ float s_F[FEAT2];
+  __shared__ float s_q[FEAT2];
   const int tid = threadIdx.x;
+  const double* am = area + (size_t)(e * (n + 1) + n) * FEAT2;
+  if (tid < FEAT2) s_q[tid] = (float)(am[tid] * (1.0 / ((double)gx * (double)gy)));
   if (tid < n) {
     const int j = tid;
     for (int q = 0; q < 4; ++q) L.r[j][q] = rect[(size_t)(e * n + j) * 4 + q];
@@ -279,8 +312,6 @@ k_critic_features(const ippm_config* __restrict__ c, const double* __restrict__ 
   indicator_plane(L, n, gx, gy, 1.f, s_F);  // plane 10: 1 where any agent's measurement lies, else 0.5 (:91-108)
   const float lo = c->clip_lo, hi = c->clip_hi;
   const int Z = c->space_z, A = c->n_actions;
-  const double inv_map = 1.0 / ((double)gx * (double)gy);
-  const double* am = area + (size_t)(e * (n + 1) + n) * FEAT2;
   for (int w = tid; w < n * FEAT2; w += blockDim.x) {
     const int i = w / FEAT2, o = w % FEAT2;
     const int a = o / IPPM_FEAT, b = o % IPPM_FEAT;
@@ -293,7 +324,7 @@ k_critic_features(const ippm_config* __restrict__ c, const double* __restrict__ 
     }
     // "other actions": later agents overwrite earlier ones on a shared cell, the own agent never writes
     // (handled above: am_ only changes for j != i, in ascending j)
-    const float q = (float)(am[o] * inv_map);
+    const float q = s_q[o];
     const float* src = obs + ((size_t)(e * n + i) * FEAT2 + o) * IPPM_ACTOR_PLANES;
     float* dst = state + ((size_t)(e * n + i) * FEAT2 + o) * IPPM_CRITIC_PLANES;
 #pragma unroll
@@ -432,8 +463,10 @@ extern "C" int ippm_actor_features(ippm_ctx* ctx, const double* area, const uint
   if (!ctx || !area || !code || !rect || !pos || !comm || !obs) { ippm_set_error("ippm_actor_features: null argument"); return -1; }
   if (int rc = feature_checks(ctx, "ippm_actor_features")) return rc;
   if (n_envs <= 0) return 0;
-  hipLaunchKernelGGL(k_actor_features, dim3(n_envs * ctx->cfg.n_agents), dim3(256), 0, S_(stream), ctx->dcfg, area, code, rect, pos,
-                     comm, t, obs);
+  const ippm_config& c = ctx->cfg;
+  const size_t tile = ippm_tile_bytes(c.tile_stride, ctx->vec);
+  hipLaunchKernelGGL(k_actor_features, dim3(n_envs * c.n_agents), dim3(K6_THREADS), (tile + 3) / 4 * 4, S_(stream), ctx->dcfg, area,
+                     code, rect, pos, comm, t, obs);
   IPPM_LAUNCH_CHECK("actor_features");
   return 0;
 }
@@ -443,7 +476,7 @@ extern "C" int ippm_critic_features(ippm_ctx* ctx, const double* area, const int
   if (!ctx || !area || !rect || !pos_pre || !action || !obs || !state) { ippm_set_error("ippm_critic_features: null argument"); return -1; }
   if (int rc = feature_checks(ctx, "ippm_critic_features")) return rc;
   if (n_envs <= 0) return 0;
-  hipLaunchKernelGGL(k_critic_features, dim3(n_envs), dim3(256), 0, S_(stream), ctx->dcfg, area, rect, pos_pre, action, obs, state);
+  hipLaunchKernelGGL(k_critic_features, dim3(n_envs), dim3(K6_THREADS), 0, S_(stream), ctx->dcfg, area, rect, pos_pre, action, obs, state);
   IPPM_LAUNCH_CHECK("critic_features");
   return 0;
 }
