@@ -204,7 +204,8 @@ int ippm_fuse_global_reward(ippm_ctx* ctx, float* global, const uint8_t* code, c
  *                     Only policies that do not depend on this step's observations (0 explicit, 1 uniform) can share a call
  *                     with COMM/GLOBAL; a learned policy calls MOVE separately after the actor.
  *   work (optional, int32 [ippm_work_words()]): with COMM | GLOBAL the kernel also lists the non-empty work items of the
- *   step's fusion (map, run of rows) for ippm_fuse_step.
+ *   step's fusion (map, run of rows) for ippm_fuse_step, every env into its own slice (count + items: written, never
+ *   accumulated, so there is nothing to clear between steps).
  * ippm_fuse_step: K4 for all local maps and K5 for all global maps from the plans above, in one launch; keeps `area`
  *   (optional) up to date; leaves the reward sums open (ippm_sense_step or ippm_reward_finalize completes them).  With the
  *   `work` list of the same step's ippm_plan_step a fixed number of resident wavefronts strides over exactly the non-empty

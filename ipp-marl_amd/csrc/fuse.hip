@@ -398,9 +398,10 @@ __device__ __forceinline__ void fuse_item(const ippm_config* __restrict__ c, flo
 // Workgroup = one wavefront.  Two ways to hand out the work items:
 //   work == NULL : the grid enumerates (map, run) pairs, most of which turn out empty (maps that received nothing, runs
 //                  beyond the hull) -- the stand-alone entry points use this;
-//   work != NULL : `work` = {count, items...} written by the plan kernel holds exactly the non-empty items
-//                  (item = map << 8 | run); the launch is a fixed number of wavefronts that stride over the list, so no slot
-//                  is ever spent on an empty item and no "round" of short-lived workgroups has to drain before the next.
+//   work != NULL : `work` = per-env {count, items...} written by the plan kernel holds exactly the non-empty items
+//                  (item = map << 8 | run); the launch is a fixed number of wavefronts, a few per env, that stride over their
+//                  env's items, so hardly a slot is spent on an empty item and no "round" of short-lived workgroups has to
+//                  drain before the next.
 #ifndef IPPM_FUSE_WAVES
 #define IPPM_FUSE_WAVES 4
 #endif
@@ -410,18 +411,19 @@ k_fuse_rows(const ippm_config* __restrict__ c, float* __restrict__ local, float*
             const uint8_t* __restrict__ code, const int32_t* __restrict__ plan_ro, int32_t* __restrict__ ws,
             double* __restrict__ sums, double* __restrict__ area, unsigned long long* __restrict__ counters,
             const int32_t* __restrict__ work, int wave_rows, int chunks, int min_ops, int local_units, int agent_sel,
-            int n_envs_total, int shard_cap) {
+            int n_envs_total, int env_cap) {
   __shared__ double s_area[TRACK ? (IPPM_FEAT + 1) * IPPM_AREA_LD : 1];
   const int n = c->n_agents;
-  if (work) {  // gridDim.x is a multiple of IPPM_WORK_SHARDS: wavefront b serves shard b % SHARDS
-    const int shard = blockIdx.x % IPPM_WORK_SHARDS;
-    const int count = work[shard];
-    const int32_t* items = work + IPPM_WORK_HEADER + (size_t)shard * shard_cap;
-    for (int i = blockIdx.x / IPPM_WORK_SHARDS; i < count; i += gridDim.x / IPPM_WORK_SHARDS) {
+  if (work) {  // gridDim.x is a multiple of the env count: wavefront b serves env b % E, taking every (gridDim.x / E)-th item
+    const int env = blockIdx.x % n_envs_total;
+    const int count = work[env];
+    const int32_t* items = work + n_envs_total + (size_t)env * env_cap;
+    const int step = gridDim.x / n_envs_total;
+    for (int i = blockIdx.x / n_envs_total; i < count; i += step) {
       const int item = items[i];
       const int m = item >> 8;
       fuse_item<VEC, TRACK, NAMAX>(c, local, global, code, plan_ro, ws, sums, area, counters, s_area, wave_rows, min_ops, n_envs_total,
-                                   m / (n + 1), m % (n + 1), item & 0xFF, i);
+                                   m / (n + 1), m % (n + 1), item & 0xFF, blockIdx.x);
     }
     return;
   }
@@ -452,9 +454,20 @@ static int env_int(const char* name, int dflt) {  // tuning knob; the default is
   return v && *v ? atoi(v) : dflt;
 }
 
-int ippm_fuse_wave_rows(const ippm_ctx* ctx) {  // rows per work item; plan (work list) and fusion must agree
-  const int dflt = 32;
-  return std::min(ctx->cfg.grid_x, std::max((ctx->cfg.grid_x + 255) / 256, env_int("IPPM_FUSE_WAVE_ROWS", dflt)));
+// Rows per work item; the plan kernel (work list) and the fusion must agree, both derive it from (config, n_envs).
+// Sized so that a step yields roughly three items per wavefront slot of the chip (256 CUs x 4 SIMDs x 4 waves): about half
+// of the maps take part in a fusion and their op hulls span ~60 % of the grid's rows.  Fewer envs -> shorter runs -> the
+// same parallelism with shorter per-wavefront latency chains.
+int ippm_fuse_wave_rows(const ippm_ctx* ctx, int n_envs) {
+  const int gx = ctx->cfg.grid_x;
+  const int forced = env_int("IPPM_FUSE_WAVE_ROWS", 0);
+  int rows = forced;
+  if (rows <= 0) {
+    const double est_rows = 0.5 * (double)n_envs * (ctx->cfg.n_agents + 1) * 0.6 * gx;
+    rows = 8;
+    while (rows < 64 && est_rows / rows > 12288.0 * 1.5) rows *= 2;
+  }
+  return std::min(gx, std::max((gx + 255) / 256, rows));
 }
 
 // One launch per plan-size class (<= 6 ops, 7..10, 11..18); each returns immediately for plans it does not own.
@@ -465,15 +478,15 @@ static int launch_fuse(ippm_ctx* ctx, float* local, float* global, const uint8_t
   const int units = local_units + global_units;
   if (units <= 0) return 0;
   const int max_ops = c.n_agents + 1;  // local: 2 clamp-only ops + N-1 messages; global: 1 clamp-only op + N messages
-  const int wave_rows = ippm_fuse_wave_rows(ctx);
+  const int wave_rows = ippm_fuse_wave_rows(ctx, n_envs_total);
   const int chunks = (c.grid_x + wave_rows - 1) / wave_rows;
   // resident wavefronts of the persistent form: CUs x SIMDs x waves per SIMD the kernel's registers allow
   const int persist = std::max(64, env_int("IPPM_FUSE_PERSIST", 12288));
-  const int pgrid = std::max(IPPM_WORK_SHARDS, std::min(persist, units * chunks) / IPPM_WORK_SHARDS * IPPM_WORK_SHARDS);
+  const int pgrid = n_envs_total * std::max(1, std::min(persist / std::max(n_envs_total, 1), (c.n_agents + 1) * chunks));
   dim3 grid(work ? (unsigned)pgrid : (unsigned)units * chunks), block(64);
 #define IPPM_FUSE(V, T, NA, MINOPS)                                                                                  \
   hipLaunchKernelGGL((k_fuse_rows<V, T, NA>), grid, block, 0, st, ctx->dcfg, local, global, code, ws, ws, sums, area, \
-                     ctx->dcounters, work, wave_rows, chunks, MINOPS, local_units, agent_sel, n_envs_total, ippm_work_shard_cap(ctx, n_envs_total))
+                     ctx->dcounters, work, wave_rows, chunks, MINOPS, local_units, agent_sel, n_envs_total, ippm_work_env_cap(ctx, n_envs_total))
 #define IPPM_FUSE_ALL(V, T)                    \
   do {                                         \
     IPPM_FUSE(V, T, 6, 1);                     \

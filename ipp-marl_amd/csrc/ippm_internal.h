@@ -52,12 +52,11 @@ struct ippm_ctx {
 
 void ippm_set_error(const std::string& msg);
 // k_plan for local (global_maps == 0) or global fusion plans; step_small.hip
-// Fusion work list (int32, caller-owned, ippm_work_words() long): IPPM_WORK_SHARDS counters, then per shard a region of
-// items (map << 8 | run of rows); env e appends to shard e % IPPM_WORK_SHARDS, so no counter sees more than E/16 atomics.
-#define IPPM_WORK_SHARDS 16
-#define IPPM_WORK_HEADER 16
-int ippm_fuse_wave_rows(const ippm_ctx* ctx);          // rows per work item (fuse.hip)
-int ippm_work_shard_cap(const ippm_ctx* ctx, int n_envs);  // items a shard can hold
+// Fusion work list (int32, caller-owned, ippm_work_words() long): [E] item counts, then [E][cap] items (map << 8 | run of
+// rows), cap = (N+1) * runs per map.  Every env owns its slice: the plan wavefront of env e WRITES count and items (no atomics,
+// nothing to clear between steps), the fusion's resident wavefronts b serve env b % E.
+int ippm_fuse_wave_rows(const ippm_ctx* ctx, int n_envs);  // rows per work item (fuse.hip)
+int ippm_work_env_cap(const ippm_ctx* ctx, int n_envs);    // items an env's slice can hold
 int ippm_launch_plan(ippm_ctx* ctx, const int32_t* rect, const int32_t* pos, const uint8_t* comm, int32_t* ws, int global_maps,
                      int n_envs, int agent_sel, hipStream_t st);
 int ippm_check_hip(hipError_t err, const char* what);

@@ -74,9 +74,10 @@ __device__ __forceinline__ void plan_push(const ippm_config* __restrict__ c, int
 
 // plans map i of env e (i == n: the global map); recv = agents whose measurements map i receives this step.
 // Returns the number of rows of the plan's hull (0: nothing to fuse).
-__device__ __forceinline__ int plan_map(const ippm_config* __restrict__ c, const int32_t* __restrict__ rect,
-                                         const int32_t* pos_e, uint32_t recv, int32_t* __restrict__ ws,
-                                         int global_maps, int e, int i) {
+// rect_e = the env's [N,4] published footprints, st = the map's first 6 workspace words (deferred-clamp state), both possibly
+// prefetched by the caller (global memory or LDS / registers).
+__device__ __forceinline__ int plan_map(const ippm_config* __restrict__ c, const int32_t* rect_e, const int32_t* pos_e, uint32_t recv,
+                                         int32_t* __restrict__ ws, int global_maps, int e, int i, const int32_t* st) {
   const int n = c->n_agents;
   int32_t* w = ws + (size_t)(e * (n + 1) + i) * IPPM_WS_WORDS;
   int nops = 0, x0 = 1 << 30, x1 = -1, y0 = 1 << 30, y1 = -1;
@@ -88,11 +89,11 @@ __device__ __forceinline__ int plan_map(const ippm_config* __restrict__ c, const
   int32_t* hdr = w + WS_PLAN;
   const int whole = c->logit_prior != 0.f;
   if (last_src < 0) {  // nothing received: the map is untouched; carry possible out-of-range regions forward
-    if (!global_maps && w[WS_FLAG_S]) {
-      const int32_t* ri = rect + (size_t)(e * n + i) * 4;
-      if (w[WS_FLAG_A]) {
-        w[WS_RECT_A + 0] = min(w[WS_RECT_A + 0], ri[0]); w[WS_RECT_A + 1] = max(w[WS_RECT_A + 1], ri[1]);
-        w[WS_RECT_A + 2] = min(w[WS_RECT_A + 2], ri[2]); w[WS_RECT_A + 3] = max(w[WS_RECT_A + 3], ri[3]);
+    if (!global_maps && st[WS_FLAG_S]) {
+      const int32_t* ri = rect_e + i * 4;
+      if (st[WS_FLAG_A]) {
+        w[WS_RECT_A + 0] = min(st[WS_RECT_A + 0], ri[0]); w[WS_RECT_A + 1] = max(st[WS_RECT_A + 1], ri[1]);
+        w[WS_RECT_A + 2] = min(st[WS_RECT_A + 2], ri[2]); w[WS_RECT_A + 3] = max(st[WS_RECT_A + 3], ri[3]);
       } else {
         for (int q = 0; q < 4; ++q) w[WS_RECT_A + q] = ri[q];
       }
@@ -102,13 +103,13 @@ __device__ __forceinline__ int plan_map(const ippm_config* __restrict__ c, const
     hdr[PL_NOPS] = 0;
     return 0;
   }
-  if (w[WS_FLAG_A]) plan_push(c, w, nops, 0, -1, 0, w + WS_RECT_A, x0, x1, y0, y1);
-  if (!global_maps && w[WS_FLAG_S]) plan_push(c, w, nops, 0, -1, 0, rect + (size_t)(e * n + i) * 4, x0, x1, y0, y1);
+  if (st[WS_FLAG_A]) plan_push(c, w, nops, 0, -1, 0, st + WS_RECT_A, x0, x1, y0, y1);
+  if (!global_maps && st[WS_FLAG_S]) plan_push(c, w, nops, 0, -1, 0, rect_e + i * 4, x0, x1, y0, y1);
   int last_op = -1;
   for (int j = 0; j < n; ++j) {
     bool take = global_maps ? true : (j != i && ((recv >> j) & 1u) != 0);
     if (!take) continue;
-    const int32_t* rj = rect + (size_t)(e * n + j) * 4;
+    const int32_t* rj = rect_e + j * 4;
     int before = nops;
     plan_push(c, w, nops, 1, j, ippm_alt_index(c, pos_e[j * 3 + 2]), rj, x0, x1, y0, y1);
     if (j == last_src) {
@@ -137,7 +138,9 @@ __global__ void k_plan(const ippm_config* __restrict__ c, const int32_t* __restr
   uint32_t recv = 0;
   if (!global_maps)
     for (int j = 0; j < n; ++j) recv |= comm[(size_t)(e * n + i) * n + j] ? (1u << j) : 0u;
-  plan_map(c, rect, pos + (size_t)e * n * 3, recv, ws, global_maps, e, i);
+  int32_t st[6];
+  for (int q = 0; q < 6; ++q) st[q] = ws[(size_t)(e * (n + 1) + i) * IPPM_WS_WORDS + q];
+  plan_map(c, rect + (size_t)e * n * 4, pos + (size_t)e * n * 3, recv, ws, global_maps, e, i, st);
 }
 
 // ======================================================================================================
@@ -247,10 +250,23 @@ __device__ void k1_env(const ippm_config* __restrict__ c, int64_t ep, int32_t* s
   const int lane = threadIdx.x;
   const uint32_t k0 = (uint32_t)c->philox_seed, k1 = (uint32_t)(c->philox_seed >> 32);
   int flt = 0;
+  // Off the serial chain, up front: every agent's boundary mask (its position does not change before its own move; lanes =
+  // actions, one ballot each, kept in lane i) and its Philox word (lane i draws for agent i).
+  __shared__ float s_pr[IPPM_MAX_AGENTS * IPPM_MAX_ACTIONS];  // the policy's probabilities: fetched once, not per agent in the chain
+  if (policy >= 2)
+    for (int q = lane; q < n * A; q += 64) s_pr[q] = probs_e[q];
+  uint32_t bmask_mine = 0, word_mine = 0;
+  for (int i = 0; i < n; ++i) {
+    const uint32_t b = (uint32_t)__ballot(lane < A && action_in_bounds(c, lane, s_pos[i * 3], s_pos[i * 3 + 1], s_pos[i * 3 + 2]));
+    bmask_mine = lane == i ? b : bmask_mine;
+  }
+  if ((policy == 1 || policy == 2) && lane < n)
+    word_mine = ippm_philox(0u, (uint32_t)ep, ippm_stream_word((uint32_t)lane, (uint32_t)t, IPPM_DOMAIN_ACTION), (uint32_t)(ep >> 32), k0, k1).v[0];
+  __syncthreads();
   for (int i = 0; i < n; ++i) {
     const int px = s_pos[i * 3], py = s_pos[i * 3 + 1], pz = s_pos[i * 3 + 2];
-    // lanes = actions: one ballot gives the boundary mask
-    const uint32_t bmask = (uint32_t)__ballot(lane < A && action_in_bounds(c, lane, px, py, pz));
+    const uint32_t bmask = (uint32_t)__builtin_amdgcn_readlane((int)bmask_mine, i);
+    const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)word_mine, i);
     uint32_t m = bmask;
     int ix, iy, iz;
     ippm_pos_to_index(c, px, py, pz, ix, iy, iz);
@@ -265,14 +281,12 @@ __device__ void k1_env(const ippm_config* __restrict__ c, int64_t ep, int32_t* s
     } else if (policy == 0) {
       a = action_in_e[i];
     } else if (policy == 1) {
-      Philox4 ph = ippm_philox(0u, (uint32_t)ep, ippm_stream_word((uint32_t)i, (uint32_t)t, IPPM_DOMAIN_ACTION),
-                               (uint32_t)(ep >> 32), k0, k1);
-      const int kth = (int)__umulhi(ph.v[0], (uint32_t)__popc(m));
+      const int kth = (int)__umulhi(word, (uint32_t)__popc(m));
       // the kth valid action: the lane whose bit is set and has kth set bits below it
-      const bool mine = lane < A && ((m >> lane) & 1u) && __popc(m & ((1u << lane) - 1u)) == kth;
+      const bool mine = lane < A && ((m >> lane) & 1u) && __popc(m & ((1u << (lane & 31)) - 1u)) == kth;
       a = __ffsll((unsigned long long)__ballot(mine)) - 1;
     } else {
-      const float* pr = probs_e + (size_t)i * A;
+      const float* pr = s_pr + i * A;
       if (policy == 3) {  // eval: argmax of probs*mask (first maximum)
         float best = -1.f;
         for (int q = 0; q < A; ++q) {
@@ -282,9 +296,7 @@ __device__ void k1_env(const ippm_config* __restrict__ c, int64_t ep, int32_t* s
       } else {  // train: inverse CDF over probs*mask, sequential float32 sums without FMA contraction
         float total = 0.f;
         for (int q = 0; q < A; ++q) total = __fadd_rn(total, ((m >> q) & 1u) ? pr[q] : 0.f);
-        Philox4 ph = ippm_philox(0u, (uint32_t)ep, ippm_stream_word((uint32_t)i, (uint32_t)t, IPPM_DOMAIN_ACTION),
-                                 (uint32_t)(ep >> 32), k0, k1);
-        const float u = (float)(ph.v[0] >> 8) * (1.0f / 16777216.0f);
+        const float u = (float)(word >> 8) * (1.0f / 16777216.0f);
         const float target = __fmul_rn(u, total);
         float acc = 0.f;
         int lastv = -1;
@@ -324,33 +336,40 @@ k_plan_step(const ippm_config* __restrict__ c, const int64_t* __restrict__ episo
             const int32_t* __restrict__ rect, int32_t* __restrict__ ws, int t, int flags, const float* __restrict__ probs,
             const int32_t* __restrict__ action_in, int policy, uint8_t* __restrict__ mask, int32_t* __restrict__ action,
             int32_t* __restrict__ fault, int32_t* __restrict__ rect_next, int agent_sel, int32_t* __restrict__ work,
-            int wave_rows, int shard_cap) {
+            int wave_rows, int env_cap) {
   const int e = blockIdx.x, lane = threadIdx.x;
   const int n = c->n_agents, A = c->n_actions;
   __shared__ int32_t s_pos[IPPM_MAX_AGENTS * 3];
+  __shared__ int32_t s_rect[IPPM_MAX_AGENTS * 4];
   int32_t* pg = pos + (size_t)e * n * 3;
+  const bool plans = (flags & (IPPM_STEP_COMM | IPPM_STEP_GLOBAL)) != 0;
+  // everything this wavefront will read is requested now, in one round trip: positions, published footprints, the
+  // deferred-clamp state of my map (lane i: local map i, lane n: the global map)
   if (lane < n * 3) s_pos[lane] = pg[lane];
+  if (plans && lane < n * 4) s_rect[lane] = rect[(size_t)e * n * 4 + lane];
+  int32_t st[6] = {0, 0, 0, 0, 0, 0};
+  if (plans && lane <= n)
+    for (int q = 0; q < 6; ++q) st[q] = ws[(size_t)(e * (n + 1) + lane) * IPPM_WS_WORDS + q];
   __syncthreads();
   int hull_rows = 0;
   if ((flags & IPPM_STEP_COMM) && lane < n) {
     const uint32_t recv = comm_row(c, episode, s_pos, comm_range, draws, comm, t, e, lane);
-    if (agent_sel < 0 || agent_sel == lane) hull_rows = plan_map(c, rect, s_pos, recv, ws, 0, e, lane);
+    if (agent_sel < 0 || agent_sel == lane) hull_rows = plan_map(c, s_rect, s_pos, recv, ws, 0, e, lane, st);
   }
-  if ((flags & IPPM_STEP_GLOBAL) && lane == n) hull_rows = plan_map(c, rect, s_pos, 0u, ws, 1, e, n);
-  if (work && (flags & (IPPM_STEP_COMM | IPPM_STEP_GLOBAL))) {
-    // work items of this env's plans: one reservation per wavefront (exclusive scan of the lanes' item counts)
+  if ((flags & IPPM_STEP_GLOBAL) && lane == n) hull_rows = plan_map(c, s_rect, s_pos, 0u, ws, 1, e, n, st);
+  // work items of this env's plans into the env's own slice of the list (exclusive scan of the lanes' item counts)
+  if (work && plans) {
     const int items = (hull_rows + wave_rows - 1) / wave_rows;
-    int before = 0, total = 0;
-    for (int j = 0; j <= n; ++j) {
+    // the global map's runs go first (they carry the reward arithmetic: longest items first balances the env's wavefronts)
+    const int g_items = __builtin_amdgcn_readlane(items, n);
+    int before = lane == n ? 0 : g_items, total = g_items;
+    for (int j = 0; j < n; ++j) {
       const int v = __builtin_amdgcn_readlane(items, j);
-      before += j < lane ? v : 0;
+      before += (j < lane && lane != n) ? v : 0;
       total += v;
     }
-    const int shard = e % IPPM_WORK_SHARDS;
-    int base = 0;
-    if (lane == 0 && total > 0) base = atomicAdd(&work[shard], total);
-    base = __builtin_amdgcn_readfirstlane(base);
-    int32_t* dst = work + IPPM_WORK_HEADER + (size_t)shard * shard_cap + base + before;
+    if (lane == 0) work[e] = total;
+    int32_t* dst = work + gridDim.x + (size_t)e * env_cap + before;
     if (lane <= n)
       for (int k = 0; k < items; ++k) dst[k] = ((e * (n + 1) + lane) << 8) | k;
   }
@@ -367,6 +386,10 @@ k_plan_step(const ippm_config* __restrict__ c, const int64_t* __restrict__ episo
       r[0] = cl[0]; r[1] = cl[1]; r[2] = cl[2]; r[3] = cl[3];
     }
   }
+}
+
+__global__ void k_zero_i32(int32_t* __restrict__ p, int n) {
+  if ((int)threadIdx.x < n) p[threadIdx.x] = 0;
 }
 
 // ======================================================================================================
@@ -395,15 +418,15 @@ extern "C" int ippm_comm_matrix(ippm_ctx* ctx, const int64_t* episode, const int
   return 0;
 }
 
-int ippm_work_shard_cap(const ippm_ctx* ctx, int n_envs) {
-  const int wave_rows = ippm_fuse_wave_rows(ctx);
+int ippm_work_env_cap(const ippm_ctx* ctx, int n_envs) {
+  const int wave_rows = ippm_fuse_wave_rows(ctx, n_envs);
   const int chunks = (ctx->cfg.grid_x + wave_rows - 1) / wave_rows;
-  return ((n_envs + IPPM_WORK_SHARDS - 1) / IPPM_WORK_SHARDS) * (ctx->cfg.n_agents + 1) * chunks;
+  return (ctx->cfg.n_agents + 1) * chunks;
 }
 
 extern "C" int ippm_work_words(ippm_ctx* ctx, int32_t n_envs, int64_t* words) {
   if (!ctx || !words || n_envs < 0) { ippm_set_error("ippm_work_words: bad argument"); return -1; }
-  *words = IPPM_WORK_HEADER + (int64_t)IPPM_WORK_SHARDS * ippm_work_shard_cap(ctx, n_envs);
+  *words = (int64_t)n_envs * (1 + ippm_work_env_cap(ctx, n_envs));
   return 0;
 }
 
@@ -430,11 +453,10 @@ extern "C" int ippm_plan_step(ippm_ctx* ctx, const int64_t* episode, int32_t* po
       ippm_set_error("ippm_plan_step: the work list is built for local and global plans together");
       return -1;
     }
-    IPPM_HIP(hipMemsetAsync(work, 0, sizeof(int32_t) * IPPM_WORK_SHARDS, S_(stream)));
   }
   hipLaunchKernelGGL(k_plan_step, dim3(n_envs), dim3(64), 0, S_(stream), ctx->dcfg, episode, pos, comm_range, draws, comm, rect, ws,
                      t, flags, probs, action_in, policy, mask, action, fault, rect_next, -1, plans ? work : nullptr,
-                     ippm_fuse_wave_rows(ctx), ippm_work_shard_cap(ctx, n_envs));
+                     ippm_fuse_wave_rows(ctx, n_envs), ippm_work_env_cap(ctx, n_envs));
   IPPM_LAUNCH_CHECK("plan_step");
   return 0;
 }
