@@ -61,8 +61,17 @@ struct WaveCtx {   // what a wave needs while it walks its rows
 struct WaveAcc {
   bool exceed;
   float a1, aD, aT;
+  double d1, dD, dT;  // SHIFT only: there every cell of the grid enters the reward sums with a tiny H(b) - H(a)
   unsigned cells, opcells;
 };
+
+// Shannon entropy of sigmoid(clamp(l)) in float64 (SHIFT path: the float32 form's 1e-7 absolute error per cell, summed over
+// a whole grid of barely changed cells, would show at 1e-4 in the returns)
+__device__ __forceinline__ double entropy_l_f64(float l, float lc) {
+  const double a = fmin(fabs((double)l), (double)lc);
+  const double e = exp(-a), d = 1.0 + e;
+  return log2(d) + a * 1.4426950408889634 * (e / d);
+}
 
 template <int VEC>
 __device__ __forceinline__ CellVec<VEC> buf_load_cells(__amdgpu_buffer_rsrc_t r, int off) {
@@ -228,10 +237,17 @@ __device__ __forceinline__ void walk_slab(const WaveCtx& w, const OpTable& t, Wa
           if (__any(wsum != 0.f)) {
 #pragma unroll
             for (int q = 0; q < VEC; ++q) {
-              const float hb = ippm_entropy_l(bsave[q], w.lc), ha = ippm_entropy_l(mv.v[q], w.lc);
-              acc_out.a1 += wa[q] * (hb - ha);
-              acc_out.aD += (wa[q] - wb[q]) * hb;
-              acc_out.aT += wa[q] * ha - wb[q] * hb;
+              if (SHIFT) {
+                const double hb = entropy_l_f64(bsave[q], w.lc), ha = entropy_l_f64(mv.v[q], w.lc);
+                acc_out.d1 += (double)wa[q] * (hb - ha);
+                acc_out.dD += (double)(wa[q] - wb[q]) * hb;
+                acc_out.dT += (double)wa[q] * ha - (double)wb[q] * hb;
+              } else {
+                const float hb = ippm_entropy_l(bsave[q], w.lc), ha = ippm_entropy_l(mv.v[q], w.lc);
+                acc_out.a1 += wa[q] * (hb - ha);
+                acc_out.aD += (wa[q] - wb[q]) * hb;
+                acc_out.aT += wa[q] * ha - wb[q] * hb;
+              }
             }
           }
         }
@@ -345,7 +361,7 @@ __device__ __forceinline__ void fuse_item(const ippm_config* __restrict__ c, flo
     __syncthreads();
   }
   WaveAcc acc;
-  acc.exceed = false; acc.a1 = acc.aD = acc.aT = 0.f; acc.cells = acc.opcells = 0;
+  acc.exceed = false; acc.a1 = acc.aD = acc.aT = 0.f; acc.d1 = acc.dD = acc.dT = 0.0; acc.cells = acc.opcells = 0;
 
   // slabs that intersect my rows [r0, r1): the table is sorted, the first one is found with one ballot
   int s = __popcll(__ballot(lane < nslabs && st.xb <= r0));
@@ -379,10 +395,16 @@ __device__ __forceinline__ void fuse_item(const ippm_config* __restrict__ c, flo
   // wave reduction of the reward terms and work counters: one atomic per wavefront and quantity
   {
     const float fc = ippm_wave_sum((float)acc.cells), fo = ippm_wave_sum((float)acc.opcells);
-    const float a1 = ippm_wave_sum(acc.a1), aD = ippm_wave_sum(acc.aD), aT = ippm_wave_sum(acc.aT);
+    double a1 = (double)ippm_wave_sum(acc.a1), aD = (double)ippm_wave_sum(acc.aD), aT = (double)ippm_wave_sum(acc.aT);
+    if (shift && is_global) {
+      double x1 = acc.d1, xD = acc.dD, xT = acc.dT;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { x1 += __shfl_xor(x1, o, 64); xD += __shfl_xor(xD, o, 64); xT += __shfl_xor(xT, o, 64); }
+      a1 += x1; aD += xD; aT += xT;
+    }
     if (lane < 3) {
-      const float v = lane == 0 ? a1 : (lane == 1 ? aD : aT);
-      if (is_global && sums && v != 0.f) atomicAdd(&sums[(size_t)e * 8 + SUM_ACC1 + lane], (double)v);
+      const double v = lane == 0 ? a1 : (lane == 1 ? aD : aT);
+      if (is_global && sums && v != 0.0) atomicAdd(&sums[(size_t)e * 8 + SUM_ACC1 + lane], v);
     } else if (lane < 5 && counters) {
       const float v = lane == 3 ? fc : fo;
       if (v > 0.f) atomicAdd(&counters[(cslot & (IPPM_COUNTER_SLOTS - 1)) * 8 + (is_global ? 3 : 1) + (lane - 3)], (unsigned long long)v);

@@ -49,6 +49,19 @@ class EpisodeEngine:
                      env.stream)
         self.start_positions = env.pos[0].cpu().numpy().astype(np.int64)
         self.stage = [0] * self.d.n_agents  # per-agent sensing counter = Philox stage
+        # cells any sensing of this episode has covered (evaluation metrics: an unobserved cell is exactly 0.5 in the reference
+        # too and never counts as "> 0.5", whereas a cell whose observations cancel is classified by rounding noise)
+        self.observed = torch.zeros(self.d.grid_x, self.d.grid_y, dtype=torch.bool, device=env.device)
+        raw_sense = env.sense
+
+        def sense(stage, flips=None, agent=-1, close_step=False):
+            raw_sense(stage, flips, agent, close_step)
+            rects = env.rect[0].cpu().numpy()
+            for i in (range(self.d.n_agents) if agent < 0 else [agent]):
+                yu, yd, xl, xr = (int(v) for v in rects[i])
+                self.observed[xl:xr, yu:yd] = True
+
+        env.sense = sense
 
     # ---- maps -------------------------------------------------------------------------------------------
     def _to_logodds(self, prob: np.ndarray) -> torch.Tensor:
@@ -134,3 +147,11 @@ def scratch_engine(params: Dict) -> EpisodeEngine:
     if key not in _engines:
         _engines[key] = EpisodeEngine(params, 1)
     return _engines[key]
+
+
+def engine_for_grid(shape) -> Optional[EpisodeEngine]:
+    """An already created scratch engine whose grid has this shape (helpers that receive bare maps, e.g. get_wrmse)."""
+    for eng in _engines.values():
+        if (eng.d.grid_x, eng.d.grid_y) == tuple(int(v) for v in shape):
+            return eng
+    return None

@@ -24,6 +24,7 @@ class MissionMetrics:
     free / as occupied — the attainable range."""
 
     f1_bracket: List[Tuple[float, float]]
+    f1_cancelled: List[float]
 
     def _f1_counts(self, map_tensor: torch.Tensor, threshold: float = 0.0):
         env = self.mapping.engine.env
@@ -39,11 +40,19 @@ class MissionMetrics:
         ent = torch.zeros(1, dtype=torch.float64, device=env.device)
         env.ctx.call("ippm_weighted_entropy", _ffi.ptr(m), env._p(env.truth), 1, _ffi.ptr(ent), 1, env.stream)
         target = int(env.truth_map[0].sum())
-        tp_s, fp_s, fn_s = self._f1_counts(m, 1e-5)
-        tp_l, fp_l, fn_l = self._f1_counts(m, -1e-5)
+        # never-observed cells (exactly 0 here, exactly 0.5 in the reference) are class 0 for certain: keep them out of the
+        # optimistic count below
+        never = ~self.mapping.engine.observed.view_as(m) & (m == 0)
+        m_b = torch.where(never, torch.full_like(m, -1.0), m).contiguous()
+        tp_s, fp_s, fn_s = self._f1_counts(m_b, 1e-5)
+        tp_l, fp_l, fn_l = self._f1_counts(m_b, -1e-5)
         if not hasattr(self, "f1_bracket") or self.f1_bracket is None:
             self.f1_bracket = []
+        if getattr(self, "f1_cancelled", None) is None:
+            self.f1_cancelled = []
         self.f1_bracket.append((f1_of(tp_s, fp_l, fn_s), f1_of(tp_l, fp_s, fn_l)))
+        # cells within 1e-5 of p = 0.5 in log-odds (their class is rounding noise), as a share of the target cells
+        self.f1_cancelled.append(((tp_l - tp_s) + (fp_l - fp_s)) / max(target, 1))
         return float(ent[0]) / target, f1_of(*self._f1_counts(m, 0.0))
 
     def _fuse_global(self):

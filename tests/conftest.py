@@ -50,13 +50,13 @@ def assert_posteriors(actual, desired, strict, msg=""):
     """Posterior-map parity.
 
     strict=True  (``desired`` from the oracle in exact float64 mode): every cell within 1e-5 relative.
-    strict=False (``desired`` produced by the reference itself / the oracle in reference mode): the reference
-      re-quantises each map to float32 *probabilities* at every fusion (mappings.py:83), which perturbs 1-p by up
-      to 2^-25 / 1e-4 = 3e-4 relative for cells that came close to the 0.9999 clip; a later contradicting
-      observation turns that into a relative error of the same size in p.  That noise is the reference's, it is
-      not reproducible by any other arithmetic, and it is bounded in log-odds (one such rounding per step while a
-      cell sits near the clip; three of them ~ 1e-3).  So: >= 99.95 % of the cells within 1e-5 relative, and ALL
-      cells within 1e-3 in log-odds (0.1 % in odds).
+    strict=False (``desired`` recorded from the reference itself / the oracle in reference mode): the reference
+      re-quantises each map to float32 *probabilities* at every fusion (mappings.py:83), which perturbs 1-p by up to
+      2^-25 / 1e-4 = 3e-4 relative for cells that came close to the 0.9999 clip; a later contradicting observation turns
+      that into a relative error of the same size in p.  That noise is the reference's own and no other arithmetic
+      reproduces it.  Its measured extent on the recorded episodes (exact-float64 oracle against the recordings): 3 cells
+      of 98 304 outside 1e-5, the worst at 2.45e-5 (episode_small5_e3); none in the other two episodes.  So: at least
+      99.99 % of the cells within 1e-5 relative, and EVERY cell within 5e-5.
     """
     actual = np.asarray(actual, dtype=np.float64)
     desired = np.asarray(desired, dtype=np.float64)
@@ -65,9 +65,5 @@ def assert_posteriors(actual, desired, strict, msg=""):
         return
     rel = np.abs(actual - desired) / np.abs(desired)
     frac = float((rel <= 1e-5).mean())
-    assert frac >= 0.9995, f"{msg}: only {frac:.6f} of the cells within 1e-5 relative"
-    # beyond the clip bound the stored value only matters up to its clip (every consumer clips first), and float32
-    # cannot resolve 1-p there at all; inside it the quantisation bound applies
-    a, b = np.clip(actual, 1e-4, 0.9999), np.clip(desired, 1e-4, 0.9999)
-    dl = np.abs(np.log(a / (1 - a)) - np.log(b / (1 - b)))
-    assert float(dl.max()) <= 1e-3, f"{msg}: log-odds deviation {dl.max():.3e} exceeds the float32-quantisation bound"
+    assert frac >= 0.9999, f"{msg}: only {frac:.6f} of the cells within 1e-5 relative"
+    assert float(rel.max()) <= 5e-5, f"{msg}: relative deviation {rel.max():.3e} exceeds the reference's own float32 re-quantisation noise"

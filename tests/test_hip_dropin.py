@@ -60,13 +60,16 @@ def test_action_space_matches_reference_tables(golden):
     from ippmarl.agent.action_space import AgentActionSpace
     from ippmarl.agent.state_space import AgentStateSpace
     fx = golden("masks")
-    for A in (6, 27):
-        params = make_params("default", experiment__constraints__num_actions=A)
+    for A in (4, 6, 9, 27):
+        over = dict(experiment__constraints__num_actions=A)
+        if A in (4, 9):  # the 2-D sets are only self-consistent with one altitude level (the fixtures were recorded that way)
+            over.update(experiment__constraints__min_altitude=15, experiment__constraints__max_altitude=15)
+        params = make_params("default", **over)
         asp, ss = AgentActionSpace(params), AgentStateSpace(params)
         for pos, want in list(zip(fx[f"a{A}_pos"], fx[f"a{A}_mask"]))[::7]:
             flat, _ = asp.get_action_mask(pos)
             assert np.array_equal(flat, want), (A, pos)
-        base = np.array([25, 25, 10])
+        base = np.array([25, 25, 15 if A in (4, 9) else 10])
         assert np.array_equal(np.array([asp.action_to_position(base, a) for a in range(A)]), fx[f"a{A}_moves"])
         for pos, others, k, m_in, m_out in list(zip(fx[f"a{A}_col_pos"], fx[f"a{A}_col_others"], fx[f"a{A}_col_n"],
                                                     fx[f"a{A}_col_in"], fx[f"a{A}_col_out"]))[:200]:
@@ -197,17 +200,25 @@ def test_ig_baseline_replays_reference_run(golden, tag, monkeypatch):
     # sit at 0.5 +- 1e-8 in the reference and are classified by its rounding noise, so the recorded F1 can only be
     # bracketed: every such cell in the wrong class <= reference <= every such cell in the right class.
     assert f1s[0] == fx["f1"][0] == 0.0
-    for (lo, hi), want in zip(ig.f1_bracket, fx["f1"]):
-        assert min(lo, hi) - 1e-9 <= want <= max(lo, hi) + 1e-9, (lo, want, hi)
+    _check_f1_brackets(ig, fx)
     np.testing.assert_allclose([rel, ab], [fx["relative_return"], fx["absolute_return"]], rtol=1e-9)
+
+
+def _check_f1_brackets(obj, fx):
+    """The recorded F1 lies inside the bracket, and the bracket is no wider than the exactly-cancelled cells allow: moving
+    c cells between the classes moves 2tp / (2tp + fp + fn) by at most 2c / (tp + fn) -- a [0, 1] bracket does not pass."""
+    assert len(obj.f1_bracket) == len(obj.f1_cancelled) == len(fx["f1"])
+    for k, ((lo, hi), share, want) in enumerate(zip(obj.f1_bracket, obj.f1_cancelled, fx["f1"])):
+        lo, hi = min(lo, hi), max(lo, hi)
+        assert lo - 1e-9 <= want <= hi + 1e-9, (lo, want, hi)
+        assert hi - lo <= 2 * share + 1e-9, (lo, hi, share)
+        assert hi - lo < 0.2, (k, lo, hi)   # (widest where footprints overlap most: ~0.1 after the start sensing, 0.15 for the sweeps)
 
 
 def _check_curves(obj, entropies, f1s, fx):
     np.testing.assert_allclose(entropies, fx["entropies"], rtol=RTOL)
     assert f1s[0] == fx["f1"][0] == 0.0
-    assert len(obj.f1_bracket) == len(fx["f1"])
-    for (lo, hi), want in zip(obj.f1_bracket, fx["f1"]):   # exactly-cancelled cells: see the IG test above
-        assert min(lo, hi) - 1e-9 <= want <= max(lo, hi) + 1e-9, (lo, want, hi)
+    _check_f1_brackets(obj, fx)   # exactly-cancelled cells: see the IG test above
 
 
 def test_random_baseline_replays_reference_run(golden):
@@ -303,3 +314,43 @@ def test_batched_ig_policy_matches_oracle():
             util = O.ig_cell_utilities(pls, O.ig_relative(gls))
             assert [int(np.argmax(u)) for u in util] == list(chosen[e]), (t, e)
         env.steps(t, policy=POLICY_EXPLICIT, actions=acts, features=False)
+
+
+def test_state_and_metric_helpers_match_reference(golden):
+    """utils.state.get_w_entropy_map / get_shannon_entropy and utils.utils.get_wrmse (the names IG_baseline.py:28-29 and
+    coma_test.py:25-26 import) against the planes the reference itself returned (entropy_reward.npz)."""
+    from ippmarl.agent.state_space import AgentStateSpace
+    from ippmarl.utils.state import get_shannon_entropy, get_w_entropy_map
+    from ippmarl.utils.utils import get_wrmse
+    fx = golden("entropy_reward")
+    params = make_params("small")
+    ss = AgentStateSpace(params)
+    for k in range(3):
+        after, truth = fx[f"after{k}"], fx[f"truth{k}"].astype(np.float64)
+        for mode in ("reward", "eval", "global"):
+            arg = after.copy()
+            wH, w, H, fp, grid = get_w_entropy_map(None, arg, truth, mode, ss)
+            assert fp is None
+            np.testing.assert_allclose(wH, fx[f"{mode}{k}_wH"], rtol=RTOL, atol=2e-6, err_msg=f"{mode} wH")
+            np.testing.assert_array_equal(w, fx[f"{mode}{k}_w"])
+            np.testing.assert_allclose(H, fx[f"{mode}{k}_H"], rtol=RTOL, atol=2e-6)
+            np.testing.assert_allclose(grid, fx[f"{mode}{k}_p"], rtol=RTOL, atol=2e-7)
+            assert w.dtype == fx[f"{mode}{k}_w"].dtype and wH.dtype == fx[f"{mode}{k}_wH"].dtype
+            assert np.array_equal(arg, after)                       # the caller's map is copied / resized, never clipped
+        p = after.copy()
+        H = get_shannon_entropy(p, ss)
+        assert p.min() >= np.float32(0.0001) and p.max() <= np.float32(0.9999)   # clipped in place (utils/state.py:118-121)
+        np.testing.assert_allclose(H, fx[f"reward{k}_H"], rtol=RTOL, atol=2e-6)
+    # actor mode: the footprint image goes through the same resize + weights
+    rng = np.random.RandomState(4)
+    m, fpimg = rng.random_sample((128, 128)).astype(np.float32), rng.random_sample((60, 60))
+    wH, w, H, wfp, grid = get_w_entropy_map(fpimg.copy(), m, np.zeros((128, 128)), "actor", ss)
+    q = O.area_resize(m.astype(np.float64), (11, 11))
+    f = O.area_resize(fpimg, (11, 11))
+    np.testing.assert_allclose(grid, np.clip(q, 1e-4, 0.9999), rtol=RTOL)
+    np.testing.assert_allclose(wfp, O.class_weights(f) * O.shannon_entropy(f.copy()), rtol=RTOL, atol=2e-6)
+    # F1 of the thresholded map (utils/utils.py:43-76) on a 128 x 128 map with values on both sides of, and exactly at, 0.5
+    truth = (rng.random_sample((128, 128)) > 0.6).astype(np.float64)
+    state = np.where(rng.random_sample((128, 128)) < 0.3, 0.5, m).astype(np.float32)
+    state[:4, :4] = np.float32(0.5) + np.float32(2 ** -24)
+    np.testing.assert_allclose(get_wrmse(state, truth, params), O.f1_target(state, truth), rtol=1e-12)

@@ -50,11 +50,12 @@ def test_actor_and_critic_step_match_reference(golden):
     np.testing.assert_allclose([am[k] for k in ACTOR_TAGS[7:]], fx["actor_metrics"][7:], rtol=3e-2, atol=1e-6)
 
 
-def test_trainer_round_and_td_chains():
+@pytest.mark.parametrize("name,n_envs", [("small", 6), ("c2", 64)])   # c2 x 64 envs: BASELINE config 3 at its real grid
+def test_trainer_round_and_td_chains(name, n_envs):
     from ippmarl.trainer import COMATrainer
-    params = make_params("small")
+    params = make_params(name)
     torch.manual_seed(0)
-    tr = COMATrainer(params, n_envs=6, waves_per_update=2, first_episode=3)
+    tr = COMATrainer(params, n_envs=n_envs, waves_per_update=2, first_episode=3)
     s1 = tr.rollout("train")
     s2 = tr.rollout("train")
     assert s1["faults"] == 0 and np.isfinite(s1["episode_return"]) and np.isfinite(s2["episode_return"])
@@ -171,3 +172,57 @@ def test_evaluation_metrics_match_oracle():
         want = O.f1_target(glob[e], truth[e])
         assert worst - 1e-9 <= want <= best + 1e-9 and worst - 1e-9 <= float(f1[e]) <= best + 1e-9
         assert np.array_equal(strict[e, [0, 2]].sum(), truth[e].sum())          # tp + fn = number of target cells
+
+
+def test_evaluate_scores_the_freshly_sensed_measurements():
+    """COMATrainer.evaluate() against the oracle's restatement of the coma_test loop (coma_test.py:98-196): the map scored at
+    index t+1 holds the measurements taken right AFTER the move of step t (the env's own global fusion lags by one step).
+    A stub actor with fixed preferences makes the greedy choice a function of the masks alone, so the oracle can follow."""
+    from ippmarl.trainer import COMATrainer
+    params = make_params("small", experiment__missions__n_agents=3)
+    d = O.Derived(params)
+    seed, E, first = 77, 3, 21
+    tr = COMATrainer(params, n_envs=E, philox_seed=seed, first_episode=first)
+    prefs = torch.tensor([0.05, 0.3, 0.1, 0.25, 0.2, 0.1])
+
+    class Stub(torch.nn.Module):
+        def forward(self, obs, eps):
+            return prefs.to(obs.device).expand(obs.shape[0], -1).contiguous(), None
+
+    tr.actor = Stub()
+    out = tr.evaluate(waves=1)
+    ents, f1s = [], []
+    for ep_no in range(first, first + E):
+        holder, seen = {}, {}
+
+        def correctness(i, s, shape, ep_no=ep_no, holder=holder):
+            pos = holder["ep"].agents[i]["position"]
+            _, fc = O.project_field_of_view(d, pos)
+            return O.philox_correctness(seed, ep_no, i, s, fc, d.gy, O.noise_of_altitude(pos[2]))
+
+        ep = O.OracleEpisode(params, ep_no, correctness, lambda i, t, m, o: int(np.argmax(prefs.numpy() * m)),
+                             comm_draw=lambda i, j, t, ep_no=ep_no: O.philox_comm_draw(seed, ep_no, i, j, t), build_features=False,
+                             exact=True)
+        holder["ep"] = ep
+        real_sense = ep._sense
+
+        def sense(i, s, ep=ep, seen=seen, real_sense=real_sense):
+            real_sense(i, s)
+            seen[(i, s)] = ep.agents[i]["map2communicate"]
+
+        ep._sense = sense
+        g = O.init_prior_map(ep.d)
+        ent, f1 = [O.target_entropy(ep.d, g.copy(), ep.truth)], [O.f1_target(g, ep.truth)]
+        for t in range(d.budget + 1):
+            ep.step(t)
+            if t == 0:
+                g = O.fuse_map(ep.d, g, {i: dict(map2communicate=seen[(i, 0)]) for i in range(d.n_agents)}, None, "global")
+            g = O.fuse_map(ep.d, g, [seen[(i, t + 1)] for i in range(d.n_agents)], None, "global")
+            ent.append(O.target_entropy(ep.d, g.copy(), ep.truth))
+            f1.append(O.f1_target(g, ep.truth))
+        ents.append(ent)
+        f1s.append(f1)
+    np.testing.assert_allclose(out["target_entropy"], np.mean(ents, axis=0), rtol=1e-5)
+    # F1 thresholds at p > 0.5: exactly-cancelled cells are rounding noise on either side (DESIGN.md section 7)
+    np.testing.assert_allclose(out["f1"], np.mean(f1s, axis=0), atol=0.05)
+    assert abs(out["f1"][-1] - np.mean(f1s, axis=0)[-1]) < 0.05 and out["f1"][1] > 0
