@@ -280,6 +280,13 @@ int ippm_entropy_maps(ippm_ctx* ctx, const float* prob, const float* target, flo
 int ippm_coma_advantage(ippm_ctx* ctx, const float* probs, const float* q, const uint8_t* mask,
                         const int32_t* action, float* advantage, float* pi_tilde, int32_t batch, void* stream);
 
+/* col2im of the input gradient of a stride-1, unpadded kernel x kernel convolution evaluated as a GEMM (the learners' conv2:
+ * actor/network.py:19-21, critic/network.py:21-23; MIOpen's float32 backward-data kernel runs it at a third of the forward's
+ * rate).  cols float [batch*out_h*out_w, kernel*kernel*channels] (tap-major, channel-minor) -> grad_x float
+ * [batch, out_h+kernel-1, out_w+kernel-1, channels] (channels-last).  No context needed. */
+int ippm_col2im_nhwc(const float* cols, float* grad_x, int32_t batch, int32_t out_h, int32_t out_w, int32_t kernel,
+                     int32_t channels, void* stream);
+
 /* ---- K8: BatchMemory.build_td_targets (batch_memory.py:120-162) over `chains` independent transition
  * lists of length `len` (row-major [chains,len]): reward float, done uint8, q_sel float = target critic
  * Q(s_t)[a_t] -> td_target, discounted_return float. */

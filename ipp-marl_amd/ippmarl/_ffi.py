@@ -81,6 +81,7 @@ PROTOTYPES = {
     "ippm_critic_features": [P, P, P, P, P, P, P, I32, P],
     "ippm_coma_advantage": [P, P, P, P, P, P, P, I32, P],
     "ippm_td_lambda": [P, P, P, P, P, P, I32, I32, P],
+    "ippm_col2im_nhwc": [P, P, I32, I32, I32, I32, I32, P],
     "ippm_ig_candidates": [P, P, P, P, P, I32, P],
     "ippm_ig_select": [P, P, P, P, I32, P, P, I32, P],
     "ippm_f1_counts": [P, P, P, I32, C.c_float, P, I32, P],

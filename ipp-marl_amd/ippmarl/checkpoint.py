@@ -3,7 +3,9 @@
 The reference saves the WHOLE actor module with ``torch.save(actor_network, path)``, i.e. a pickle that names the class
 ``actor.network.ActorNetwork`` (or ``marl_framework.actor.network.ActorNetwork``).  ``load_reference_actor`` unpickles
 such a file onto :class:`ippmarl.networks.ActorNetwork` (same layer names and shapes) without needing the reference on
-the path; ``save_actor`` writes the same whole-module format for our class."""
+the path.  ``save_actor`` writes a whole-module pickle that names the REFERENCE's class path, so the reference's own
+``torch.load(best_model.pth)`` (coma_test.py:52-56) resolves it to its ``actor.network.ActorNetwork`` without this package
+(or libippmarl.so) being importable, and puts the plain ``state_dict`` next to it."""
 from __future__ import annotations
 
 import pickle
@@ -45,5 +47,36 @@ def load_reference_actor(path: str, params: Dict, map_location="cpu") -> ActorNe
     return actor
 
 
-def save_actor(actor: ActorNetwork, path: str):
-    torch.save(actor, path)
+def save_actor(actor: ActorNetwork, path: str, reference_class_path: str = "actor.network"):
+    """Whole-module pickle of the actor under the reference's class path + ``<path>.state_dict`` (weights only).
+
+    pickle stores classes by (module, name) and insists that importing that name yields the very class being pickled, so
+    for the duration of the save the class is registered under ``reference_class_path`` (the reference's scripts run with
+    marl_framework/ as the working directory: ``actor.network``).  Only module state travels in the pickle (parameters,
+    buffers, the ``params`` dict, plain attributes), all of which the reference's class accepts through ``__setstate__``."""
+    import sys
+    import types
+    cls = type(actor)
+    saved_module = cls.__module__
+    parts = reference_class_path.split(".")
+    created = []
+    for k in range(1, len(parts) + 1):
+        name = ".".join(parts[:k])
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+            created.append(name)
+    holder = sys.modules[reference_class_path]
+    had = getattr(holder, cls.__name__, None)
+    try:
+        setattr(holder, cls.__name__, cls)
+        cls.__module__ = reference_class_path
+        torch.save(actor, path)
+    finally:
+        cls.__module__ = saved_module
+        if had is None:
+            delattr(holder, cls.__name__)
+        else:
+            setattr(holder, cls.__name__, had)
+        for name in created:
+            del sys.modules[name]
+    torch.save(actor.state_dict(), path + ".state_dict")

@@ -40,23 +40,36 @@ class CriticLearner:
                 for t, s in zip(self.target_critic.parameters(), self.critic.parameters()):
                     t.mul_(1 - self.tau).add_(s, alpha=self.tau)
 
-    def step(self, states: torch.Tensor, actions: torch.Tensor, td_targets: torch.Tensor, grad_hook=None):
-        """One minibatch: MSE on the chosen Q, Adam step, then the POST-step Q handed to the actor
-        (critic/learner.py:76-105).  Returns (loss, q_new [B,A])."""
+    def backward(self, states: torch.Tensor, actions: torch.Tensor, td_targets: torch.Tensor):
+        """First half of a minibatch step: MSE on the chosen Q and its gradients (critic/learner.py:76-92).  The gradients
+        are cleared in place, so views handed out by parallel.GradAllReducer.attach stay valid."""
         q, _ = self.critic(states)
         q_chosen = q.gather(1, actions.long().view(-1, 1))
         loss = torch.square(q_chosen - td_targets.view(-1, 1).detach()).squeeze().mean()
-        self.optimizer.zero_grad()
+        self.optimizer.zero_grad(set_to_none=False)
         loss.backward()
-        if grad_hook is not None:
-            grad_hook(self.critic)
+        self._pending = (states, actions, td_targets, loss.detach(), q_chosen.detach())
+        return loss.detach()
+
+    def apply(self):
+        """Second half: Adam step, then the POST-step Q handed to the actor (critic/learner.py:93-105).  -> q_new [B,A]"""
+        states, actions, td_targets, loss, q_chosen = self._pending
+        self._pending = None
         self.optimizer.step()
         with torch.no_grad():
             q_new, logp = self.critic(states)
         if self.collect:
-            self.last = dict(loss=loss.detach(), q_chosen=q_chosen.detach(), td=td_targets.detach(), q_new=q_new,
+            self.last = dict(loss=loss, q_chosen=q_chosen, td=td_targets.detach(), q_new=q_new,
                              logp_chosen=logp.view(-1, q_new.shape[-1]).gather(1, actions.long().view(-1, 1)))
-        return loss.detach(), q_new
+        return q_new
+
+    def step(self, states: torch.Tensor, actions: torch.Tensor, td_targets: torch.Tensor, grad_hook=None):
+        """One minibatch: MSE on the chosen Q, Adam step, then the POST-step Q handed to the actor
+        (critic/learner.py:76-105).  Returns (loss, q_new [B,A])."""
+        loss = self.backward(states, actions, td_targets)
+        if grad_hook is not None:
+            grad_hook(self.critic)
+        return loss, self.apply()
 
 
 class ActorLearner:
@@ -88,22 +101,30 @@ class ActorLearner:
         self.ctx.call("ippm_coma_advantage", _ffi.ptr(p32), _ffi.ptr(q32), _ffi.ptr(m8), _ffi.ptr(a32), _ffi.ptr(adv), None, b, stream)
         return adv
 
-    def step(self, observations: torch.Tensor, actions: torch.Tensor, masks: torch.Tensor, q_values: torch.Tensor, eps: float,
-             grad_hook=None):
-        """One minibatch (actor/learner.py:52-101).  The reference's loss broadcasts [B,1]*[B,1]*[B,A] before the
-        mean, i.e. every sample is weighted by (#valid actions)/A."""
+    def backward(self, observations: torch.Tensor, actions: torch.Tensor, masks: torch.Tensor, q_values: torch.Tensor, eps: float):
+        """First half of a minibatch step (actor/learner.py:52-97): loss and gradients.  The reference's loss broadcasts
+        [B,1]*[B,1]*[B,A] before the mean, i.e. every sample is weighted by (#valid actions)/A."""
         probs, hidden = self.actor(observations, eps)
         log_probs = torch.log(probs)
         adv = self.advantage(probs, q_values, masks, actions)
         log_chosen = log_probs.gather(1, actions.long().view(-1, 1)).squeeze(1)
         weight = masks.to(log_chosen.dtype).sum(-1) / self.n_actions
         loss = -(adv.detach() * log_chosen * weight).mean()
-        self.optimizer.zero_grad()
+        self.optimizer.zero_grad(set_to_none=False)
         loss.backward()
-        if grad_hook is not None:
-            grad_hook(self.actor)
-        self.optimizer.step()
         if self.collect:
             self.last = dict(loss=loss.detach(), adv=adv.detach(), log_probs=log_probs.detach(), log_chosen=log_chosen.detach(),
                              hidden0=hidden[0].detach())
         return loss.detach(), adv
+
+    def apply(self):
+        self.optimizer.step()
+
+    def step(self, observations: torch.Tensor, actions: torch.Tensor, masks: torch.Tensor, q_values: torch.Tensor, eps: float,
+             grad_hook=None):
+        """One minibatch (actor/learner.py:52-101)."""
+        loss, adv = self.backward(observations, actions, masks, q_values, eps)
+        if grad_hook is not None:
+            grad_hook(self.actor)
+        self.apply()
+        return loss, adv

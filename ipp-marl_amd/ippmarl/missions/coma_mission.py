@@ -16,6 +16,7 @@ from typing import Dict, Optional
 import torch
 
 from .. import metrics
+from ..checkpoint import save_actor
 from ..trainer import COMATrainer
 from .missions import Mission
 
@@ -67,9 +68,9 @@ class COMAMission(Mission):
         os.makedirs(self.log_dir, exist_ok=True)
         if len(self.episode_returns) >= self.patience and running > self.max_mean_episode_return:
             self.max_mean_episode_return = running
-            torch.save(actor_network, os.path.join(self.log_dir, "best_model.pth"))
+            save_actor(actor_network, os.path.join(self.log_dir, "best_model.pth"))
         if self.training_step_idx in (300, 400, 500, 600):
-            torch.save(actor_network, os.path.join(self.log_dir, f"best_model_{self.training_step_idx}.pth"))
+            save_actor(actor_network, os.path.join(self.log_dir, f"best_model_{self.training_step_idx}.pth"))
 
     def execute(self):
         tr = self.trainer

@@ -21,12 +21,58 @@ for _v in ("FWD", "BWD", "WRW"):
     os.environ.setdefault(f"MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_{_v}", "0")
 
 
+# conv3 as a GEMM (see _ConvTrunk.trunk); IPPMARL_CONV3_GEMM=0 keeps the convolution call
+CONV3_AS_GEMM = os.environ.get("IPPMARL_CONV3_GEMM", "1") != "0"
+# conv2's input gradient as GEMM + col2im (see _ConvDataGradAsGemm); IPPMARL_CONV2_BWD_GEMM=0 keeps the library's kernel
+CONV2_BWD_DATA_AS_GEMM = os.environ.get("IPPMARL_CONV2_BWD_GEMM", "1") != "0"
+
+
 def epsilon_schedule(params: Dict, num_episode: int) -> float:
     """Linear anneal eps_max -> eps_min over eps_anneal_phase episodes (actor/network.py:53-58)."""
     m = params["experiment"]["missions"]
     if num_episode > m["eps_anneal_phase"]:
         return m["eps_min"]
     return m["eps_max"] - num_episode / m["eps_anneal_phase"] * (m["eps_max"] - m["eps_min"])
+
+
+class _ConvDataGradAsGemm(torch.autograd.Function):
+    """conv2d whose INPUT gradient is a GEMM + col2im instead of the library's implicit-GEMM backward-data kernel.
+
+    Measured on MI355X (profiles/r02/coma_update_flops.json): MIOpen's float32 forward and weight-gradient kernels run this
+    4x4 convolution at 132 / 136 TFLOP/s (84-87 % of the float32 matrix peak), its backward-data kernel at 48 -- 44 % of a
+    COMA update's kernel time.  The input gradient of a stride-1 convolution is  fold(grad_out[B*L, O] x W[O, C*kh*kw])  (L =
+    output positions): one hipBLASLt GEMM at the forward's rate plus a memory-bound scatter.  Forward, weight and bias
+    gradients stay with the library."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return torch.nn.functional.conv2d(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, weight = ctx.saved_tensors
+        grad_x = grad_w = grad_b = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            _, grad_w, grad_b = torch.ops.aten.convolution_backward(
+                grad_out, x, weight, [weight.shape[0]], [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, True])
+        if ctx.needs_input_grad[0]:
+            B, O, Ho, Wo = grad_out.shape
+            C, K = weight.shape[1], weight.shape[2]
+            g = grad_out.permute(0, 2, 3, 1).reshape(B * Ho * Wo, O)                  # [B*L, O] (a view for channels-last)
+            if grad_out.is_cuda and C % 4 == 0 and weight.shape[2] == weight.shape[3]:
+                # tap-major, channel-minor columns: the gather kernel of libippmarl reads and writes channels-last rows
+                cols = g.contiguous() @ weight.permute(0, 2, 3, 1).reshape(O, -1)     # [B*L, K*K*C]
+                from . import _ffi
+                grad_x = torch.empty(B, Ho + K - 1, Wo + K - 1, C, dtype=cols.dtype, device=cols.device)
+                _ffi.check(_ffi.load_library().ippm_col2im_nhwc(_ffi.ptr(cols), _ffi.ptr(grad_x), B, Ho, Wo, K, C,
+                                                                torch.cuda.current_stream(cols.device).cuda_stream), "ippm_col2im_nhwc")
+                grad_x = grad_x.permute(0, 3, 1, 2)                                   # logical NCHW, channels-last strides
+            else:
+                cols = g @ weight.reshape(O, -1)                                       # [B*L, C*kh*kw]
+                cols = cols.view(B, Ho * Wo, -1).transpose(1, 2)                       # [B, C*kh*kw, L]
+                grad_x = torch.nn.functional.fold(cols, x.shape[-2:], weight.shape[-2:])
+        return grad_x, grad_w, grad_b
 
 
 class _ConvTrunk(nn.Module):
@@ -46,9 +92,18 @@ class _ConvTrunk(nn.Module):
             x = x.unsqueeze(0)
         x = x.permute(0, 3, 1, 2)  # NHWC storage -> logical NCHW (channels_last strides, no copy)
         h = self.activation(self.conv1(x))
-        h = self.activation(self.conv2(h))
-        h = self.activation(self.conv3(h))
-        h = self.flatten(h)
+        if CONV2_BWD_DATA_AS_GEMM and h.requires_grad:
+            h = self.activation(_ConvDataGradAsGemm.apply(h, self.conv2.weight, self.conv2.bias))
+        else:
+            h = self.activation(self.conv2(h))
+        if CONV3_AS_GEMM and h.shape[-2:] == self.conv3.kernel_size:
+            # conv3 sees a 4x4 map with a 4x4 kernel: ONE output position, i.e. a plain [B, 4096] x [4096, 256] product.
+            # As a GEMM it goes to hipBLASLt instead of an implicit-GEMM convolution with a degenerate output tile.
+            # (h is channels-last: flattening it in (H, W, C) order is a view; the weight is permuted to match.)
+            w3 = self.conv3.weight.permute(0, 2, 3, 1).reshape(self.conv3.out_channels, -1)
+            h = self.activation(torch.nn.functional.linear(h.permute(0, 2, 3, 1).reshape(h.shape[0], -1), w3, self.conv3.bias))
+        else:
+            h = self.flatten(self.activation(self.conv3(h)))
         return self.fc3(self.activation(self.fc1(h))), h
 
 

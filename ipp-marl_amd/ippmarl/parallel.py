@@ -27,28 +27,86 @@ def episode_ids(first_episode: int, wave: int, envs_per_rank: int, rank: int, wo
 
 
 class GradAllReducer:
-    """Averages the gradients of a module across ranks with one flat all-reduce (call after backward())."""
+    """Gradient averaging across ranks without staging copies.
+
+    ``attach(*modules)`` lays the gradients of all the modules' trainable parameters out in ONE persistent flat buffer and
+    makes every ``p.grad`` a view into it (``fc2`` of the convnets is skipped: the reference keeps that layer but never
+    uses it, so it never has a gradient).  ``reducer(module, ...)`` then all-reduces the span of the buffer that holds the
+    named modules in a single call -- no ``torch.cat``, no copy-back; modules attached next to each other (the trainer
+    attaches critic then actor) go out together.  Optimizers must clear gradients with ``zero_grad(set_to_none=False)``
+    (``GradAllReducer.zero``) so that the views survive.
+    """
 
     def __init__(self, group: Optional[dist.ProcessGroup] = None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.bytes_reduced = 0
+        self.calls = 0
+        self.flat: Optional[torch.Tensor] = None
+        self.spans = {}   # id(module) -> (lo, hi) in elements
+
+    @staticmethod
+    def _trainable(module: torch.nn.Module):
+        return [p for n, p in module.named_parameters() if p.requires_grad and not n.startswith("fc2")]
+
+    def attach(self, *modules: torch.nn.Module):
+        params = [p for m in modules for p in self._trainable(m)]
+        total = sum(p.numel() for p in params)
+        self.flat = torch.zeros(total, dtype=params[0].dtype, device=params[0].device)
+        off = 0
+        for m in modules:
+            lo = off
+            for p in self._trainable(m):
+                p.grad = self.flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+            self.spans[id(m)] = (lo, off)
+        return self
+
+    def zero(self, *modules: torch.nn.Module):
+        """Clears the gradients of the modules in place (their views into the flat buffer stay)."""
+        for m in modules:
+            lo, hi = self.spans[id(m)]
+            self.flat[lo:hi].zero_()
 
     def __call__(self, *modules: torch.nn.Module):
         if self.world == 1:
             return
-        grads: List[torch.Tensor] = [p.grad for m in modules for p in m.parameters() if p.grad is not None]
-        if not grads:
+        if self.flat is None or any(id(m) not in self.spans for m in modules):   # unattached modules: staged path
+            grads: List[torch.Tensor] = [p.grad for m in modules for p in m.parameters() if p.grad is not None]
+            if not grads:
+                return
+            flat = torch.cat([g.reshape(-1) for g in grads])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            flat.div_(self.world)
+            off = 0
+            for g in grads:
+                g.copy_(flat[off:off + g.numel()].view_as(g))
+                off += g.numel()
+            self.bytes_reduced += flat.numel() * flat.element_size()
+            self.calls += 1
             return
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        flat.div_(self.world)
-        off = 0
-        for g in grads:
-            n = g.numel()
-            g.copy_(flat[off:off + n].view_as(g))
-            off += n
-        self.bytes_reduced += flat.numel() * flat.element_size()
+        spans = sorted(self.spans[id(m)] for m in modules)
+        merged = [list(spans[0])]
+        for lo, hi in spans[1:]:
+            if lo == merged[-1][1]:
+                merged[-1][1] = hi
+            else:
+                merged.append([lo, hi])
+        for lo, hi in merged:   # adjacent modules: one call
+            view = self.flat[lo:hi]
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+            view.div_(self.world)
+            self.bytes_reduced += view.numel() * view.element_size()
+            self.calls += 1
+
+
+def max_over_ranks(value: float, device, group: Optional[dist.ProcessGroup] = None) -> float:
+    """The slowest rank's figure (bench.py times a region per rank and reports the maximum)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t[0])
 
 
 def broadcast_module(module: torch.nn.Module, src: int = 0, group: Optional[dist.ProcessGroup] = None):

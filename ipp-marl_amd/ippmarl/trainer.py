@@ -43,7 +43,9 @@ class COMATrainer:
         self.critic_learner = CriticLearner(params, self.critic, self.device)
         for m in (self.actor, self.critic, self.critic_learner.target_critic, self.frozen_target):
             broadcast_module(m)
-        self.reducer = GradAllReducer()
+        # gradients of both nets live in one flat buffer (critic, then actor): the data-parallel average is one all-reduce of a
+        # view, and the actor's gradients of minibatch b travel together with the critic's of minibatch b+1
+        self.reducer = GradAllReducer().attach(self.critic, self.actor)
         W, T, E, N = waves_per_update, self.T, self.E, self.N
         dev = self.device
         self.buf_obs = torch.empty(W, T, E, N, 11, 11, 7, device=dev)
@@ -146,18 +148,29 @@ class COMATrainer:
             self.critic_learner.update_target_network(self.train_step, data_pass)
             collect = diagnostics and data_pass == 0
             self.critic_learner.collect = self.actor_learner.collect = collect
-            q_new, crit_rec, act_rec = [], [], []
-            for b in range(self.batch_number):  # critic first over all minibatches (critic/learner.py:58-105)
-                idx = perm[b * bs:(b + 1) * bs]
-                closs, q = self.critic_learner.step(states[idx], actions[idx], td[idx], grad_hook=self.reducer)
-                q_new.append(q)
+            crit_rec, act_rec = [], []
+            # Reference order (critic/learner.py:58-105, actor/learner.py:36-101): all critic minibatches, each followed by
+            # the post-step Q of ITS minibatch, then all actor minibatches with those Q.  Neither net's step feeds the
+            # other's, so interleaving them -- actor(b) right after critic(b) -- computes the same numbers; it lets the
+            # gradient exchange of actor(b) and critic(b+1) share one all-reduce (B+1 collectives per pass, not 2B).
+            idx = [perm[b * bs:(b + 1) * bs] for b in range(self.batch_number)]
+            closs = self.critic_learner.backward(states[idx[0]], actions[idx[0]], td[idx[0]])
+            self.reducer(self.critic)
+            q_b = self.critic_learner.apply()
+            for b in range(self.batch_number):
                 if collect:
-                    crit_rec.append(dict(self.critic_learner.last, discounted=dr[idx]))
-            for b in range(self.batch_number):  # then the actor with the post-step Q values (actor/learner.py:36-101)
-                idx = perm[b * bs:(b + 1) * bs]
-                aloss, _ = self.actor_learner.step(obs[idx], actions[idx], masks[idx], q_new[b], self.eps, grad_hook=self.reducer)
+                    crit_rec.append(dict(self.critic_learner.last, discounted=dr[idx[b]]))
+                aloss, _ = self.actor_learner.backward(obs[idx[b]], actions[idx[b]], masks[idx[b]], q_b, self.eps)
                 if collect:
                     act_rec.append(self.actor_learner.last)
+                if b + 1 < self.batch_number:
+                    closs = self.critic_learner.backward(states[idx[b + 1]], actions[idx[b + 1]], td[idx[b + 1]])
+                    self.reducer(self.critic, self.actor)
+                    self.actor_learner.apply()
+                    q_b = self.critic_learner.apply()
+                else:
+                    self.reducer(self.actor)
+                    self.actor_learner.apply()
             if collect:
                 from . import metrics
                 with torch.no_grad():
@@ -241,4 +254,5 @@ class COMATrainer:
 
     def save_actor(self, path: str):
         """Whole-module pickle of the actor, the reference's checkpoint format (coma_mission.py:425-451)."""
-        torch.save(self.actor, path)
+        from .checkpoint import save_actor
+        save_actor(self.actor, path)

@@ -226,3 +226,87 @@ def test_evaluate_scores_the_freshly_sensed_measurements():
     # F1 thresholds at p > 0.5: exactly-cancelled cells are rounding noise on either side
     np.testing.assert_allclose(out["f1"], np.mean(f1s, axis=0), atol=0.05)
     assert abs(out["f1"][-1] - np.mean(f1s, axis=0)[-1]) < 0.05 and out["f1"][1] > 0
+
+
+def test_interleaved_update_equals_reference_order():
+    """COMATrainer.update() runs actor(b) right after critic(b) so that one all-reduce carries actor(b) + critic(b+1); the
+    reference runs all critic minibatches, then all actor minibatches (critic/learner.py:58-105, actor/learner.py:36-101).
+    Same minibatches, same numbers: neither net's step feeds the other's."""
+    from ippmarl.trainer import COMATrainer
+    params = make_params("small")
+
+    def fresh():
+        torch.manual_seed(3)
+        tr = COMATrainer(params, n_envs=4, first_episode=5)
+        tr.rollout("train")
+        return tr
+
+    a, b = fresh(), fresh()
+    torch.manual_seed(11)
+    a.update()
+    torch.manual_seed(11)
+    W, T, E, N = b.filled, b.T, b.E, b.N
+    n = W * T * E * N
+    td, _ = b.td_targets()
+    obs, states = b.buf_obs[:W].reshape(n, 11, 11, 7), b.buf_state[:W].reshape(n, 11, 11, 12)
+    actions, masks = b.buf_action[:W].reshape(n), b.buf_mask[:W].reshape(n, b.A)
+    bs = n // b.batch_number
+    for data_pass in range(b.data_passes):
+        perm = torch.randperm(n, device=b.device)
+        b.critic_learner.update_target_network(b.train_step, data_pass)
+        q_new = []
+        for k in range(b.batch_number):
+            idx = perm[k * bs:(k + 1) * bs]
+            q_new.append(b.critic_learner.step(states[idx], actions[idx], td[idx])[1])
+        for k in range(b.batch_number):
+            idx = perm[k * bs:(k + 1) * bs]
+            b.actor_learner.step(obs[idx], actions[idx], masks[idx], q_new[k], b.eps)
+        if data_pass == 0:
+            b.train_step += 1
+    # MIOpen's weight-gradient kernels split K with atomics, so two runs of the SAME schedule differ in the last bits and Adam
+    # turns a near-zero gradient's sign into +-lr: nearly all weights agree to 1e-6, stragglers stay within a few lr (1e-4)
+    for pa, pb in zip(list(a.actor.parameters()) + list(a.critic.parameters()), list(b.actor.parameters()) + list(b.critic.parameters())):
+        assert float(((pa - pb).abs() <= 1e-6).float().mean()) >= 0.98
+        torch.testing.assert_close(pa, pb, rtol=0, atol=5e-4)
+    assert a.reducer.flat is not None and a.actor.conv1.weight.grad.data_ptr() >= a.reducer.flat.data_ptr()
+
+
+def test_conv2_input_gradient_through_gemm_and_col2im_kernel():
+    """networks._ConvDataGradAsGemm on the GPU (hipBLASLt GEMM + ippm_col2im_nhwc) against the library's own convolution
+    backward: same outputs, same gradients for every parameter and for the input."""
+    from ippmarl import networks as N
+    params = make_params("c2")
+    torch.manual_seed(4)
+    net = N.CriticNetwork(params).cuda()
+    x = torch.rand(96, 11, 11, 12, device="cuda", requires_grad=True)
+
+    def run(flag):
+        old, N.CONV2_BWD_DATA_AS_GEMM = N.CONV2_BWD_DATA_AS_GEMM, flag
+        try:
+            net.zero_grad()
+            x.grad = None
+            q, _ = net(x)
+            (q * q).sum().backward()
+            return q.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+        finally:
+            N.CONV2_BWD_DATA_AS_GEMM = old
+
+    q0, gx0, g0 = run(False)
+    q1, gx1, g1 = run(True)
+    torch.testing.assert_close(q1, q0, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(gx1, gx0, rtol=2e-4, atol=1e-6 * float(gx0.abs().max()))
+    for n in g0:
+        torch.testing.assert_close(g1[n], g0[n], rtol=2e-4, atol=2e-5 * float(g0[n].abs().max()), msg=n)
+    # the kernel alone against the definition (every column element lands in exactly one output sum)
+    from ippmarl import _ffi
+    B, Ho, Wo, K, C = 3, 4, 4, 4, 8
+    cols = torch.rand(B * Ho * Wo, K * K * C, device="cuda")
+    out = torch.empty(B, Ho + K - 1, Wo + K - 1, C, device="cuda")
+    _ffi.check(_ffi.load_library().ippm_col2im_nhwc(_ffi.ptr(cols), _ffi.ptr(out), B, Ho, Wo, K, C,
+                                                    torch.cuda.current_stream().cuda_stream), "ippm_col2im_nhwc")
+    want = torch.zeros_like(out)
+    cv = cols.view(B, Ho, Wo, K, K, C)
+    for ky in range(K):
+        for kx in range(K):
+            want[:, ky:ky + Ho, kx:kx + Wo] += cv[:, :, :, ky, kx]
+    torch.testing.assert_close(out, want, rtol=1e-6, atol=1e-6)
