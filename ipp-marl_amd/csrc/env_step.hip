@@ -270,6 +270,147 @@ k_sense_update(const ippm_config* __restrict__ c, const int64_t* __restrict__ ep
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// K3, tile form (no area tracking): the form the env-only step and bench.py's roofline run.
+// A footprint at 15 m is 90 cells = 23-24 four-cell groups: as one 32-lane row it fills 72-75 % of the lanes, and every
+// lane pays the full Philox round chain.  Here a row is covered by CH = 3 passes of `lpr` lanes (8 lanes x 3 for the 90-cell
+// footprint: 96-100 % of the lanes busy, 128-byte row segments), a wavefront covers 64/lpr rows, a workgroup 4 x that in ONE
+// trip -- no row loop in the common case -- with the CH loads of a lane's row in flight together.  Loads and stores go
+// through raw buffer resources (one VALU per address; a lane without work points out of range: loads return 0, stores
+// are dropped), per-cell selects are bit-mask blends, the clip is one v_med3.
+// ------------------------------------------------------------------------------------------------------
+typedef unsigned ippm_k3_u4 __attribute__((ext_vector_type(4)));
+#define IPPM_K3_RSRC(ptr, bytes) __builtin_amdgcn_make_buffer_rsrc((void*)(ptr), 0, (int)(bytes), 0x00020000)
+#define IPPM_K3_OOB 0x7FFFFFF0
+
+template <int VEC>
+__global__ void __launch_bounds__(256)
+k_sense_tiles(const ippm_config* __restrict__ c, const int64_t* __restrict__ episode, const int32_t* __restrict__ pos,
+              const uint8_t* __restrict__ truth, float* __restrict__ local, const uint8_t* __restrict__ flips,
+              uint8_t* __restrict__ code, const int32_t* __restrict__ rect_in, int32_t* __restrict__ rect_out,
+              int32_t* __restrict__ ws, double* __restrict__ sums, float* __restrict__ reward,
+              unsigned long long* __restrict__ counters, int stage, int agent_sel, int parts, int rows_per_part, int n_tiles,
+              int n_envs) {
+  constexpr int CH = 3;
+  if ((int)blockIdx.x >= n_tiles * parts) {  // reward-finalize tail
+    const int e = ((int)blockIdx.x - n_tiles * parts) * 256 + (int)threadIdx.x;
+    if (e < n_envs) ippm_reward_finalize_env(c, sums, reward, e);
+    return;
+  }
+  const int n = c->n_agents;
+  const int tile = blockIdx.x / parts, part = blockIdx.x % parts;
+  int e, i;
+  if (agent_sel >= 0) { e = tile; i = agent_sel; }
+  else { e = tile / n; i = tile % n; }
+  const int gx = c->grid_x, gy = c->grid_y, S = c->tile_stride;
+  const int32_t* p = pos + (size_t)(e * n + i) * 3;
+  int r[4];
+  if (rect_in) {
+    const int32_t* ri = rect_in + (size_t)(e * n + i) * 4;
+    r[0] = ri[0]; r[1] = ri[1]; r[2] = ri[2]; r[3] = ri[3];
+  } else {
+    ippm_footprint_rect(c, p[0], p[1], p[2], r, nullptr);
+  }
+  const int yu = r[0], yd = r[1], xl = r[2], xr = r[3];
+  if (rect_out && part == 0 && threadIdx.x < 4) rect_out[(size_t)(e * n + i) * 4 + threadIdx.x] = r[threadIdx.x];
+  const int h = xr - xl, w = yd - yu;
+  const int r0 = part * rows_per_part, r1 = min(h, r0 + rows_per_part);
+  if (w <= 0 || r0 >= r1) return;
+  const int k = ippm_alt_index(c, p[2]);
+  const float lp = c->logit_prior;
+  const float lm0 = c->logit_meas[k][0] - lp, lm1 = c->logit_meas[k][1] - lp;
+  const uint32_t thr = c->flip_threshold[k];
+  const float lc = c->logit_clip;
+  const int y0 = yu & ~(VEC - 1), tile_y0 = yu & ~3;
+  const int groups = (yd - y0 + VEC - 1) / VEC;
+  int shift = 3;
+  while (shift < 6 && ((groups + (1 << shift) - 1) >> shift) > CH) ++shift;
+  const int lpr = 1 << shift, rpw = 64 >> shift;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int sub = lane >> shift, gl = lane & (lpr - 1);
+  const size_t TB = ippm_tile_bytes(S, VEC);
+  const __amdgpu_buffer_rsrc_t rmap = IPPM_K3_RSRC(local + (size_t)(e * n + i) * gx * gy, (size_t)gx * gy * 4);
+  const __amdgpu_buffer_rsrc_t rtruth = IPPM_K3_RSRC(truth + (size_t)e * ippm_truth_bytes(gx, gy), ippm_truth_bytes(gx, gy));
+  const __amdgpu_buffer_rsrc_t rcode = IPPM_K3_RSRC(code + (size_t)(e * n + i) * TB, TB);
+  const __amdgpu_buffer_rsrc_t rflip = IPPM_K3_RSRC(flips ? flips + (size_t)(e * n + i) * TB : code, flips ? TB : 0);
+  const int64_t ep = episode ? episode[e] : 0;
+  const uint32_t sw = ippm_stream_word((uint32_t)i, (uint32_t)stage, IPPM_DOMAIN_FLIP);
+  const uint32_t k0 = (uint32_t)c->philox_seed, k1 = (uint32_t)(c->philox_seed >> 32);
+  float amax = 0.f;
+  for (int gbase = 0; gbase < groups; gbase += CH * lpr) {     // one trip unless the footprint is wider than 3 x 64 groups
+    for (int row = r0 + wv * rpw + sub; row < r1; row += 4 * rpw) {  // one trip for rows_per_part = 4 * rpw
+      const int x = xl + row;
+      CellVec<VEC> m[CH];
+      uint32_t tw[CH], fw[CH];
+      int cellv[CH];
+      bool on[CH];
+#pragma unroll
+      for (int q = 0; q < CH; ++q) {
+        const int gidx = gbase + gl + q * lpr;
+        on[q] = gidx < groups;
+        const int y = y0 + gidx * VEC;
+        const int cell = x * gy + y;
+        cellv[q] = cell;
+        if (VEC == 4) {
+          const ippm_k3_u4 t = __builtin_amdgcn_raw_buffer_load_b128(rmap, on[q] ? cell * 4 : IPPM_K3_OOB, 0, 0);
+          m[q].v[0] = __uint_as_float(t.x); m[q].v[1 % VEC] = __uint_as_float(t.y);
+          m[q].v[2 % VEC] = __uint_as_float(t.z); m[q].v[3 % VEC] = __uint_as_float(t.w);
+        } else {
+          m[q].v[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rmap, on[q] ? cell * 4 : IPPM_K3_OOB, 0, 0));
+        }
+        tw[q] = __builtin_amdgcn_raw_buffer_load_b8(rtruth, on[q] ? (cell >> 3) : IPPM_K3_OOB, 0, 0);
+        fw[q] = flips ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rflip, on[q] ? (int)tile_index<VEC>(row, y - tile_y0, S) : IPPM_K3_OOB, 0, 0)
+                      : 0u;
+      }
+#pragma unroll
+      for (int q = 0; q < CH; ++q) {
+        const int gidx = gbase + gl + q * lpr;
+        const int y = y0 + gidx * VEC;
+        const int cell = cellv[q];
+        const uint32_t tbits = VEC == 4 ? (tw[q] >> (cell & 4)) & 0xFu : (tw[q] >> (cell & 7)) & 1u;
+        uint32_t flipbits;
+        if (flips) {
+          flipbits = fw[q] & (VEC == 4 ? 0xFu : 1u);
+        } else if (VEC == 4) {
+          const Philox4 ph = ippm_philox((uint32_t)(cell >> 2), (uint32_t)ep, sw, (uint32_t)(ep >> 32), k0, k1);
+          flipbits = (ph.v[0] < thr ? 1u : 0u) | (ph.v[1] < thr ? 2u : 0u) | (ph.v[2] < thr ? 4u : 0u) | (ph.v[3] < thr ? 8u : 0u);
+        } else {
+          const Philox4 ph = ippm_philox((uint32_t)(cell >> 2), (uint32_t)ep, sw, (uint32_t)(ep >> 32), k0, k1);
+          const int s4 = cell & 3;
+          const uint32_t word = s4 == 0 ? ph.v[0] : s4 == 1 ? ph.v[1] : s4 == 2 ? ph.v[2] : ph.v[3];
+          flipbits = word < thr ? 1u : 0u;
+        }
+        uint32_t inm = 0;  // cells of the group inside the footprint's columns (edge groups)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) inm |= ((unsigned)(y + j - yu) < (unsigned)w) ? (1u << j) : 0u;
+        const uint32_t obs = (tbits ^ flipbits) & inm;
+        // mappings.py:109-124 in log-odds: clip the prior belief, add the measurement's log-odds (minus logit(prior))
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float old = m[q].v[j];
+          const float l = ippm_clampl(old, lc) + ippm_blend(ippm_bitmask(obs, j), lm1, lm0);
+          const uint32_t im = ippm_bitmask(inm, j);
+          m[q].v[j] = ippm_blend(im, l, old);
+          amax = fmaxf(amax, fabsf(ippm_masked(im, l)));
+        }
+        const int off = on[q] ? cell * 4 : IPPM_K3_OOB;
+        if (VEC == 4) {
+          ippm_k3_u4 t;
+          t.x = __float_as_uint(m[q].v[0]); t.y = __float_as_uint(m[q].v[1 % VEC]);
+          t.z = __float_as_uint(m[q].v[2 % VEC]); t.w = __float_as_uint(m[q].v[3 % VEC]);
+          __builtin_amdgcn_raw_buffer_store_b128(t, rmap, off, 0, 0);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m[q].v[0]), rmap, off, 0, 0);
+        }
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)obs, rcode, on[q] ? (int)tile_index<VEC>(row, y - tile_y0, S) : IPPM_K3_OOB, 0, 0);
+      }
+    }
+  }
+  if (ws && __any(amax > lc) && lane == 0) ws[(size_t)(e * (n + 1) + i) * IPPM_WS_WORDS + WS_FLAG_S] = 1;
+  if (counters && part == 0 && threadIdx.x == 0)
+    atomicAdd(&counters[(tile & (IPPM_COUNTER_SLOTS - 1)) * 8 + 0], (unsigned long long)h * w);
+}
+
 // full-grid weighted entropy per map (initialisation of T, evaluation metrics)
 __global__ void __launch_bounds__(256)
 k_weighted_entropy(const ippm_config* __restrict__ c, const float* __restrict__ maps, const uint8_t* __restrict__ truth,
@@ -394,9 +535,28 @@ extern "C" int ippm_sense_step(ippm_ctx* ctx, const int64_t* episode, const int3
   if ((sums == nullptr) != (reward == nullptr)) { ippm_set_error("ippm_sense_step: sums and reward go together"); return -1; }
   if (n_envs <= 0) return 0;
   const int maps = agent_sel >= 0 ? n_envs : n_envs * ctx->cfg.n_agents;
-  const int split = std::max(1, env_int("IPPM_SPLIT_K3", 2));
   const int tail = sums ? grid1(n_envs) : 0;
-  dim3 grid((unsigned)maps * split + tail), block(256);
+  dim3 block(256);
+  if (!area && !env_int("IPPM_K3_CLASSIC", 0)) {
+    // tile form: one trip per workgroup for the common footprints (rows_per_part = 4 wavefronts x 8 rows)
+    const ippm_config& c = ctx->cfg;
+    int h_max = 1;
+    for (int k = 0; k < c.space_z; ++k) h_max = std::max(h_max, 2 * c.radius_x[k]);
+    const int rows_per_part = std::max(4, env_int("IPPM_K3_ROWS", 32));
+    const int parts = (h_max + rows_per_part - 1) / rows_per_part;
+    dim3 grid((unsigned)maps * parts + tail);
+    int32_t* rect_out = rect_in == rect ? nullptr : rect;
+    if (ctx->vec == 4)
+      hipLaunchKernelGGL((k_sense_tiles<4>), grid, block, 0, S_(stream), ctx->dcfg, episode, pos, truth, local, flips, code, rect_in,
+                         rect_out, ws, sums, reward, ctx->dcounters, stage, agent_sel, parts, rows_per_part, maps, n_envs);
+    else
+      hipLaunchKernelGGL((k_sense_tiles<1>), grid, block, 0, S_(stream), ctx->dcfg, episode, pos, truth, local, flips, code, rect_in,
+                         rect_out, ws, sums, reward, ctx->dcounters, stage, agent_sel, parts, rows_per_part, maps, n_envs);
+    IPPM_LAUNCH_CHECK("sense_tiles");
+    return 0;
+  }
+  const int split = std::max(1, env_int("IPPM_SPLIT_K3", 2));
+  dim3 grid((unsigned)maps * split + tail);
   const int unr = env_int("IPPM_UNROLL_K3", 2);
   int32_t* rect_out = rect_in == rect ? nullptr : rect;
 #define IPPM_K3_LAUNCH(V, U, T)                                                                                               \

@@ -50,6 +50,7 @@ struct WaveCtx {   // what a wave needs while it walks its rows
   __amdgpu_buffer_rsrc_t map;    // this map: gx * gy floats
   __amdgpu_buffer_rsrc_t code;   // the whole code tensor (lanes outside an op's columns may point anywhere inside it)
   double* s_area;
+  double* sums_env;  // this env's reward sums (global map only), nullptr otherwise
   int gx, gy, row_bytes;
   float lc, wt, lp, inv_gx, inv_gy;
   int lane;
@@ -61,7 +62,6 @@ struct WaveCtx {   // what a wave needs while it walks its rows
 struct WaveAcc {
   bool exceed;
   float a1, aD, aT;
-  double d1, dD, dT;  // SHIFT only: there every cell of the grid enters the reward sums with a tiny H(b) - H(a)
   unsigned cells, opcells;
 };
 
@@ -119,6 +119,9 @@ __device__ __forceinline__ void walk_slab(const WaveCtx& w, const OpTable& t, Wa
   int cshift[NA];      // uniform part of a slot's code byte offset; a huge value (-> out of range, reads 0) for slots without bits
   float lm0[NA], lm1[NA];
   float lpk[NA];       // SHIFT: logit(prior) for the slots that are messages
+  // SHIFT: every cell of the grid enters the reward sums with a tiny H(b) - H(a); these are summed in float64 and go out
+  // at the end of the slab (kept out of WaveAcc: the common path must not carry six more registers)
+  double sd1 = 0.0, sdD = 0.0, sdT = 0.0;
   int keep_slot = -1;  // slot of the plan's last op: its outputs stay unclamped
   // Spare slots come FIRST: an empty slot still clips (like every op of the reference), which is a no-op ahead of the
   // first real op but would wrongly clip the last op's outputs behind it.
@@ -239,9 +242,9 @@ __device__ __forceinline__ void walk_slab(const WaveCtx& w, const OpTable& t, Wa
             for (int q = 0; q < VEC; ++q) {
               if (SHIFT) {
                 const double hb = entropy_l_f64(bsave[q], w.lc), ha = entropy_l_f64(mv.v[q], w.lc);
-                acc_out.d1 += (double)wa[q] * (hb - ha);
-                acc_out.dD += (double)(wa[q] - wb[q]) * hb;
-                acc_out.dT += (double)wa[q] * ha - (double)wb[q] * hb;
+                sd1 += (double)wa[q] * (hb - ha);
+                sdD += (double)(wa[q] - wb[q]) * hb;
+                sdT += (double)wa[q] * ha - (double)wb[q] * hb;
               } else {
                 const float hb = ippm_entropy_l(bsave[q], w.lc), ha = ippm_entropy_l(mv.v[q], w.lc);
                 acc_out.a1 += wa[q] * (hb - ha);
@@ -260,6 +263,14 @@ __device__ __forceinline__ void walk_slab(const WaveCtx& w, const OpTable& t, Wa
     acc_out.opcells += nrows * ops_here;
     if (TRACK) acc.flush(w.s_area, ac.cb);
   }
+  if (SHIFT && w.sums_env) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sd1 += __shfl_xor(sd1, o, 64); sdD += __shfl_xor(sdD, o, 64); sdT += __shfl_xor(sdT, o, 64); }
+    if (w.lane < 3) {
+      const double v = w.lane == 0 ? sd1 : (w.lane == 1 ? sdD : sdT);
+      if (v != 0.0) atomicAdd(&w.sums_env[SUM_ACC1 + w.lane], v);
+    }
+  }
 }
 
 #ifndef IPPM_FU_SMALL
@@ -274,7 +285,7 @@ __device__ __forceinline__ void walk_slab(const WaveCtx& w, const OpTable& t, Wa
 
 // One work item = (map, run of `wave_rows` consecutive rows of the map's op hull), done by one wavefront.
 // NAMAX = plan-size class of the launch (6 / 10 / 18): the row loops compiled in are those for <= NAMAX active ops.
-template <int VEC, bool TRACK, int NAMAX>
+template <int VEC, bool TRACK, int NAMAX, bool SHIFT>
 __device__ __forceinline__ void fuse_item(const ippm_config* __restrict__ c, float* __restrict__ local, float* __restrict__ global,
                                           const uint8_t* __restrict__ code, const int32_t* __restrict__ plan_ro,
                                           int32_t* __restrict__ ws, double* __restrict__ sums, double* __restrict__ area,
@@ -292,7 +303,7 @@ __device__ __forceinline__ void fuse_item(const ippm_config* __restrict__ c, flo
   const int4 ob = *reinterpret_cast<const int4*>(plan_ro + wbase + WS_OPS + min(lane, IPPM_MAX_OPS - 1) * OP_WORDS + 4);
   int edge = plan_ro[wbase + WS_OPS + min(lane >> 1, IPPM_MAX_OPS - 1) * OP_WORDS + ((lane & 1) ? OP_XR : OP_XL)];
   const int gx = c->grid_x, gy = c->grid_y, S = c->tile_stride;
-  const bool shift = c->logit_prior != 0.f;
+  constexpr bool shift = SHIFT;  // mapping.prior != 0.5: its own instantiation, so the common path carries none of its code
   if (nops > NAMAX || nops < min_ops) return;  // (another launch handles other plan sizes; 0 ops: nothing to do)
   const int r0 = X0 + chunk * wave_rows, r1 = min(X1, r0 + wave_rows);
   if (r0 >= r1) return;
@@ -354,6 +365,7 @@ __device__ __forceinline__ void fuse_item(const ippm_config* __restrict__ c, flo
   w.last_op = last_op;
   w.fusemask = fusemask;
   w.is_global = is_global;
+  w.sums_env = (is_global && sums) ? sums + (size_t)e * 8 : nullptr;
   if (TRACK) {
     area_lds_clear(s_area);
     w.inv_gx = __builtin_amdgcn_rcpf((float)gx);
@@ -361,7 +373,7 @@ __device__ __forceinline__ void fuse_item(const ippm_config* __restrict__ c, flo
     __syncthreads();
   }
   WaveAcc acc;
-  acc.exceed = false; acc.a1 = acc.aD = acc.aT = 0.f; acc.d1 = acc.dD = acc.dT = 0.0; acc.cells = acc.opcells = 0;
+  acc.exceed = false; acc.a1 = acc.aD = acc.aT = 0.f; acc.cells = acc.opcells = 0;
 
   // slabs that intersect my rows [r0, r1): the table is sorted, the first one is found with one ballot
   int s = __popcll(__ballot(lane < nslabs && st.xb <= r0));
@@ -395,16 +407,10 @@ __device__ __forceinline__ void fuse_item(const ippm_config* __restrict__ c, flo
   // wave reduction of the reward terms and work counters: one atomic per wavefront and quantity
   {
     const float fc = ippm_wave_sum((float)acc.cells), fo = ippm_wave_sum((float)acc.opcells);
-    double a1 = (double)ippm_wave_sum(acc.a1), aD = (double)ippm_wave_sum(acc.aD), aT = (double)ippm_wave_sum(acc.aT);
-    if (shift && is_global) {
-      double x1 = acc.d1, xD = acc.dD, xT = acc.dT;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { x1 += __shfl_xor(x1, o, 64); xD += __shfl_xor(xD, o, 64); xT += __shfl_xor(xT, o, 64); }
-      a1 += x1; aD += xD; aT += xT;
-    }
+    const float a1 = ippm_wave_sum(acc.a1), aD = ippm_wave_sum(acc.aD), aT = ippm_wave_sum(acc.aT);
     if (lane < 3) {
-      const double v = lane == 0 ? a1 : (lane == 1 ? aD : aT);
-      if (is_global && sums && v != 0.0) atomicAdd(&sums[(size_t)e * 8 + SUM_ACC1 + lane], v);
+      const float v = lane == 0 ? a1 : (lane == 1 ? aD : aT);
+      if (is_global && sums && v != 0.f) atomicAdd(&sums[(size_t)e * 8 + SUM_ACC1 + lane], (double)v);
     } else if (lane < 5 && counters) {
       const float v = lane == 3 ? fc : fo;
       if (v > 0.f) atomicAdd(&counters[(cslot & (IPPM_COUNTER_SLOTS - 1)) * 8 + (is_global ? 3 : 1) + (lane - 3)], (unsigned long long)v);
@@ -427,7 +433,7 @@ __device__ __forceinline__ void fuse_item(const ippm_config* __restrict__ c, flo
 #ifndef IPPM_FUSE_WAVES
 #define IPPM_FUSE_WAVES 4
 #endif
-template <int VEC, bool TRACK, int NAMAX>
+template <int VEC, bool TRACK, int NAMAX, bool SHIFT>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(IPPM_FUSE_WAVES, 8)))
 k_fuse_rows(const ippm_config* __restrict__ c, float* __restrict__ local, float* __restrict__ global,
             const uint8_t* __restrict__ code, const int32_t* __restrict__ plan_ro, int32_t* __restrict__ ws,
@@ -444,7 +450,7 @@ k_fuse_rows(const ippm_config* __restrict__ c, float* __restrict__ local, float*
     for (int i = blockIdx.x / n_envs_total; i < count; i += step) {
       const int item = items[i];
       const int m = item >> 8;
-      fuse_item<VEC, TRACK, NAMAX>(c, local, global, code, plan_ro, ws, sums, area, counters, s_area, wave_rows, min_ops, n_envs_total,
+      fuse_item<VEC, TRACK, NAMAX, SHIFT>(c, local, global, code, plan_ro, ws, sums, area, counters, s_area, wave_rows, min_ops, n_envs_total,
                                    m / (n + 1), m % (n + 1), item & 0xFF, blockIdx.x);
     }
     return;
@@ -455,7 +461,7 @@ k_fuse_rows(const ippm_config* __restrict__ c, float* __restrict__ local, float*
   if (unit >= local_units) { e = unit - local_units; slot = n; }
   else if (agent_sel >= 0) { e = unit; slot = agent_sel; }
   else { e = unit / n; slot = unit % n; }
-  fuse_item<VEC, TRACK, NAMAX>(c, local, global, code, plan_ro, ws, sums, area, counters, s_area, wave_rows, min_ops, n_envs_total, e, slot,
+  fuse_item<VEC, TRACK, NAMAX, SHIFT>(c, local, global, code, plan_ro, ws, sums, area, counters, s_area, wave_rows, min_ops, n_envs_total, e, slot,
                                chunk, blockIdx.x);
 }
 
@@ -506,14 +512,18 @@ static int launch_fuse(ippm_ctx* ctx, float* local, float* global, const uint8_t
   const int persist = std::max(64, env_int("IPPM_FUSE_PERSIST", 12288));
   const int pgrid = n_envs_total * std::max(1, std::min(persist / std::max(n_envs_total, 1), (c.n_agents + 1) * chunks));
   dim3 grid(work ? (unsigned)pgrid : (unsigned)units * chunks), block(64);
-#define IPPM_FUSE(V, T, NA, MINOPS)                                                                                  \
-  hipLaunchKernelGGL((k_fuse_rows<V, T, NA>), grid, block, 0, st, ctx->dcfg, local, global, code, ws, ws, sums, area, \
+#define IPPM_FUSE(V, T, NA, SH, MINOPS)                                                                                  \
+  hipLaunchKernelGGL((k_fuse_rows<V, T, NA, SH>), grid, block, 0, st, ctx->dcfg, local, global, code, ws, ws, sums, area, \
                      ctx->dcounters, work, wave_rows, chunks, MINOPS, local_units, agent_sel, n_envs_total, ippm_work_env_cap(ctx, n_envs_total))
-#define IPPM_FUSE_ALL(V, T)                    \
-  do {                                         \
-    IPPM_FUSE(V, T, 6, 1);                     \
-    if (max_ops > 6) IPPM_FUSE(V, T, 10, 7);   \
-    if (max_ops > 10) IPPM_FUSE(V, T, 18, 11); \
+#define IPPM_FUSE_ALL(V, T)                                  \
+  do {                                                       \
+    if (c.logit_prior != 0.f) {                              \
+      IPPM_FUSE(V, T, 18, true, 1); /* slow path: one size */ \
+      break;                                                 \
+    }                                                        \
+    IPPM_FUSE(V, T, 6, false, 1);                            \
+    if (max_ops > 6) IPPM_FUSE(V, T, 10, false, 7);          \
+    if (max_ops > 10) IPPM_FUSE(V, T, 18, false, 11);        \
   } while (0)
   static_assert(IPPM_MAX_OPS <= 18, "largest instantiation of k_fuse_rows");
   if (ctx->vec == 4) { if (area) IPPM_FUSE_ALL(4, true); else IPPM_FUSE_ALL(4, false); }
