@@ -105,8 +105,9 @@ def main():
                     help="ground truth: the power-law random field of ground_truths.py:25-40 generated on the device, or "
                          "the half-plane split the reference flies over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-events", type=int, default=1, help="bracket every K3 and fusion launch of the timed region with "
-                    "HIP events (roofline)")
+    ap.add_argument("--profile-events", type=int, default=4, help="bracket the K3 and fusion launches of every K-th step (and "
+                    "every K-th reset) of the timed region with HIP events for the roofline legs; an event pair costs ~3 us of "
+                    "stream time, so K=1 adds ~13 us to every step; 0 = no brackets")
     ap.add_argument("--train-rounds", type=int, default=2, help="COMA rounds (rollout with the actor + full update) timed after "
                     "the env-only region for the COMA updates/s figure; 0 disables")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI; gloo lets the "
@@ -148,8 +149,14 @@ def main():
         env.reset(episode_ids(1, wave[0], E, rank, world))   # disjoint episodes per rank and wave
         wave[0] += 1
 
+    sample = [0]
+
+    def sampled():   # every K-th launch group of the timed region carries event brackets
+        sample[0] += 1
+        return bool(args.profile_events) and sample[0] % args.profile_events == 0
+
     def one_step(t, timed):
-        env.profile = bool(timed and args.profile_events)
+        env.profile = timed and sampled()
         if args.graphs:
             env.step_graphed(t)
         else:
@@ -181,11 +188,13 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    resets_timed = 0
     for _ in range(args.steps):
         one_step(t_in_ep, True)
         t_in_ep += 1
         if t_in_ep == T:
-            env.profile = bool(args.profile_events)   # the reset's start-position sensing is a K3 launch of the timed region too
+            resets_timed += 1
+            env.profile = sampled()   # the reset's start-position sensing is a K3 launch of the timed region too
             reset()
             env.profile = False
             t_in_ep = 0
@@ -239,7 +248,7 @@ def main():
                "traffic_source": f"{pmc_path} (static: separate rocprofv3 --pmc passes of this command, not measured in this run)"
                if traffic is not None else None,
                "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": us, "avg_launch_us_raw": raw_us,
-               "launches": bracket["launches"], "empty_event_pair_us": event_overhead_us,
+               "bracketed_launches": bracket["launches"], "empty_event_pair_us": event_overhead_us,
                "frac_raw": bytes_per_launch / (raw_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                "stream_copy_GBps": copy_gbs, "frac_of_stream_copy": achieved / copy_gbs}
         out.update(extra or {})
@@ -249,22 +258,25 @@ def main():
     fuse = times.get("fuse")
     roofline = roofline_kernels = None
     if k3:
-        cells = counters["sense_cells"] / k3["launches"]
+        # the counters cover every launch of the timed region, the brackets a 1-in-K sample of them
+        k3_launches, fuse_launches = args.steps + resets_timed, args.steps
+        cells = counters["sense_cells"] / k3_launches
         roofline = roofline_entry("k_sense_update", "k_sense_update", "k_sense_update (K3: sense + Bayes update of the footprint tile)",
                                   K3_BYTES_PER_CELL * cells, k3,
                                   {"algorithmic_bytes_per_cell": K3_BYTES_PER_CELL, "cells_per_launch": cells,
-                                   "note": "avg_launch_us = HIP-event bracket of every K3 launch of the timed region minus the cost of an "
+                                   "note": "avg_launch_us = HIP-event brackets of the K3 launches of every K-th step of the timed region "
+                                           "(config.event_brackets_every) minus the cost of an "
                                            "empty event pair measured in the same run; frac_raw keeps the uncorrected figure"})
         roofline_kernels = [roofline]
     if fuse:
         lc, lo = counters["fuse_local_cells"], counters["fuse_local_ops"]
         gc, go = counters["fuse_global_cells"], counters["fuse_global_ops"]
-        by = (8 * (lc + gc) + (lo + go)) / fuse["launches"]
+        by = (8 * (lc + gc) + (lo + go)) / fuse_launches
         roofline_kernels.append(roofline_entry(
             "k_fuse_rows", "k_fuse_rows", "k_fuse_rows (K4 local fusion + K5 global fusion and reward terms, one launch)", by, fuse,
             {"algorithmic_bytes": "8 B per cell of the union (R+W once) + 1 B per (cell, message) code read",
-             "local_cells_per_launch": lc / fuse["launches"], "global_cells_per_launch": gc / fuse["launches"],
-             "message_cells_per_launch": (lo + go) / fuse["launches"]}))
+             "local_cells_per_launch": lc / fuse_launches, "global_cells_per_launch": gc / fuse_launches,
+             "message_cells_per_launch": (lo + go) / fuse_launches}))
 
     coma = None
     if args.train_rounds > 0:
@@ -352,7 +364,7 @@ def main():
             "config": {"workload": ("BASELINE.json configs[1]: " if is_c1 else "NOT the metric's config (a parity-test shape): ") + shape,
                        "envs_per_gpu": E, "n_agents": N, "grid": grid,
                        "episode_steps": T, "terrain": args.terrain, "parallelism": f"env-sharded x{world} (no data-path collective)",
-                       "launches_per_step": 3, "hip_graphs": bool(args.graphs)},
+                       "launches_per_step": 3, "hip_graphs": bool(args.graphs), "event_brackets_every": args.profile_events},
             "faults": faults,
             "cells": counters,
             "roofline": roofline,

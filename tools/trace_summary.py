@@ -14,3 +14,13 @@ grid = "grid_size" if "grid_size" in df.columns else [c for c in df.columns if "
 df["k"] = df[name].str.replace("void ", "").str.slice(0, 44)
 g = df.groupby(["k", grid])["us"].agg(["count", "mean", "min", "max", "sum"]).sort_values("sum", ascending=False)
 print(g[g["sum"] > (float(sys.argv[2]) if len(sys.argv) > 2 else 50)].round(1).to_string())
+
+# idle time in front of each kernel of the env step (end of the previous kernel on the device -> start of this one)
+step = df[df["k"].str.contains("k_plan_step|k_sense_|k_fuse_rows")].sort_values("start").reset_index(drop=True)
+if len(step) > 12:
+    step["gap_us"] = (step["start"] - step["end"].shift(1)) / 1e3
+    tail = step.iloc[len(step) // 2:]
+    print("\nidle time before each step kernel (second half of the run):")
+    print(tail.groupby("k")["gap_us"].agg(["count", "mean", "min", "max"]).round(1).to_string())
+    span = (tail["end"].iloc[-1] - tail["start"].iloc[0]) / 1e3
+    print("span per step kernel triple: %.1f us, kernel time %.1f us" % (span / (len(tail) / 3), tail["us"].sum() / (len(tail) / 3)))
