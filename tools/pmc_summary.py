@@ -1,60 +1,62 @@
 #!/usr/bin/env python
-"""Turns rocprofv3 output (kernel-trace --stats CSV + separate --pmc passes for FETCH_SIZE and WRITE_SIZE) of
-`bench.py --calib` into profiles/pmc_summary.json and a short text table.
+"""profiles/rNN/pmc_summary.json from rocprofv3's sqlite output of three runs of `bench.py --calib`:
+a FETCH_SIZE pass, a WRITE_SIZE pass (each `--pmc X --kernel-trace` only) and a plain `--kernel-trace` run for durations.
 
-HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE are reported in KiB-units
-of 64-B requests; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x.  Instead of assuming the factor, both
-counters are calibrated on a kernel with known traffic captured in the same run: the device-to-device clone of the
-local-map tensor (reads and writes exactly its size with 16 B/lane accesses).
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE count in KiB; on gfx950
+FETCH_SIZE under-reports wide coalesced reads by 2x.  Instead of assuming the factor, both counters are calibrated on a kernel
+with known traffic captured in the same run: k_stream_copy (ippm_stream_copy), which reads and writes exactly the local-map
+tensor with 16 B per lane.
 
-    python tools/pmc_summary.py <fetch_dir> <write_dir> <stats_dir> <n_envs> <n_agents> <grid> [out.json]
+    python tools/pmc_summary.py <fetch.db> <write.db> <trace.db> <n_envs> <n_agents> <grid> [out.json]
 """
 import json
+import sqlite3
 import sys
 
 import pandas as pd
 
 
-def per_kernel(directory, counter):
-    c = pd.read_csv(f"{directory}/p_counter_collection.csv")
-    c = c[c["Counter_Name"] == counter]
-    per_dispatch = c.groupby(["Dispatch_Id", "Kernel_Name"])["Counter_Value"].sum().reset_index()
-    g = per_dispatch.groupby("Kernel_Name")["Counter_Value"].agg(["mean", "count", "max"])
-    return g
+def counters(path, counter):
+    df = pd.read_sql("select kernel_name, dispatch_id, counter_name, value from counters_collection", sqlite3.connect(path))
+    df = df[df["counter_name"] == counter]
+    per_dispatch = df.groupby(["dispatch_id", "kernel_name"])["value"].sum().reset_index()
+    return per_dispatch.groupby("kernel_name")["value"].agg(["mean", "count", "max"])
+
+
+def durations(path):
+    df = pd.read_sql("select * from kernels", sqlite3.connect(path))
+    name = [c for c in df.columns if c in ("name", "kernel_name")][0]
+    df["us"] = (df["end"] - df["start"]) / 1e3
+    return df.rename(columns={name: "kernel"})[["kernel", "us"]]
+
+
+def pick(df, pat):
+    rows = df[df.index.str.contains(pat, regex=False)]
+    return rows.sort_values("count", ascending=False).iloc[0] if len(rows) else None
 
 
 def main():
-    fetch_dir, write_dir, stats_dir, n_envs, n_agents, grid = sys.argv[1:7]
-    out_path = sys.argv[7] if len(sys.argv) > 7 else "profiles/pmc_summary.json"
+    fetch_db, write_db, trace_db, n_envs, n_agents, grid = sys.argv[1:7]
+    out_path = sys.argv[7] if len(sys.argv) > 7 else "pmc_summary.json"
     n_envs, n_agents, grid = int(n_envs), int(n_agents), int(grid)
-    clone_bytes = n_envs * n_agents * grid * grid * 4
-    fetch = per_kernel(fetch_dir, "FETCH_SIZE")
-    write = per_kernel(write_dir, "WRITE_SIZE")
-
-    def pick(df, pat):
-        rows = df[df.index.str.contains(pat, regex=False)]
-        return rows.sort_values("count", ascending=False).iloc[0] if len(rows) else None
-
-    # calibration kernel: torch's copy of a float tensor (largest elementwise copy in the trace)
-    # (the largest copy dispatch of the run is the clone; smaller copies share the kernel name)
-    cal_f = fetch[fetch.index.str.contains("copy", case=False)].sort_values("max", ascending=False).iloc[0]
-    cal_w = write[write.index.str.contains("copy", case=False)].sort_values("max", ascending=False).iloc[0]
-    f_scale = clone_bytes / (cal_f["max"] * 1024.0)  # true bytes per reported KiB
-    w_scale = clone_bytes / (cal_w["max"] * 1024.0)
+    copy_bytes = n_envs * n_agents * grid * grid * 4   # read once and written once by k_stream_copy
+    fetch, write, trace = counters(fetch_db, "FETCH_SIZE"), counters(write_db, "WRITE_SIZE"), durations(trace_db)
+    cal_f, cal_w = pick(fetch, "k_stream_copy"), pick(write, "k_stream_copy")
+    f_scale = copy_bytes / (cal_f["mean"] * 1024.0)  # true bytes per reported KiB
+    w_scale = copy_bytes / (cal_w["mean"] * 1024.0)
     summary = {"envs_per_gpu": n_envs, "n_agents": n_agents, "grid": grid, "calibration": {
-        "kernel": "torch clone of the local maps", "bytes": clone_bytes, "FETCH_SIZE_reported_KiB": float(cal_f["max"]),
-        "WRITE_SIZE_reported_KiB": float(cal_w["max"]), "fetch_correction": f_scale, "write_correction": w_scale}}
-    trace = pd.read_csv(f"{stats_dir}/p_kernel_trace.csv")
-    trace["dur_us"] = (trace["End_Timestamp"] - trace["Start_Timestamp"]) / 1e3
-    for key, pat in (("k_sense_update", "k_sense_update"), ("k_apply_ops_local", "k_apply_ops<4, false, 6>"),
-                     ("k_apply_ops_global", "k_apply_ops<4, true, 6>")):
+        "kernel": "k_stream_copy of the local maps (ippm_stream_copy, 16 B per lane)", "bytes_each_way": copy_bytes,
+        "FETCH_SIZE_reported_KiB": float(cal_f["mean"]), "WRITE_SIZE_reported_KiB": float(cal_w["mean"]),
+        "fetch_correction": f_scale, "write_correction": w_scale}}
+    for key, pat in (("k_sense_update", "k_sense_tiles<4>"), ("k_fuse_rows", "k_fuse_rows<4, false, 6, false>"),
+                     ("k_plan_step", "k_plan_step"), ("k_stream_copy", "k_stream_copy")):
         f, w = pick(fetch, pat), pick(write, pat)
-        t = trace[trace["Kernel_Name"].str.contains(pat, regex=False)]["dur_us"]
-        if f is None or w is None:
+        t = trace[trace["kernel"].str.contains(pat, regex=False)]["us"]
+        if f is None or w is None or not len(t):
             continue
         rd = float(f["mean"]) * 1024.0 * f_scale
         wr = float(w["mean"]) * 1024.0 * w_scale
-        summary[key] = {"launches": int(f["count"]), "avg_us": float(t.mean()), "hbm_read_bytes_per_launch": rd,
+        summary[key] = {"kernel": pat, "launches": int(f["count"]), "avg_us": float(t.mean()), "hbm_read_bytes_per_launch": rd,
                         "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
                         "hbm_GBps": (rd + wr) / (float(t.mean()) * 1e-6) / 1e9}
     with open(out_path, "w") as fh:
