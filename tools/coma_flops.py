@@ -35,10 +35,12 @@ flops = {"conv_fwd": 0.0, "conv_bwd_data": 0.0, "conv_wrw": 0.0, "gemm": 0.0}
 for net, macs in (("actor", actor), ("critic", critic)):
     s_f, s_b = fwd_only[net] + fwd_bwd[net], fwd_bwd[net]
     conv = macs["conv1"] + macs["conv2"] + macs["conv3"]
-    flops["conv_fwd"] += 2.0 * s_f * conv
-    flops["conv_bwd_data"] += 2.0 * s_b * (macs["conv2"] + macs["conv3"])   # conv1's input needs no gradient
-    flops["conv_wrw"] += 2.0 * s_b * conv
-    flops["gemm"] += 2.0 * macs["fc"] * (s_f + 2 * s_b)
+    # ippmarl.networks runs conv3 (4x4 kernel on a 4x4 input = one dot product per output channel) as a plain GEMM in all
+    # three directions and conv2's input gradient as a GEMM + col2im, so those FLOPs are done by hipBLASLt kernels
+    conv_miopen = macs["conv1"] + macs["conv2"]
+    flops["conv_fwd"] += 2.0 * s_f * conv_miopen
+    flops["conv_wrw"] += 2.0 * s_b * conv_miopen
+    flops["gemm"] += 2.0 * macs["fc"] * (s_f + 2 * s_b) + 2.0 * macs["conv3"] * (s_f + 2 * s_b) + 2.0 * s_b * macs["conv2"]
 
 con = sqlite3.connect(db)
 k = pd.read_sql("select * from kernels", con)
