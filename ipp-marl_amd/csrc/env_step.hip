@@ -83,20 +83,22 @@ __global__ void k_fill_truth(const ippm_config* __restrict__ c, const int32_t* _
   }
 }
 
-// 16 bytes per lane, grid-stride (n4 = number of float4)
+// One 16-byte access per lane, one trip per workgroup, non-temporal: tools/probe/copy_probe.cpp measures 6.5 TB/s for this
+// copy on a 1 GiB buffer against 4.6-5.0 TB/s for grid-stride forms (and for hipMemcpyDtoD) and 3.6 TB/s when a workgroup
+// moves 32 KiB: on this device many short workgroups stream better than few long ones.
+typedef float ippm_f4 __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256) k_fill_f32x4(float4* __restrict__ p, float v, size_t n4) {
-  const float4 val = make_float4(v, v, v, v);
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) p[i] = val;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const ippm_f4 val = {v, v, v, v};
+  if (i < n4) __builtin_nontemporal_store(val, reinterpret_cast<ippm_f4*>(p) + i);
 }
-// plain device-to-device copy, 16 bytes per lane, 4 independent loads in flight: the streaming-rate yardstick of bench.py
+// plain device-to-device copy: the streaming-rate yardstick of bench.py
 __global__ void __launch_bounds__(256) k_stream_copy(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (; i + 3 * stride < n4; i += 4 * stride) {
-    const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n4) {
+    const ippm_f4 v = __builtin_nontemporal_load(reinterpret_cast<const ippm_f4*>(src) + i);
+    __builtin_nontemporal_store(v, reinterpret_cast<ippm_f4*>(dst) + i);
   }
-  for (; i < n4; i += stride) dst[i] = src[i];
 }
 __global__ void k_fill_f32(float* __restrict__ p, float v, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -282,6 +284,12 @@ k_sense_update(const ippm_config* __restrict__ c, const int64_t* __restrict__ ep
 typedef unsigned ippm_k3_u4 __attribute__((ext_vector_type(4)));
 #define IPPM_K3_RSRC(ptr, bytes) __builtin_amdgcn_make_buffer_rsrc((void*)(ptr), 0, (int)(bytes), 0x00020000)
 #define IPPM_K3_OOB 0x7FFFFFF0
+#ifndef IPPM_K3_LOAD_AUX   // cache policy of the map accesses (bit 1 = non-temporal on gfx950)
+#define IPPM_K3_LOAD_AUX 0
+#endif
+#ifndef IPPM_K3_STORE_AUX
+#define IPPM_K3_STORE_AUX 0
+#endif
 
 template <int VEC>
 __global__ void __launch_bounds__(256)
@@ -352,11 +360,11 @@ k_sense_tiles(const ippm_config* __restrict__ c, const int64_t* __restrict__ epi
         const int cell = x * gy + y;
         cellv[q] = cell;
         if (VEC == 4) {
-          const ippm_k3_u4 t = __builtin_amdgcn_raw_buffer_load_b128(rmap, on[q] ? cell * 4 : IPPM_K3_OOB, 0, 0);
+          const ippm_k3_u4 t = __builtin_amdgcn_raw_buffer_load_b128(rmap, on[q] ? cell * 4 : IPPM_K3_OOB, 0, IPPM_K3_LOAD_AUX);
           m[q].v[0] = __uint_as_float(t.x); m[q].v[1 % VEC] = __uint_as_float(t.y);
           m[q].v[2 % VEC] = __uint_as_float(t.z); m[q].v[3 % VEC] = __uint_as_float(t.w);
         } else {
-          m[q].v[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rmap, on[q] ? cell * 4 : IPPM_K3_OOB, 0, 0));
+          m[q].v[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rmap, on[q] ? cell * 4 : IPPM_K3_OOB, 0, IPPM_K3_LOAD_AUX));
         }
         tw[q] = __builtin_amdgcn_raw_buffer_load_b8(rtruth, on[q] ? (cell >> 3) : IPPM_K3_OOB, 0, 0);
         fw[q] = flips ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rflip, on[q] ? (int)tile_index<VEC>(row, y - tile_y0, S) : IPPM_K3_OOB, 0, 0)
@@ -364,6 +372,7 @@ k_sense_tiles(const ippm_config* __restrict__ c, const int64_t* __restrict__ epi
       }
 #pragma unroll
       for (int q = 0; q < CH; ++q) {
+        if (gbase + q * lpr >= groups) continue;   // wave-uniform: narrow footprints use one or two of the three passes
         const int gidx = gbase + gl + q * lpr;
         const int y = y0 + gidx * VEC;
         const int cell = cellv[q];
@@ -398,9 +407,9 @@ k_sense_tiles(const ippm_config* __restrict__ c, const int64_t* __restrict__ epi
           ippm_k3_u4 t;
           t.x = __float_as_uint(m[q].v[0]); t.y = __float_as_uint(m[q].v[1 % VEC]);
           t.z = __float_as_uint(m[q].v[2 % VEC]); t.w = __float_as_uint(m[q].v[3 % VEC]);
-          __builtin_amdgcn_raw_buffer_store_b128(t, rmap, off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(t, rmap, off, 0, IPPM_K3_STORE_AUX);
         } else {
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m[q].v[0]), rmap, off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m[q].v[0]), rmap, off, 0, IPPM_K3_STORE_AUX);
         }
         __builtin_amdgcn_raw_buffer_store_b8((unsigned char)obs, rcode, on[q] ? (int)tile_index<VEC>(row, y - tile_y0, S) : IPPM_K3_OOB, 0, 0);
       }
@@ -447,7 +456,7 @@ static int env_int(const char* name, int dflt) {
 static int fill_f32(float* p, float v, size_t n, hipStream_t st) {
   if (n == 0) return 0;
   if (n % 4 == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
-    hipLaunchKernelGGL(k_fill_f32x4, dim3(std::min(8192, grid1(n / 4))), dim3(256), 0, st, reinterpret_cast<float4*>(p), v, n / 4);
+    hipLaunchKernelGGL(k_fill_f32x4, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<float4*>(p), v, n / 4);
   } else {
     hipLaunchKernelGGL(k_fill_f32, dim3(std::min(4096, grid1(n))), dim3(256), 0, st, p, v, n);
   }
@@ -509,7 +518,7 @@ extern "C" int ippm_stream_copy(ippm_ctx* ctx, const void* src, void* dst, int64
   }
   if (n_bytes <= 0) return 0;
   const size_t n4 = (size_t)n_bytes / 16;
-  hipLaunchKernelGGL(k_stream_copy, dim3((unsigned)std::min<size_t>(256 * 32, (n4 + 255) / 256)), dim3(256), 0, S_(stream),
+  hipLaunchKernelGGL(k_stream_copy, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, S_(stream),
                      reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), n4);
   IPPM_LAUNCH_CHECK("stream_copy");
   return 0;

@@ -73,14 +73,20 @@ __device__ __forceinline__ double entropy_l_f64(float l, float lc) {
   return log2(d) + a * 1.4426950408889634 * (e / d);
 }
 
+#ifndef IPPM_FUSE_LOAD_AUX   // cache policy of the map accesses (bit 1 = non-temporal on gfx950)
+#define IPPM_FUSE_LOAD_AUX 0
+#endif
+#ifndef IPPM_FUSE_STORE_AUX
+#define IPPM_FUSE_STORE_AUX 0
+#endif
 template <int VEC>
 __device__ __forceinline__ CellVec<VEC> buf_load_cells(__amdgpu_buffer_rsrc_t r, int off) {
   CellVec<VEC> c;
   if (VEC == 4) {
-    const ippm_u4 t = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    const ippm_u4 t = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, IPPM_FUSE_LOAD_AUX);
     c.v[0] = __uint_as_float(t.x); c.v[1 % VEC] = __uint_as_float(t.y); c.v[2 % VEC] = __uint_as_float(t.z); c.v[3 % VEC] = __uint_as_float(t.w);
   } else {
-    c.v[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+    c.v[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, IPPM_FUSE_LOAD_AUX));
   }
   return c;
 }
@@ -89,9 +95,9 @@ __device__ __forceinline__ void buf_store_cells(__amdgpu_buffer_rsrc_t r, int of
   if (VEC == 4) {
     ippm_u4 t;
     t.x = __float_as_uint(c.v[0]); t.y = __float_as_uint(c.v[1 % VEC]); t.z = __float_as_uint(c.v[2 % VEC]); t.w = __float_as_uint(c.v[3 % VEC]);
-    __builtin_amdgcn_raw_buffer_store_b128(t, r, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(t, r, off, 0, IPPM_FUSE_STORE_AUX);
   } else {
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c.v[0]), r, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(c.v[0]), r, off, 0, IPPM_FUSE_STORE_AUX);
   }
 }
 
