@@ -388,10 +388,6 @@ k_plan_step(const ippm_config* __restrict__ c, const int64_t* __restrict__ episo
   }
 }
 
-__global__ void k_zero_i32(int32_t* __restrict__ p, int n) {
-  if ((int)threadIdx.x < n) p[threadIdx.x] = 0;
-}
-
 // ======================================================================================================
 // host API
 // ======================================================================================================

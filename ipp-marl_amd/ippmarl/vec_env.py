@@ -101,6 +101,8 @@ class VecEnv:
         self._field = None
         self._pending_t = None   # step whose fusion (K4 + K5) build_observations has already launched
         self.profile = False     # bracket the big kernels with HIP events (bench.py's roofline legs)
+        self._ep_host = None     # pinned staging buffer of reset()'s episode ids, and the event of its last copy
+        self._ep_copied = None
         self.events: Dict[str, list] = {}
 
     # ------------------------------------------------------------------------------------------------
@@ -161,7 +163,15 @@ class VecEnv:
         ep = torch.as_tensor(episodes, dtype=torch.int64).reshape(self.E)
         if int(ep.max()) * d.env_seed * max(d.n_agents - 1, 1) >= 2 ** 32 or int(ep.min()) < 0:
             raise ValueError("episode * seed * agent_id must stay below 2**32 (NumPy legacy seeding limit)")
-        self.episode.copy_(ep.to(self.device))
+        # episode ids go through a pinned staging buffer: a pageable host-to-device copy stalls the stream for ~40 us per reset
+        if self._ep_host is None:
+            self._ep_host = torch.empty(self.E, dtype=torch.int64).pin_memory()
+        if self._ep_copied is not None:
+            self._ep_copied.synchronize()      # the previous reset's copy has read the buffer
+        self._ep_host.copy_(ep)
+        self.episode.copy_(self._ep_host, non_blocking=True)
+        self._ep_copied = torch.cuda.Event()
+        self._ep_copied.record()
         self.ctx.call("ippm_reset_episode", self._p(self.episode), self._p(self.pos),
                       self._p(self.truth) if truth is None and terrain == "split" else None, self._p(self.local),
                       self._p(self.glob),
