@@ -33,6 +33,15 @@ def test_actor_and_critic_step_match_reference(golden):
     np.testing.assert_allclose(float(aloss), float(fx["actor_loss"]), rtol=2e-4, atol=1e-7)
     np.testing.assert_allclose(float(adv.mean()), float(fx["adv_mean"]), rtol=2e-4, atol=1e-6)
     np.testing.assert_allclose(float(adv.std()), float(fx["adv_std"]), rtol=2e-4)
+    # K7 on the reference's own tensors of this step (its pre-update policy pi0 and post-critic-step Q): here no network
+    # runs on the device, so the kernel itself is held to the 1e-5 of the contract -- per sample against the oracle's
+    # restatement of actor/learner.py:55-83, and in the two moments the reference recorded
+    adv_k7 = al.advantage(t(fx["pi0"]), t(fx["q_new"]), t(masks, torch.float32), t(actions))
+    adv_ref, _, _ = O.coma_advantage(fx["pi0"], fx["q_new"], masks.astype(np.float32), actions)
+    np.testing.assert_allclose(adv_k7.cpu().numpy(), adv_ref, rtol=1e-5, atol=1e-7)
+    # (the mean is a sum of cancelling terms, 26x smaller than the spread: 1e-5 of the advantages' scale)
+    np.testing.assert_allclose(float(adv_k7.double().mean()), float(fx["adv_mean"]), rtol=0, atol=1e-5 * float(fx["adv_std"]))
+    np.testing.assert_allclose(float(adv_k7.double().std()), float(fx["adv_std"]), rtol=1e-5)
     with torch.no_grad():
         pi1, _ = actor(t(obs, torch.float32), float(fx["eps"]))
     np.testing.assert_allclose(pi1.cpu().numpy(), fx["pi1"], rtol=1e-4, atol=1e-6)
