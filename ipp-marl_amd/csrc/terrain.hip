@@ -67,9 +67,10 @@ __device__ __forceinline__ float2 terrain_bin(uint64_t ep, uint32_t k0, uint32_t
   Philox4 ph = ippm_philox(bin, (uint32_t)ep, ippm_stream_word(0u, 1u, IPPM_DOMAIN_TERRAIN), (uint32_t)(ep >> 32), k0, k1);
   const float u1 = ((float)(ph.v[0] >> 8) + 1.0f) * (1.0f / 16777216.0f);
   const float u2 = (float)(ph.v[1] >> 8) * (1.0f / 16777216.0f);
-  const float r = sqrtf(-2.0f * logf(u1));
-  float sn, cs;
-  sincospif(2.0f * u2, &sn, &cs);
+  // hardware transcendentals (v_log_f32, v_sin_f32 / v_cos_f32 take revolutions): a few ulp off the libm forms, which a
+  // noise generator does not care about -- what is checked is the transform of whatever spectrum is drawn
+  const float r = __builtin_sqrtf(-1.3862943611f * __builtin_amdgcn_logf(u1));   // -2 ln u = -2 ln2 log2 u
+  const float sn = __builtin_amdgcn_sinf(u2), cs = __builtin_amdgcn_cosf(u2);
   if (self) return make_float2(amp * 1.41421356237f * r * cs, 0.0f);
   return make_float2(amp * r * cs, conj ? -amp * r * sn : amp * r * sn);
 }
@@ -329,6 +330,28 @@ __global__ __launch_bounds__(256) void k_terrain_pack_keys(const float* __restri
   }
 }
 
+// the same for fields whose cell count is a multiple of 4: one 16-byte non-temporal load per lane, one trip per workgroup
+// (the shape that streams best on this device, tools/probe/copy_probe.cpp); 8 lanes assemble one 32-bit word of truth bits
+typedef float terrain_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_terrain_pack_keys4(const float* __restrict__ field, const uint32_t* __restrict__ range_keys,
+                                                            uint8_t* __restrict__ truth, size_t cells, size_t truth_bytes) {
+  const int e = blockIdx.y;
+  const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;   // 4-cell group of this env
+  const float lo = key_value(range_keys[2 * e]), span = key_value(range_keys[2 * e + 1]) - lo;
+  uint32_t nib = 0;
+  if (4 * g < cells) {
+    const terrain_f4 v = __builtin_nontemporal_load(reinterpret_cast<const terrain_f4*>(field + (size_t)e * cells) + g);
+    nib = ((v.x - lo) / span >= 0.5f ? 1u : 0u) | ((v.y - lo) / span >= 0.5f ? 2u : 0u) | ((v.z - lo) / span >= 0.5f ? 4u : 0u) |
+          ((v.w - lo) / span >= 0.5f ? 8u : 0u);
+  }
+  uint32_t w = nib << (4 * (threadIdx.x & 7));
+  w |= __shfl_xor(w, 1, 64);
+  w |= __shfl_xor(w, 2, 64);
+  w |= __shfl_xor(w, 4, 64);
+  const size_t word = g >> 3;
+  if ((threadIdx.x & 7) == 0 && word < (truth_bytes >> 2)) reinterpret_cast<uint32_t*>(truth + (size_t)e * truth_bytes)[word] = w;
+}
+
 extern "C" int ippm_terrain_noise(ippm_ctx* ctx, const int64_t* episode, float* noise, int32_t n_envs, void* stream) {
   if (!ctx || !episode || !noise) { ippm_set_error("ippm_terrain_noise: null argument"); return -1; }
   if (n_envs <= 0) return 0;
@@ -344,6 +367,12 @@ extern "C" int ippm_terrain_pack(ippm_ctx* ctx, const float* field, const uint32
   if (!ctx || !field || !truth) { ippm_set_error("ippm_terrain_pack: null argument"); return -1; }
   if (n_envs <= 0) return 0;
   const size_t cells = (size_t)ctx->cfg.grid_x * ctx->cfg.grid_y;
+  if (range_keys && cells % 4 == 0 && (reinterpret_cast<uintptr_t>(field) & 15) == 0) {
+    hipLaunchKernelGGL(k_terrain_pack_keys4, dim3((unsigned)((cells / 4 + 255) / 256), n_envs), dim3(256), 0, S_(stream), field,
+                       range_keys, truth, cells, ippm_truth_bytes(ctx->cfg.grid_x, ctx->cfg.grid_y));
+    IPPM_LAUNCH_CHECK("terrain_pack_keys4");
+    return 0;
+  }
   if (range_keys) {
     const int gxb = (int)std::min<size_t>(64, ((cells + 63) / 64 + 15) / 16);
     hipLaunchKernelGGL(k_terrain_pack_keys, dim3(gxb > 0 ? gxb : 1, n_envs), dim3(256), 0, S_(stream), field, range_keys, truth, cells,

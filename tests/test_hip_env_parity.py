@@ -221,8 +221,9 @@ def test_random_field_terrain_native_path(name):
     w = _ffi.host_philox(kx * hy + ky, int(eps[1]) & 0xFFFFFFFF, (1 << 8) | (3 << 24), int(eps[1]) >> 32, 3, 0)
     u1, u2 = ((w[0] >> 8) + 1.0) / 2 ** 24, (w[1] >> 8) / 2 ** 24
     r = np.sqrt(-2.0 * np.log(u1)) * amp[kx, ky]
+    # (the device uses the hardware log2 / sin / cos: a few float32 ulp of the radius off the libm values)
     np.testing.assert_allclose([S[1, kx, ky].real, S[1, kx, ky].imag], [r * np.cos(2 * np.pi * u2), r * np.sin(2 * np.pi * u2)],
-                               rtol=1e-4, atol=1e-7)
+                               rtol=1e-4, atol=3e-6 * r)
     # Hermitian structure of the self-mirrored columns; white-noise statistics of the generic bins
     for col in (0, gy // 2):
         assert np.array_equal(S[:, 1:gx // 2, col], np.conj(S[:, :gx // 2:-1, col]))
