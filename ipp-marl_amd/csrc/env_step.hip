@@ -297,19 +297,14 @@ k_sense_tiles(const ippm_config* __restrict__ c, const int64_t* __restrict__ epi
               const uint8_t* __restrict__ truth, float* __restrict__ local, const uint8_t* __restrict__ flips,
               uint8_t* __restrict__ code, const int32_t* __restrict__ rect_in, int32_t* __restrict__ rect_out,
               int32_t* __restrict__ ws, double* __restrict__ sums, float* __restrict__ reward,
-              unsigned long long* __restrict__ counters, int stage, int agent_sel, int parts, int rows_per_part, int n_tiles,
-              int n_envs) {
+              unsigned long long* __restrict__ counters, int stage, int agent_sel, int rows_per_part) {
   constexpr int CH = 3;
-  if ((int)blockIdx.x >= n_tiles * parts) {  // reward-finalize tail
-    const int e = ((int)blockIdx.x - n_tiles * parts) * 256 + (int)threadIdx.x;
-    if (e < n_envs) ippm_reward_finalize_env(c, sums, reward, e);
-    return;
-  }
+  // grid = (row parts, agents, envs): no index arithmetic to undo
   const int n = c->n_agents;
-  const int tile = blockIdx.x / parts, part = blockIdx.x % parts;
-  int e, i;
-  if (agent_sel >= 0) { e = tile; i = agent_sel; }
-  else { e = tile / n; i = tile % n; }
+  const int part = blockIdx.x, e = blockIdx.z, i = agent_sel >= 0 ? agent_sel : (int)blockIdx.y;
+  const int tile = e * (int)gridDim.y + (int)blockIdx.y;
+  // the reward of the step whose global fusion ran in the launch before this one: any one thread per env can complete it
+  if (sums && part == 0 && blockIdx.y == 0 && threadIdx.x == 0) ippm_reward_finalize_env(c, sums, reward, e);
   const int gx = c->grid_x, gy = c->grid_y, S = c->tile_stride;
   const int32_t* p = pos + (size_t)(e * n + i) * 3;
   int r[4];
@@ -324,7 +319,8 @@ k_sense_tiles(const ippm_config* __restrict__ c, const int64_t* __restrict__ epi
   const int h = xr - xl, w = yd - yu;
   const int r0 = part * rows_per_part, r1 = min(h, r0 + rows_per_part);
   if (w <= 0 || r0 >= r1) return;
-  const int k = ippm_alt_index(c, p[2]);
+  // altitude index = (z - z_min) / spacing through one reciprocal (exact: (n + 1/2) / d is never within 1e-6 of an integer)
+  const int k = min(max((int)(((float)(p[2] - c->min_altitude) + 0.5f) * __builtin_amdgcn_rcpf((float)c->spacing)), 0), c->space_z - 1);
   const float lp = c->logit_prior;
   const float lm0 = c->logit_meas[k][0] - lp, lm1 = c->logit_meas[k][1] - lp;
   const uint32_t thr = c->flip_threshold[k];
@@ -553,14 +549,15 @@ extern "C" int ippm_sense_step(ippm_ctx* ctx, const int64_t* episode, const int3
     for (int k = 0; k < c.space_z; ++k) h_max = std::max(h_max, 2 * c.radius_x[k]);
     const int rows_per_part = std::max(4, env_int("IPPM_K3_ROWS", 32));
     const int parts = (h_max + rows_per_part - 1) / rows_per_part;
-    dim3 grid((unsigned)maps * parts + tail);
+    if (n_envs > 65535) { ippm_set_error("ippm_sense_step: more than 65535 envs per launch"); return -1; }
+    dim3 grid((unsigned)parts, (unsigned)(agent_sel >= 0 ? 1 : c.n_agents), (unsigned)n_envs);
     int32_t* rect_out = rect_in == rect ? nullptr : rect;
     if (ctx->vec == 4)
       hipLaunchKernelGGL((k_sense_tiles<4>), grid, block, 0, S_(stream), ctx->dcfg, episode, pos, truth, local, flips, code, rect_in,
-                         rect_out, ws, sums, reward, ctx->dcounters, stage, agent_sel, parts, rows_per_part, maps, n_envs);
+                         rect_out, ws, sums, reward, ctx->dcounters, stage, agent_sel, rows_per_part);
     else
       hipLaunchKernelGGL((k_sense_tiles<1>), grid, block, 0, S_(stream), ctx->dcfg, episode, pos, truth, local, flips, code, rect_in,
-                         rect_out, ws, sums, reward, ctx->dcounters, stage, agent_sel, parts, rows_per_part, maps, n_envs);
+                         rect_out, ws, sums, reward, ctx->dcounters, stage, agent_sel, rows_per_part);
     IPPM_LAUNCH_CHECK("sense_tiles");
     return 0;
   }
