@@ -287,6 +287,14 @@ int ippm_coma_advantage(ippm_ctx* ctx, const float* probs, const float* q, const
 int ippm_col2im_nhwc(const float* cols, float* grad_x, int32_t batch, int32_t out_h, int32_t out_w, int32_t kernel,
                      int32_t channels, void* stream);
 
+/* activation(conv(x)) of the learners' convnets (actor/network.py:72-80, critic/network.py:33-41) with the convolution run
+ * bias-free by the library: y = max(x + bias, 0) IN PLACE on channels-last rows x float [rows, channels]; and its backward
+ * pass grad_x = grad_y * (y > 0), grad_bias[c] += sum over rows of grad_x[., c] (grad_bias must be zeroed by the caller).
+ * channels % 4 == 0 and channels / 4 divides 256; 16-byte aligned buffers.  No context needed. */
+int ippm_bias_relu_nhwc(float* x, const float* bias, int64_t rows, int32_t channels, void* stream);
+int ippm_bias_relu_backward_nhwc(const float* grad_y, const float* y, float* grad_x, float* grad_bias, int64_t rows,
+                                 int32_t channels, void* stream);
+
 /* ---- K8: BatchMemory.build_td_targets (batch_memory.py:120-162) over `chains` independent transition
  * lists of length `len` (row-major [chains,len]): reward float, done uint8, q_sel float = target critic
  * Q(s_t)[a_t] -> td_target, discounted_return float. */

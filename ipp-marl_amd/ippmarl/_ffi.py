@@ -82,6 +82,8 @@ PROTOTYPES = {
     "ippm_coma_advantage": [P, P, P, P, P, P, P, I32, P],
     "ippm_td_lambda": [P, P, P, P, P, P, I32, I32, P],
     "ippm_col2im_nhwc": [P, P, I32, I32, I32, I32, I32, P],
+    "ippm_bias_relu_nhwc": [P, P, I64, I32, P],
+    "ippm_bias_relu_backward_nhwc": [P, P, P, P, I64, I32, P],
     "ippm_ig_candidates": [P, P, P, P, P, I32, P],
     "ippm_ig_select": [P, P, P, P, I32, P, P, I32, P],
     "ippm_f1_counts": [P, P, P, I32, C.c_float, P, I32, P],

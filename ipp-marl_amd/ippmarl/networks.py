@@ -23,6 +23,8 @@ for _v in ("FWD", "BWD", "WRW"):
 
 # conv3 as a GEMM (see _ConvTrunk.trunk); IPPMARL_CONV3_GEMM=0 keeps the convolution call
 CONV3_AS_GEMM = os.environ.get("IPPMARL_CONV3_GEMM", "1") != "0"
+# bias + ReLU after conv1 / conv2 as one pass (see _BiasReLU); IPPMARL_FUSED_BIAS_RELU=0 keeps PyTorch's separate passes
+FUSED_BIAS_RELU = os.environ.get("IPPMARL_FUSED_BIAS_RELU", "1") != "0"
 # conv2's input gradient as GEMM + col2im (see _ConvDataGradAsGemm); IPPMARL_CONV2_BWD_GEMM=0 keeps the library's kernel
 CONV2_BWD_DATA_AS_GEMM = os.environ.get("IPPMARL_CONV2_BWD_GEMM", "1") != "0"
 
@@ -55,7 +57,10 @@ class _ConvDataGradAsGemm(torch.autograd.Function):
         grad_x = grad_w = grad_b = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             _, grad_w, grad_b = torch.ops.aten.convolution_backward(
-                grad_out, x, weight, [weight.shape[0]], [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, True])
+                grad_out, x, weight, [weight.shape[0]], [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                [False, True, bool(ctx.needs_input_grad[2])])
+            if not ctx.needs_input_grad[2]:
+                grad_b = None
         if ctx.needs_input_grad[0]:
             B, O, Ho, Wo = grad_out.shape
             C, K = weight.shape[1], weight.shape[2]
@@ -75,6 +80,46 @@ class _ConvDataGradAsGemm(torch.autograd.Function):
         return grad_x, grad_w, grad_b
 
 
+class _BiasReLU(torch.autograd.Function):
+    """relu(x + bias) for a channels-last activation tensor as ONE pass in each direction (libippmarl's ippm_bias_relu_nhwc
+    / ippm_bias_relu_backward_nhwc) instead of the bias pass + ReLU pass (and threshold pass + column reduction) PyTorch runs
+    around a MIOpen convolution.  ``x`` is the bias-free convolution output and is overwritten."""
+
+    @staticmethod
+    def usable(x: torch.Tensor, bias) -> bool:
+        c = x.shape[1]
+        return (FUSED_BIAS_RELU and bias is not None and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and c % 4 == 0
+                and 256 % (c // 4) == 0 and x.is_contiguous(memory_format=torch.channels_last))
+
+    @staticmethod
+    def _lib():
+        from . import _ffi
+        return _ffi, _ffi.load_library()
+
+    @staticmethod
+    def forward(ctx, x, bias):
+        ffi, lib = _BiasReLU._lib()
+        b = bias.detach().contiguous()
+        # (channels-last storage: dense [rows, C]; `usable` has checked that)
+        ffi.check(lib.ippm_bias_relu_nhwc(x.data_ptr(), ffi.ptr(b), x.numel() // x.shape[1], x.shape[1],
+                                          torch.cuda.current_stream(x.device).cuda_stream), "ippm_bias_relu_nhwc")
+        ctx.mark_dirty(x)
+        ctx.save_for_backward(x)
+        return x
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        (y,) = ctx.saved_tensors
+        ffi, lib = _BiasReLU._lib()
+        g = grad_y.contiguous(memory_format=torch.channels_last)
+        grad_x = torch.empty_like(y)                      # channels-last like y
+        grad_b = torch.zeros(y.shape[1], dtype=y.dtype, device=y.device)
+        ffi.check(lib.ippm_bias_relu_backward_nhwc(g.data_ptr(), y.data_ptr(), grad_x.data_ptr(), ffi.ptr(grad_b),
+                                                   y.numel() // y.shape[1], y.shape[1],
+                                                   torch.cuda.current_stream(y.device).cuda_stream), "ippm_bias_relu_backward_nhwc")
+        return grad_x, grad_b
+
+
 class _ConvTrunk(nn.Module):
     def __init__(self, in_planes: int, n_actions: int):
         super().__init__()
@@ -87,15 +132,22 @@ class _ConvTrunk(nn.Module):
         self.fc2 = nn.Linear(256, 256)  # never used in forward (reference: commented out) -> never gets a gradient
         self.fc3 = nn.Linear(256, n_actions)
 
+    def _conv_relu(self, conv: nn.Conv2d, x: torch.Tensor, data_grad_as_gemm: bool):
+        """activation(conv(x)); on the device the convolution runs bias-free and bias + ReLU are one in-place pass."""
+        conv2d = _ConvDataGradAsGemm.apply if data_grad_as_gemm else torch.nn.functional.conv2d
+        if x.is_cuda and FUSED_BIAS_RELU:
+            out = conv2d(x, conv.weight, None)
+            if _BiasReLU.usable(out, conv.bias):
+                return _BiasReLU.apply(out, conv.bias)
+            return self.activation(out + conv.bias.view(1, -1, 1, 1))
+        return self.activation(conv2d(x, conv.weight, conv.bias))
+
     def trunk(self, x: torch.Tensor):
         if x.dim() == 3:
             x = x.unsqueeze(0)
         x = x.permute(0, 3, 1, 2)  # NHWC storage -> logical NCHW (channels_last strides, no copy)
-        h = self.activation(self.conv1(x))
-        if CONV2_BWD_DATA_AS_GEMM and h.requires_grad:
-            h = self.activation(_ConvDataGradAsGemm.apply(h, self.conv2.weight, self.conv2.bias))
-        else:
-            h = self.activation(self.conv2(h))
+        h = self._conv_relu(self.conv1, x, False)
+        h = self._conv_relu(self.conv2, h, CONV2_BWD_DATA_AS_GEMM and h.requires_grad)
         if CONV3_AS_GEMM and h.shape[-2:] == self.conv3.kernel_size:
             # conv3 sees a 4x4 map with a 4x4 kernel: ONE output position, i.e. a plain [B, 4096] x [4096, 256] product.
             # As a GEMM it goes to hipBLASLt instead of an implicit-GEMM convolution with a degenerate output tile.

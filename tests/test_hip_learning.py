@@ -319,3 +319,56 @@ def test_conv2_input_gradient_through_gemm_and_col2im_kernel():
         for kx in range(K):
             want[:, ky:ky + Ho, kx:kx + Wo] += cv[:, :, :, ky, kx]
     torch.testing.assert_close(out, want, rtol=1e-6, atol=1e-6)
+
+
+def test_fused_bias_relu_equals_separate_passes():
+    """networks._BiasReLU (one in-place pass forward, one pass backward incl. the bias gradient) against PyTorch's
+    conv-with-bias + ReLU: the kernels alone on ragged row counts, then both convnets end to end with the fusion on / off."""
+    from ippmarl import _ffi
+    from ippmarl import networks as N
+    lib = _ffi.load_library()
+    stream = torch.cuda.current_stream().cuda_stream
+    torch.manual_seed(7)
+    for rows, C in ((1, 256), (513, 256), (4096 * 49 + 3, 256), (1000, 64), (77, 8)):
+        x = torch.randn(rows, C, device="cuda")
+        b = torch.randn(C, device="cuda")
+        want = torch.relu(x + b)
+        y = x.clone()
+        _ffi.check(lib.ippm_bias_relu_nhwc(_ffi.ptr(y), _ffi.ptr(b), rows, C, stream), "ippm_bias_relu_nhwc")
+        assert torch.equal(y, want), (rows, C)
+        gy = torch.randn(rows, C, device="cuda")
+        gx = torch.empty_like(gy)
+        gb = torch.zeros(C, device="cuda")
+        _ffi.check(lib.ippm_bias_relu_backward_nhwc(_ffi.ptr(gy), _ffi.ptr(y), _ffi.ptr(gx), _ffi.ptr(gb), rows, C, stream),
+                   "ippm_bias_relu_backward_nhwc")
+        want_gx = gy * (want > 0)
+        assert torch.equal(gx, want_gx), (rows, C)
+        # float32 sums in a different order: 1e-5 of the column's absolute mass
+        torch.testing.assert_close(gb, want_gx.sum(0), rtol=0, atol=1e-5 * float(want_gx.abs().sum(0).max()) + 1e-6)
+    with pytest.raises(_ffi.IppmError):
+        _ffi.check(lib.ippm_bias_relu_nhwc(_ffi.ptr(y), _ffi.ptr(b), 4, 6, stream), "ippm_bias_relu_nhwc")   # 6 channels
+
+    params = make_params("c2")
+    for cls, planes in ((N.ActorNetwork, 7), (N.CriticNetwork, 12)):
+        net = cls(params).cuda()
+        x = torch.rand(160, 11, 11, planes, device="cuda")
+
+        def run(flag):
+            old, N.FUSED_BIAS_RELU = N.FUSED_BIAS_RELU, flag
+            try:
+                net.zero_grad()
+                out = net(x, 0.1)[0] if cls is N.ActorNetwork else net(x)[0]
+                (out * out).sum().backward()
+                with torch.no_grad():
+                    out_ng = net(x, 0.1)[0] if cls is N.ActorNetwork else net(x)[0]
+                return out.detach().clone(), out_ng.clone(), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+            finally:
+                N.FUSED_BIAS_RELU = old
+
+        o0, n0, g0 = run(False)
+        o1, n1, g1 = run(True)
+        torch.testing.assert_close(o1, o0, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(n1, n0, rtol=1e-5, atol=1e-6)
+        assert set(g0) == set(g1)
+        for n in g0:
+            torch.testing.assert_close(g1[n], g0[n], rtol=2e-4, atol=2e-5 * float(g0[n].abs().max()), msg=n)
