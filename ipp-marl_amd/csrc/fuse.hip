@@ -514,8 +514,9 @@ static int launch_fuse(ippm_ctx* ctx, float* local, float* global, const uint8_t
   const int max_ops = c.n_agents + 1;  // local: 2 clamp-only ops + N-1 messages; global: 1 clamp-only op + N messages
   const int wave_rows = ippm_fuse_wave_rows(ctx, n_envs_total);
   const int chunks = (c.grid_x + wave_rows - 1) / wave_rows;
-  // resident wavefronts of the persistent form: CUs x SIMDs x waves per SIMD the kernel's registers allow
-  const int persist = std::max(64, env_int("IPPM_FUSE_PERSIST", 12288));
+  // wavefronts of the persistent form: four rounds of the chip's 4096 slots (256 CUs x 4 SIMDs x 4 waves at 128 VGPRs); measured
+  // 8192 / 12288 / 16384 / 24576 -> 122.6 / 118 / 113.5 / 116 us at config 2
+  const int persist = std::max(64, env_int("IPPM_FUSE_PERSIST", 16384));
   const int pgrid = n_envs_total * std::max(1, std::min(persist / std::max(n_envs_total, 1), (c.n_agents + 1) * chunks));
   dim3 grid(work ? (unsigned)pgrid : (unsigned)units * chunks), block(64);
 #define IPPM_FUSE(V, T, NA, SH, MINOPS)                                                                                  \
