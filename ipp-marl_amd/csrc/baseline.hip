@@ -20,6 +20,35 @@ __device__ __forceinline__ void ig_action_offset(int A, int a, int s, int& dx, i
   }
 }
 
+// Expected weighted entropy reduction of one cell with (clipped) belief log-odds l under a measurement of log-odds +-ln
+// (IG_baseline.py:236-268):  p (H(l) - H(l + ln)) w(l + ln) + (1 - p) (H(l) - H(l - ln)) w(l - ln),  w = the posterior itself
+// inside the weight band, 1 / 0 beyond it.  All three entropies and posteriors hang off ONE exponential: with e = exp(-|l|),
+// exp(-|l + s|) = exp(-l) exp(-s) or exp(l) exp(s), and exp(+-l) is e or 1/e; kp / km = exp(+-ln), ec = exp(-clip).
+// 8 transcendentals per cell instead of 15.
+__device__ __forceinline__ float ig_entropy_from_e(float a, float e, float& rd) {  // H of |L| = a, e = exp(-a); rd = 1/(1+e)
+  const float d = 1.0f + e;
+  rd = __builtin_amdgcn_rcpf(d);
+  return __log2f(d) + (a * 1.44269504f) * (e * rd);
+}
+__device__ __forceinline__ float ig_cell(float l, float ln, float kp, float km, float ec, float lc, float wt) {
+  const float a = fabsf(l), e = __expf(-a), re = __builtin_amdgcn_rcpf(e);
+  const bool pos = l >= 0.f;
+  const float en = pos ? e : re, ep = pos ? re : e;   // exp(-l), exp(l)
+  float rd;
+  const float hh = ig_entropy_from_e(a, e, rd);
+  const float pb = pos ? rd : e * rd;                  // sigmoid(l)
+  const float l1 = l + ln, l0 = l - ln;
+  // exp(-|l +- ln|), floored at exp(-clip) like the entropy's clipped argument
+  const float e1 = fmaxf(l1 >= 0.f ? en * km : ep * kp, ec), e0 = fmaxf(l0 >= 0.f ? en * kp : ep * km, ec);
+  float rd1, rd0;
+  const float h1 = ig_entropy_from_e(fminf(fabsf(l1), lc), e1, rd1), h0 = ig_entropy_from_e(fminf(fabsf(l0), lc), e0, rd0);
+  // inside the weight band |l +- ln| < clip, so e1 / e0 are the unfloored exponentials there
+  const float s1 = l1 >= 0.f ? rd1 : e1 * rd1, s0 = l0 >= 0.f ? rd0 : e0 * rd0;
+  const float cw1 = l1 > wt ? 1.f : (l1 < -wt ? 0.f : s1);
+  const float cw0 = l0 > wt ? 1.f : (l0 < -wt ? 0.f : s0);
+  return pb * (hh - h1) * cw1 + (1.f - pb) * (hh - h0) * cw0;
+}
+
 // K9: one workgroup per (env, agent, action)
 __global__ void __launch_bounds__(256)
 k_ig_candidates(const ippm_config* __restrict__ c, const float* __restrict__ local, const int32_t* __restrict__ pos,
@@ -37,6 +66,7 @@ k_ig_candidates(const ippm_config* __restrict__ c, const float* __restrict__ loc
   const int gx = c->grid_x, gy = c->grid_y;
   const int k = ippm_alt_index(c, p[2] + dz);
   const float ln = c->logit_noise[k];  // ln((1-noise)/noise) from the float64 noise level: update_cells(section, 1-noise)
+  const float kp = __expf(ln), km = __expf(-ln), ec = __expf(-c->logit_clip);
   const float lc = c->logit_clip, wt = c->logit_weight_thr;
   const float* map = local + (size_t)(e * n + i) * gx * gy;
   const bool vec = (gy & 3) == 0;
@@ -55,13 +85,7 @@ k_ig_candidates(const ippm_config* __restrict__ c, const float* __restrict__ loc
     for (int q = 0; q < step; ++q) {
       if (y + q < yu || y + q >= yd) continue;
       // IG_baseline.py:236-268 in log-odds: belief clipped once, hypothetical posteriors L +- ln
-      const float l = ippm_clampl(v[q], lc);
-      const float pb = ippm_sigmoid(l);
-      const float l1 = l + ln, l0 = l - ln;
-      const float hh = ippm_entropy_l(l, lc);
-      const float cw1 = l1 > wt ? 1.f : (l1 < -wt ? 0.f : ippm_sigmoid(l1));
-      const float cw0 = l0 > wt ? 1.f : (l0 < -wt ? 0.f : ippm_sigmoid(l0));
-      part += pb * (hh - ippm_entropy_l(l1, lc)) * cw1 + (1.f - pb) * (hh - ippm_entropy_l(l0, lc)) * cw0;
+      part += ig_cell(ippm_clampl(v[q], lc), ln, kp, km, ec, lc, wt);
     }
     acc += (double)part;
   }
@@ -76,50 +100,60 @@ k_ig_candidates(const ippm_config* __restrict__ c, const float* __restrict__ loc
   if (threadIdx.x == 0) gains[cand] = (float)(s[0] / 1000.0);
 }
 
-// K10: get_relative_ig + get_cell_utilities + select_action, literal and sequential, one thread per env
-__global__ void k_ig_select(const ippm_config* __restrict__ c, const int32_t* __restrict__ pos, const uint8_t* __restrict__ mask,
-                            const float* __restrict__ gains, int communication, int32_t* __restrict__ action,
-                            float* __restrict__ utilities, int n_envs) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_envs) return;
+// K10: get_relative_ig + get_cell_utilities + select_action (IG_baseline.py:270-325), one wavefront per env.
+// The reference walks the agents in order and discounts candidate (i, a1) IN PLACE by every other agent's candidate that lands
+// on the same lattice point: rel[i,a1] = g1 * (1 - rel[j,a2]), last match wins, where rel[j,a2] is already discounted for
+// j < i and still raw for j > i.  A row i never reads its own entries, so its candidates are independent: the agent loop
+// stays serial, lane a1 does the (j, a2) scan of its candidate against the table in LDS.
+__global__ void __launch_bounds__(64)
+k_ig_select(const ippm_config* __restrict__ c, const int32_t* __restrict__ pos, const uint8_t* __restrict__ mask,
+            const float* __restrict__ gains, int communication, int32_t* __restrict__ action,
+            float* __restrict__ utilities, int n_envs) {
+  const int e = blockIdx.x, lane = threadIdx.x;
   const int n = c->n_agents, A = c->n_actions;
-  float rel[IPPM_MAX_AGENTS * IPPM_MAX_ACTIONS];
-  for (int i = 0; i < n; ++i) {
+  __shared__ float rel[IPPM_MAX_AGENTS * IPPM_MAX_ACTIONS];
+  __shared__ int cpos[IPPM_MAX_AGENTS * IPPM_MAX_ACTIONS][3];   // lattice point of every candidate
+  __shared__ uint8_t cmask[IPPM_MAX_AGENTS * IPPM_MAX_ACTIONS];
+  for (int q = lane; q < n * A; q += 64) {
+    const int i = q / A, a = q - i * A;
+    // relative gain: the row sum in the reference's order (a = 0, 1, ...)
     float total = 0.f;
-    for (int a = 0; a < A; ++a) total += gains[(size_t)(e * n + i) * A + a];
-    for (int a = 0; a < A; ++a) rel[i * A + a] = gains[(size_t)(e * n + i) * A + a] / total;
+    for (int b = 0; b < A; ++b) total += gains[(size_t)(e * n + i) * A + b];
+    rel[q] = gains[(size_t)(e * n + i) * A + a] / total;
+    int dx, dy, dz;
+    ig_action_offset(A, a, c->spacing, dx, dy, dz);
+    const int32_t* p = pos + (size_t)(e * n + i) * 3;
+    cpos[q][0] = p[0] + dx; cpos[q][1] = p[1] + dy; cpos[q][2] = p[2] + dz;
+    cmask[q] = mask[(size_t)(e * n + i) * A + a];
   }
+  __syncthreads();
   if (communication) {
-    for (int i = 0; i < n; ++i)
-      for (int a1 = 0; a1 < A; ++a1) {
-        if (!mask[(size_t)(e * n + i) * A + a1]) continue;  // masked candidates carry the placeholder position 0
-        const float g1 = rel[i * A + a1];
-        int d1x, d1y, d1z;
-        ig_action_offset(A, a1, c->spacing, d1x, d1y, d1z);
-        const int32_t* pi = pos + (size_t)(e * n + i) * 3;
-        for (int j = 0; j < n; ++j) {
-          if (j == i) continue;
-          const int32_t* pj = pos + (size_t)(e * n + j) * 3;
-          for (int a2 = 0; a2 < A; ++a2) {
-            if (!mask[(size_t)(e * n + j) * A + a2]) continue;
-            int d2x, d2y, d2z;
-            ig_action_offset(A, a2, c->spacing, d2x, d2y, d2z);
-            if (pi[0] + d1x == pj[0] + d2x && pi[1] + d1y == pj[1] + d2y && pi[2] + d1z == pj[2] + d2z)
-              rel[i * A + a1] = g1 * (1.f - rel[j * A + a2]);
-          }
+    for (int i = 0; i < n; ++i) {
+      for (int a1 = lane; a1 < A; a1 += 64) {   // (A <= 27: one trip)
+        const int q1 = i * A + a1;
+        if (!cmask[q1]) continue;   // masked candidates carry the placeholder position 0
+        const float g1 = rel[q1];
+        float v = g1;
+        for (int q2 = 0; q2 < n * A; ++q2) {
+          if (q2 / A == i || !cmask[q2]) continue;
+          if (cpos[q1][0] == cpos[q2][0] && cpos[q1][1] == cpos[q2][1] && cpos[q1][2] == cpos[q2][2]) v = g1 * (1.f - rel[q2]);
         }
+        rel[q1] = v;   // row i is read by nobody during this pass
       }
+      __syncthreads();
+    }
   }
-  for (int i = 0; i < n; ++i) {
+  if (lane < n) {
     int best = 0;
-    float bv = rel[i * A];
+    float bv = rel[lane * A];
     for (int a = 1; a < A; ++a) {
-      const float v = rel[i * A + a];
+      const float v = rel[lane * A + a];
       if (v > bv) { bv = v; best = a; }   // np.argmax: first maximum (NaN never wins here)
     }
-    action[e * n + i] = best;
-    if (utilities) for (int a = 0; a < A; ++a) utilities[(size_t)(e * n + i) * A + a] = rel[i * A + a];
+    action[e * n + lane] = best;
   }
+  if (utilities)
+    for (int q = lane; q < n * A; q += 64) utilities[(size_t)e * n * A + q] = rel[q];
 }
 
 // target-class confusion counts of a map thresholded at L > thr (thr = 0 <=> p > 0.5): out int64 [n_maps,3] = tp, fp, fn
@@ -149,6 +183,7 @@ extern "C" int ippm_ig_candidates(ippm_ctx* ctx, const float* local, const int32
                                   int32_t n_envs, void* stream) {
   if (!ctx || !local || !pos || !mask || !gains) { ippm_set_error("ippm_ig_candidates: null argument"); return -1; }
   const int total = n_envs * ctx->cfg.n_agents * ctx->cfg.n_actions;
+  if (total <= 0) return 0;
   hipLaunchKernelGGL(k_ig_candidates, dim3(total), dim3(256), 0, S_(stream), ctx->dcfg, local, pos, mask, gains);
   IPPM_LAUNCH_CHECK("ig_candidates");
   return 0;
@@ -157,7 +192,8 @@ extern "C" int ippm_ig_candidates(ippm_ctx* ctx, const float* local, const int32
 extern "C" int ippm_ig_select(ippm_ctx* ctx, const int32_t* pos, const uint8_t* mask, const float* gains, int32_t communication,
                               int32_t* action, float* utilities, int32_t n_envs, void* stream) {
   if (!ctx || !pos || !mask || !gains || !action) { ippm_set_error("ippm_ig_select: null argument"); return -1; }
-  hipLaunchKernelGGL(k_ig_select, dim3((n_envs + 63) / 64), dim3(64), 0, S_(stream), ctx->dcfg, pos, mask, gains, communication, action,
+  if (n_envs <= 0) return 0;
+  hipLaunchKernelGGL(k_ig_select, dim3(n_envs), dim3(64), 0, S_(stream), ctx->dcfg, pos, mask, gains, communication, action,
                      utilities, n_envs);
   IPPM_LAUNCH_CHECK("ig_select");
   return 0;
