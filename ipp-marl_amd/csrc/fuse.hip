@@ -499,12 +499,12 @@ int ippm_fuse_wave_rows(const ippm_ctx* ctx, int n_envs) {
   if (rows <= 0) {
     const double est_rows = 0.5 * (double)n_envs * (ctx->cfg.n_agents + 1) * 0.6 * gx;
     rows = 8;
-    while (rows < 64 && est_rows / rows > 12288.0 * 1.5) rows *= 2;
+    while (rows < 32 && est_rows / rows > 12288.0 * 1.5) rows *= 2;   // (64 rows per item: 5 % slower at 8 UAVs x 512^2)
   }
   return std::min(gx, std::max((gx + 255) / 256, rows));
 }
 
-// One launch per plan-size class (<= 6 ops, 7..10, 11..18); each returns immediately for plans it does not own.
+// The kernel instantiation is chosen by the config's largest possible plan (<= 6 ops, <= 10, <= 18).
 // local_units / global_units: how many local / global maps; work: the plan kernel's item list (NULL: enumerate).
 static int launch_fuse(ippm_ctx* ctx, float* local, float* global, const uint8_t* code, int32_t* ws, double* sums, double* area,
                        const int32_t* work, int local_units, int global_units, int agent_sel, int n_envs_total, hipStream_t st) {
@@ -516,7 +516,10 @@ static int launch_fuse(ippm_ctx* ctx, float* local, float* global, const uint8_t
   const int chunks = (c.grid_x + wave_rows - 1) / wave_rows;
   // wavefronts of the persistent form: four rounds of the chip's 4096 slots (256 CUs x 4 SIMDs x 4 waves at 128 VGPRs); measured
   // 8192 / 12288 / 16384 / 24576 -> 122.6 / 118 / 113.5 / 116 us at config 2
-  const int persist = std::max(64, env_int("IPPM_FUSE_PERSIST", 16384));
+  // ... and about three items per wavefront on larger grids / teams (8 UAVs x 512^2 x 1024 envs: 16 / 32 / 64 wavefronts per env
+  // -> 1211 / 1173 / 1234 us; 4 UAVs x 1024^2: 16 / 64 -> 1577 / 1477 us)
+  const int per_env = ((c.n_agents + 1) * chunks + 2) / 3;
+  const int persist = std::max(64, env_int("IPPM_FUSE_PERSIST", std::max(16384, per_env * n_envs_total)));
   const int pgrid = n_envs_total * std::max(1, std::min(persist / std::max(n_envs_total, 1), (c.n_agents + 1) * chunks));
   dim3 grid(work ? (unsigned)pgrid : (unsigned)units * chunks), block(64);
 #define IPPM_FUSE(V, T, NA, SH, MINOPS)                                                                                  \
@@ -528,9 +531,11 @@ static int launch_fuse(ippm_ctx* ctx, float* local, float* global, const uint8_t
       IPPM_FUSE(V, T, 18, true, 1); /* slow path: one size */ \
       break;                                                 \
     }                                                        \
-    IPPM_FUSE(V, T, 6, false, 1);                            \
-    if (max_ops > 6) IPPM_FUSE(V, T, 10, false, 7);          \
-    if (max_ops > 10) IPPM_FUSE(V, T, 18, false, 11);        \
+    /* ONE launch, compiled for the config's largest plan, so that every item is visited once (a launch per plan-size */ \
+    /* class -- <= 6, 7..10, 11..18 ops, each skipping the others' items -- was 1.2x slower with 8 UAVs)              */ \
+    if (max_ops <= 6) IPPM_FUSE(V, T, 6, false, 1);          \
+    else if (max_ops <= 10) IPPM_FUSE(V, T, 10, false, 1);   \
+    else IPPM_FUSE(V, T, 18, false, 1);                      \
   } while (0)
   static_assert(IPPM_MAX_OPS <= 18, "largest instantiation of k_fuse_rows");
   if (ctx->vec == 4) { if (area) IPPM_FUSE_ALL(4, true); else IPPM_FUSE_ALL(4, false); }
