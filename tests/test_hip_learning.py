@@ -59,7 +59,8 @@ def test_actor_and_critic_step_match_reference(golden):
     np.testing.assert_allclose([am[k] for k in ACTOR_TAGS[7:]], fx["actor_metrics"][7:], rtol=3e-2, atol=1e-6)
 
 
-@pytest.mark.parametrize("name,n_envs", [("small", 6), ("c2", 64)])   # c2 x 64 envs: BASELINE config 3 at its real grid
+# c2 x 64 envs: BASELINE config 3 at its real grid; c4 x 8 envs: config 4's per-GPU shape (8 UAVs, 512 x 512)
+@pytest.mark.parametrize("name,n_envs", [("small", 6), ("c2", 64), ("c4", 8)])
 def test_trainer_round_and_td_chains(name, n_envs):
     from ippmarl.trainer import COMATrainer
     params = make_params(name)
