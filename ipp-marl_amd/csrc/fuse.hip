@@ -102,9 +102,11 @@ __device__ __forceinline__ void buf_store_cells(__amdgpu_buffer_rsrc_t r, int of
 }
 
 // sigmoid(a) - sigmoid(b) = (e_b - e_a) / ((1 + e_a)(1 + e_b)), e = exp(-L): three transcendentals instead of four, exact
-// zero for a == b; |L| is capped at 80 so that the product stays finite (sigmoid is saturated to 0 / 1 in float long before)
+// zero for a == b.  |L| is capped at 40 (sigmoid is 0 / 1 to float32 precision from |L| = 17 on) so that the product of the
+// two denominators stays finite: e^40 e^40 = 5.5e34.  Infinite log-odds do occur: the reference's sensor model is noise-free
+// at altitudes other than 5 / 10 / 15 m (sensor_models.py:13-22), a measurement there sets a cell to exactly 0 or 1.
 __device__ __forceinline__ float sigmoid_diff(float a, float b) {
-  const float ea = __expf(-fminf(fmaxf(a, -80.f), 80.f)), eb = __expf(-fminf(fmaxf(b, -80.f), 80.f));
+  const float ea = __expf(-fminf(fmaxf(a, -40.f), 40.f)), eb = __expf(-fminf(fmaxf(b, -40.f), 40.f));
   return (eb - ea) * __builtin_amdgcn_rcpf((1.0f + ea) * (1.0f + eb));
 }
 

@@ -15,6 +15,9 @@ MAX_AGENTS, MAX_LATTICE, MAX_Z = 16, 64, 8
 CLIP_LO, CLIP_HI = 0.0001, 0.9999
 
 
+START_ALTITUDE = 15   # agent/state_space.py:32: state_z = 15
+
+
 def _noise(altitude: int) -> float:
     # sensors/models/sensor_models.py:13-22 (coeff_a/coeff_b are never used by the reference)
     return {5: 0.01, 10: 0.265, 15: 0.375}.get(int(altitude), 0)
@@ -57,6 +60,12 @@ class DerivedConstants:
         self.altitudes = [self.min_altitude + k * self.spacing for k in range(self.space_z)]
         if self.n_agents > MAX_AGENTS or max(self.space_x, self.space_y) > MAX_LATTICE or self.space_z > MAX_Z:
             raise ValueError("configuration exceeds the compiled limits of libippmarl")
+        # The reference starts every UAV at z = 15 m whatever the altitude bounds say (agent/state_space.py:32) and projects its
+        # camera from the true altitude; the device tabulates footprints and sensor noise per lattice level, so the start level
+        # has to be one of them (otherwise the UAVs would fly at an altitude the tables do not hold)
+        if START_ALTITUDE not in self.altitudes:
+            raise ValueError(f"experiment.constraints min/max_altitude = {self.min_altitude}/{self.max_altitude} with spacing "
+                             f"{self.spacing} leave out {START_ALTITUDE} m, the altitude every UAV starts at (agent/state_space.py:32)")
         # centre cell of every lattice coordinate: floor(pos / res_x) for BOTH axes (cameras.py:66)
         xs = np.arange(self.space_x) * self.spacing
         ys = np.arange(self.space_y) * self.spacing

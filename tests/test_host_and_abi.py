@@ -56,6 +56,12 @@ def test_config_validation():
         DerivedConstants(p)
     with pytest.raises(ValueError):
         DerivedConstants(make_params("default", experiment__missions__n_agents=17))
+    # the reference starts every UAV at 15 m (agent/state_space.py:32): altitude bounds that leave that level out would fly
+    # the UAVs at an altitude the footprint / noise tables do not hold
+    with pytest.raises(ValueError, match="15 m"):
+        DerivedConstants(make_params("default", experiment__constraints__min_altitude=10, experiment__constraints__max_altitude=10))
+    DerivedConstants(make_params("default", experiment__constraints__min_altitude=15, experiment__constraints__max_altitude=15))
+    DerivedConstants(make_params("default", experiment__constraints__min_altitude=10, experiment__constraints__max_altitude=20))
 
 
 def test_library_loads_and_exports_every_declared_symbol():

@@ -1,0 +1,34 @@
+#!/usr/bin/env python
+"""Randomised sweep of the Philox-mode parity check (tests/test_hip_env_parity.py::test_production_randomness_matches_oracle):
+random team sizes, action sets, comm ranges, link-failure rates, seeds and episodes on the 128 x 128 and 256 x 256 grids; every
+step of every episode against the oracle.  python tools/stress_parity.py [n_cases] [rng_seed]"""
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for sub in ("tests", "oracle", "ipp-marl_amd"):
+    sys.path.insert(0, os.path.join(ROOT, sub))
+from test_hip_env_parity import test_production_randomness_matches_oracle as check  # noqa: E402
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+t0 = time.time()
+for k in range(n_cases):
+    name = "c2" if rng.random() < 0.2 else "small"
+    n = rng.choice([2, 3, 4, 5, 6, 7, 9, 11]) if name == "small" else rng.choice([2, 4, 6])
+    A = rng.choice([4, 6, 6, 9, 27])
+    over = dict(experiment__missions__n_agents=n, experiment__constraints__num_actions=A,
+                experiment__uav__communication_range=rng.choice([5, 10, 15, 25, 100]),
+                experiment__uav__failure_rate=rng.choice([0.0, 0.0, 0.2, 0.5]), experiment__uav__fix_range=rng.random() < 0.5)
+    if A in (4, 9):   # planar action sets fly at one altitude: the one every UAV starts at (agent/state_space.py:32)
+        over.update(experiment__constraints__min_altitude=15, experiment__constraints__max_altitude=15)
+    elif rng.random() < 0.3:   # other altitude lattices that hold the start level
+        lo, hi = rng.choice([(10, 15), (15, 20), (10, 20), (5, 20)])
+        over.update(experiment__constraints__min_altitude=lo, experiment__constraints__max_altitude=hi)
+    seed, ep0, n_envs = rng.getrandbits(40), rng.randrange(1, 5000), rng.choice([1, 2, 3])
+    check(name, over, n_envs, seed=seed, first_episode=ep0)
+    print(f"case {k}: {name} N={n} A={A} range={over['experiment__uav__communication_range']} fail={over['experiment__uav__failure_rate']} "
+          f"fix={over['experiment__uav__fix_range']} envs={n_envs} ok ({time.time() - t0:.0f}s)", flush=True)
+print("all", n_cases, "cases match the oracle")
