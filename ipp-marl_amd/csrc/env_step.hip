@@ -254,7 +254,7 @@ k_sense_update(const ippm_config* __restrict__ c, const int64_t* __restrict__ ep
           exceed |= in & (fabsf(l) > lc);
           m[u].v[q] = in ? l : old;
           cw |= (in ? obs : 0u) << q;
-          if (TRACK) d[q] = in ? ippm_sigmoid(l) - ippm_sigmoid(old) : 0.f;
+          if (TRACK) d[q] = in ? sigmoid_diff(l, old) : 0.f;
         }
         store_cells<VEC>(map + cell, m[u]);
         store_bits<VEC>(cd, rr, y - tile_y0, S, cw);

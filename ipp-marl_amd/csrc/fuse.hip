@@ -101,15 +101,6 @@ __device__ __forceinline__ void buf_store_cells(__amdgpu_buffer_rsrc_t r, int of
   }
 }
 
-// sigmoid(a) - sigmoid(b) = (e_b - e_a) / ((1 + e_a)(1 + e_b)), e = exp(-L): three transcendentals instead of four, exact
-// zero for a == b.  |L| is capped at 40 (sigmoid is 0 / 1 to float32 precision from |L| = 17 on) so that the product of the
-// two denominators stays finite: e^40 e^40 = 5.5e34.  Infinite log-odds do occur: the reference's sensor model is noise-free
-// at altitudes other than 5 / 10 / 15 m (sensor_models.py:13-22), a measurement there sets a cell to exactly 0 or 1.
-__device__ __forceinline__ float sigmoid_diff(float a, float b) {
-  const float ea = __expf(-fminf(fmaxf(a, -40.f), 40.f)), eb = __expf(-fminf(fmaxf(b, -40.f), 40.f));
-  return (eb - ea) * __builtin_amdgcn_rcpf((1.0f + ea) * (1.0f + eb));
-}
-
 // Rows [x, xe) of one slab with the ops of `set` (bit o = op o), at most NA of them.
 // Each of the rpw sub-rows of the wavefront takes a contiguous block of the slab's rows and keeps FU consecutive rows in
 // flight (all loads issued before the first use); rows therefore ascend by one per lane, which is what lets the area-sum
@@ -415,10 +406,14 @@ __device__ __forceinline__ void fuse_item(const ippm_config* __restrict__ c, flo
   // wave reduction of the reward terms and work counters: one atomic per wavefront and quantity
   {
     const float fc = ippm_wave_sum((float)acc.cells), fo = ippm_wave_sum((float)acc.opcells);
-    const float a1 = ippm_wave_sum(acc.a1), aD = ippm_wave_sum(acc.aD), aT = ippm_wave_sum(acc.aT);
+    double a1 = (double)acc.a1, aD = (double)acc.aD, aT = (double)acc.aT;   // the 64 lane sums are added up in float64
+    if (is_global) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { a1 += __shfl_xor(a1, o, 64); aD += __shfl_xor(aD, o, 64); aT += __shfl_xor(aT, o, 64); }
+    }
     if (lane < 3) {
-      const float v = lane == 0 ? a1 : (lane == 1 ? aD : aT);
-      if (is_global && sums && v != 0.f) atomicAdd(&sums[(size_t)e * 8 + SUM_ACC1 + lane], (double)v);
+      const double v = lane == 0 ? a1 : (lane == 1 ? aD : aT);
+      if (is_global && sums && v != 0.0) atomicAdd(&sums[(size_t)e * 8 + SUM_ACC1 + lane], v);
     } else if (lane < 5 && counters) {
       const float v = lane == 3 ? fc : fo;
       if (v > 0.f) atomicAdd(&counters[(cslot & (IPPM_COUNTER_SLOTS - 1)) * 8 + (is_global ? 3 : 1) + (lane - 3)], (unsigned long long)v);

@@ -114,13 +114,15 @@ __device__ __forceinline__ AreaCols<VEC> area_cols(int y, int gy, float inv_gy) 
   return a;
 }
 
+// (float64: a lane adds up to a dozen rows of weighted sigmoid differences of size ~0.5 x 121 before it flushes, and bins of
+// cells near 0 or 1 keep only a small remainder of those sums -- the entropy planes then amplify its error elevenfold)
 struct AreaAcc {  // per-lane partial sums for the row bins rb, rb+1 and the column bins cb, cb+1
-  float a0A, a0B, a1A, a1B;
+  double a0A, a0B, a1A, a1B;
   int rb;
-  __device__ __forceinline__ void init() { a0A = a0B = a1A = a1B = 0.f; rb = -1; }
-  __device__ __forceinline__ void put(double* s_area, int row_bin, int cb, float vA, float vB) {
-    if (vA != 0.f) atomicAdd(&s_area[row_bin * IPPM_AREA_LD + cb], (double)vA);      // ds_add_f64
-    if (vB != 0.f) atomicAdd(&s_area[row_bin * IPPM_AREA_LD + cb + 1], (double)vB);
+  __device__ __forceinline__ void init() { a0A = a0B = a1A = a1B = 0.0; rb = -1; }
+  __device__ __forceinline__ void put(double* s_area, int row_bin, int cb, double vA, double vB) {
+    if (vA != 0.0) atomicAdd(&s_area[row_bin * IPPM_AREA_LD + cb], vA);      // ds_add_f64
+    if (vB != 0.0) atomicAdd(&s_area[row_bin * IPPM_AREA_LD + cb + 1], vB);
   }
   __device__ __forceinline__ void flush(double* s_area, int cb) {
     if (rb >= 0) { put(s_area, rb, cb, a0A, a0B); put(s_area, rb + 1, cb, a1A, a1B); }
@@ -134,15 +136,27 @@ struct AreaAcc {  // per-lane partial sums for the row bins rb, rb+1 and the col
       if (rb >= 0) {
         put(s_area, rb, cb, a0A, a0B);
         if (rbn == rb + 1) { a0A = a1A; a0B = a1B; }
-        else { put(s_area, rb + 1, cb, a1A, a1B); a0A = a0B = 0.f; }
+        else { put(s_area, rb + 1, cb, a1A, a1B); a0A = a0B = 0.0; }
       }
-      a1A = a1B = 0.f;
+      a1A = a1B = 0.0;
       rb = rbn;
     }
     const float nA = (float)min((rbn + 1) * gx - n, 11), nB = 11.f - nA;
-    a0A += nA * cA; a0B += nA * cB; a1A += nB * cA; a1B += nB * cB;
+    a0A += (double)(nA * cA); a0B += (double)(nA * cB); a1A += (double)(nB * cA); a1B += (double)(nB * cB);
   }
 };
+
+// sigmoid(a) - sigmoid(b) = (e_b - e_a) / ((1 + e_a)(1 + e_b)), e = exp(-L): three transcendentals instead of four, exact
+// zero for a == b.  |L| is capped at 40 (sigmoid is 0 / 1 to float32 precision from |L| = 17 on) so that the product of the
+// two denominators stays finite: e^40 e^40 = 5.5e34.  Infinite log-odds do occur: the reference's sensor model is noise-free
+// at altitudes other than 5 / 10 / 15 m (sensor_models.py:13-22), a measurement there sets a cell to exactly 0 or 1.
+__device__ __forceinline__ float sigmoid_diff(float a, float b) {
+  const float ea = __expf(-fminf(fmaxf(a, -40.f), 40.f)), eb = __expf(-fminf(fmaxf(b, -40.f), 40.f));
+  return (eb - ea) * __builtin_amdgcn_rcpf((1.0f + ea) * (1.0f + eb));
+}
+// (Two separate sigmoids would carry an absolute error of ~6e-8 each; cells saturated at the clip all hold the same value and
+// make the same transitions, so those errors add up coherently over a bin -- 2e-7 on an area average near 1, which the entropy
+// plane amplifies elevenfold.  The quotient form's error is relative to the difference.)
 
 __device__ __forceinline__ void area_lds_clear(double* s_area) {
   for (int q = threadIdx.x; q < IPPM_FEAT * IPPM_AREA_LD + IPPM_AREA_LD; q += blockDim.x) s_area[q] = 0.0;

@@ -288,15 +288,15 @@ def test_coma_test_replays_reference_run(golden):
         np.testing.assert_allclose(out2[3], fx["entropies"], rtol=RTOL)
 
 
-def test_batched_ig_policy_matches_oracle():
-    """VecEnv.ig_actions (K9 + K10 for all envs at once) against the oracle's literal restatement."""
+def test_batched_ig_policy_matches_oracle(name="small", over=None, seed=5, first_episode=40, n_envs=6):
+    """VecEnv.ig_actions (K9 + K10 for all envs at once) against the oracle's literal restatement.
+    (The arguments: tools/stress_parity.py sweeps random configurations through this same check.)"""
     from ippmarl.vec_env import VecEnv, POLICY_EXPLICIT
-    params = make_params("small")
+    params = make_params(name, **(over or {}))
     d = O.Derived(params)
     d.exact = True
-    seed = 5
-    env = VecEnv(params, 6, philox_seed=seed)
-    eps = np.arange(40, 46)
+    env = VecEnv(params, n_envs, philox_seed=seed)
+    eps = np.arange(first_episode, first_episode + n_envs)
     env.reset(eps)
     for t in range(4):
         env.build_observations(t, features=False)

@@ -145,15 +145,22 @@ def test_production_randomness_matches_oracle(name, over, n_envs, seed=0x1234567
             assert np.array_equal(env.action[e].cpu().numpy(), rec["actions"]), (t, e)
             assert np.array_equal(env.pos[e].cpu().numpy(), rec["next_positions"]), (t, e)
             assert np.array_equal(env.rect[e].cpu().numpy(), rec["next_rects"]), (t, e)
-            assert_posteriors(local[e], np.array(rec["fused_local"]), strict=True, msg=f"fused local t={t} e={e}")
-            assert_posteriors(glob[e], rec["global_map"], strict=True, msg=f"global t={t} e={e}")
+            # (prior != 0.5: every message shifts every cell of the float32 log-odds maps; after dozens of whole-grid adds a few
+            #  cells per 100 000 sit just above 1e-5 -- there the bound is >= 99.99 % of the cells within 1e-5, all within 5e-5)
+            strict = env.d.prior == 0.5
+            assert_posteriors(local[e], np.array(rec["fused_local"]), strict=strict, msg=f"fused local t={t} e={e}")
+            assert_posteriors(glob[e], rec["global_map"], strict=strict, msg=f"global t={t} e={e}")
             # (prior != 0.5, the explicit slow path: every cell of the grid changes at every fusion and enters the reward sums,
             #  so the 1e-5 the cell values are held to shows up undiminished in the sums: 5e-5 on returns and sums there)
             # (altitudes outside the sensor model's table are noise-free: cells jump between exactly 0 / 1 and the clip, the
             #  reward terms are of size 1 with both signs and S1 is what is left after they cancel -- float32 wave partials)
             noise_free = any(z not in (5, 10, 15) for z in env.d.altitudes)
             rt = RTOL if env.d.prior == 0.5 and not noise_free else (5e-5 if not noise_free else 2e-4)
-            np.testing.assert_allclose(reward[e].cpu().numpy(), [rec["relative_reward"], rec["absolute_reward"]], rtol=rt, atol=1e-6)
+            # (the rewards are affine in the sums, 22 S1/S2 - 0.5 and 10 S1/cells - 0.17 (utils/reward.py:37-40): the tolerance of
+            #  the sums applies to the part in front of the offset, which matters when a reward is close to 0)
+            got_r = reward[e].cpu().numpy()
+            np.testing.assert_allclose(got_r[0], rec["relative_reward"], rtol=rt, atol=1e-6 + rt * 0.5)
+            np.testing.assert_allclose(got_r[1], rec["absolute_reward"], rtol=rt, atol=1e-6 + rt * 0.17)
             # (S1 = sum of w(a) (H(b) - H(a)) is a difference of two sums of the size of S2 -- with noise-free measurements that
             #  are clipped back at the next fusion the terms have both signs and nearly cancel: float32 wave partials, 2e-8 of S2.
             #  With prior != 0.5 every cell of the float32 maps enters both sums at every fusion: 5e-7 of S2 there.)
@@ -165,7 +172,7 @@ def test_production_randomness_matches_oracle(name, over, n_envs, seed=0x1234567
                 np.testing.assert_allclose(state[e].cpu().numpy(), np.array(rec["states"]), rtol=RTOL, atol=fa)
     final = env.posterior_local().cpu().numpy()
     for e, (ep, log) in enumerate(oracles):
-        assert_posteriors(final[e], np.array([a["local_map"] for a in ep.agents]), strict=True, msg=f"final local e={e}")
+        assert_posteriors(final[e], np.array([a["local_map"] for a in ep.agents]), strict=env.d.prior == 0.5, msg=f"final local e={e}")
 
 
 def _field_checks(got, want, tag):

@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for sub in ("tests", "oracle", "ipp-marl_amd"):
     sys.path.insert(0, os.path.join(ROOT, sub))
 from test_hip_env_parity import test_production_randomness_matches_oracle as check  # noqa: E402
+from test_hip_dropin import test_batched_ig_policy_matches_oracle as check_ig  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -36,6 +37,10 @@ for k in range(n_cases):
     seed, ep0, n_envs = rng.getrandbits(40), rng.randrange(1, 5000), rng.choice([1, 2, 3])
     try:
         check(name, over, n_envs, seed=seed, first_episode=ep0)
+        # every third case also through the greedy planner (K9 + K10) -- not above 15 m: the reference's planner divides by the
+        # sensor noise, which its sensor model sets to 0 there (ZeroDivisionError in IG_baseline.py, as in the oracle)
+        if over.get("mapping__prior", 0.5) == 0.5 and k % 3 == 0 and over.get("experiment__constraints__max_altitude", 15) <= 15:
+            check_ig(name, over, seed=seed & 0xFFFFFFFF, first_episode=ep0, n_envs=n_envs)
     except Exception as exc:
         msg = str(exc)
         if "footprint image smaller than 11 cells" in msg:   # a documented restriction: footprint images are only ever shrunk to 11 x 11
