@@ -148,7 +148,9 @@ k_ig_select(const ippm_config* __restrict__ c, const int32_t* __restrict__ pos, 
     float bv = rel[lane * A];
     for (int a = 1; a < A; ++a) {
       const float v = rel[lane * A + a];
-      if (v > bv) { bv = v; best = a; }   // np.argmax: first maximum (NaN never wins here)
+      // np.argmax: first maximum, and a nan counts as the maximum (an agent whose candidates all have zero gain has 0 / 0 in
+      // every entry, and candidates of others that share a cell with one of those inherit the nan)
+      if (v > bv || (v != v && bv == bv)) { bv = v; best = a; }
     }
     action[e * n + lane] = best;
   }

@@ -852,10 +852,13 @@ def ig_individual(d: Derived, position, mask: np.ndarray, map_state: np.ndarray)
 
 def ig_relative(gain_lists):
     """get_relative_ig (:291-298): per-agent normalisation, in place."""
+    # (the reference's gains are NumPy scalars: an agent whose candidates all have zero gain gets 0 / 0 = nan with a warning, not
+    #  a ZeroDivisionError; np.argmax then takes the first nan)
     for a in range(len(gain_lists)):
-        total = sum(gain_lists[a])
+        total = np.float64(sum(gain_lists[a]))
         for k in range(len(gain_lists[a])):
-            gain_lists[a][k] = gain_lists[a][k] / total
+            with np.errstate(divide="ignore", invalid="ignore"):
+                gain_lists[a][k] = np.float64(gain_lists[a][k]) / total
     return gain_lists
 
 
