@@ -164,7 +164,7 @@ def test_production_randomness_matches_oracle(name, over, n_envs, seed=0x1234567
             # (S1 = sum of w(a) (H(b) - H(a)) is a difference of two sums of the size of S2 -- with noise-free measurements that
             #  are clipped back at the next fusion the terms have both signs and nearly cancel: float32 wave partials, 2e-8 of S2.
             #  With prior != 0.5 every cell of the float32 maps enters both sums at every fusion: 5e-7 of S2 there.)
-            s_scale = 2e-8 if env.d.prior == 0.5 else 5e-7
+            s_scale = 2e-8 if env.d.prior == 0.5 and not noise_free else 5e-7   # (noise-free: lane sums of terms of size 1)
             np.testing.assert_allclose(env.sums[e, :2].cpu().numpy(), [rec["s1"], rec["s2"]], rtol=rt, atol=1e-6 + s_scale * abs(rec["s2"]))
             if feats:   # (prior != 0.5: the area sums take a small change of EVERY cell at every fusion: 6e-6 absolute there)
                 fa = 2e-6 if env.d.prior == 0.5 and not noise_free else 6e-6   # (noise-free: float32 increments of size 1/2)
