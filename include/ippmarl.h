@@ -305,6 +305,8 @@ int ippm_td_lambda(ippm_ctx* ctx, const float* reward, const uint8_t* done, cons
  * ippm_ig_candidates (K9): gains float [E,N,A] = expected weighted entropy reduction over the footprint each valid action
  * leads to, / 1000 (get_individual_ig); masked actions get 0.  ippm_ig_select (K10): get_relative_ig +
  * get_cell_utilities (when communication != 0) + argmax -> action int32 [E,N]; utilities float [E,N,A] optional.
+ * An agent whose candidates all have zero gain gets 0 / 0 = nan relative gains, and np.argmax's rule applies (the first nan
+ * is the maximum), as in the reference.
  * ippm_f1_counts: int64 [n_maps,3] = (tp, fp, fn) of the map thresholded at log-odds > logodds_threshold (0 <=> p > 0.5)
  * against the truth (utils/utils.py:64-76: sklearn f1_score(...)[1] = 2tp / (2tp + fp + fn)).  Cells whose evidence
  * cancels exactly sit at p = 0.5 +- rounding noise in the reference, which decides their class there; the threshold lets
