@@ -12,32 +12,14 @@ for sub in ("tests", "oracle", "ipp-marl_amd"):
     sys.path.insert(0, os.path.join(ROOT, sub))
 from test_hip_env_parity import test_production_randomness_matches_oracle as check  # noqa: E402
 from test_hip_dropin import test_batched_ig_policy_matches_oracle as check_ig  # noqa: E402
+from random_configs import random_case  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 t0 = time.time()
 ties = 0
 for k in range(n_cases):
-    u = rng.random()
-    name = "c4" if u < 0.03 else ("c2" if u < 0.2 else "small")   # 512 x 512 / 256 x 256 / 128 x 128 (and other sizes below)
-    n = rng.choice([2, 3, 4, 5, 6, 7, 9, 11]) if name == "small" else (rng.choice([2, 4, 6]) if name == "c2" else rng.choice([3, 8]))
-    A = rng.choice([4, 6, 6, 9, 27])
-    over = dict(experiment__missions__n_agents=n, experiment__constraints__num_actions=A,
-                experiment__uav__communication_range=rng.choice([5, 10, 15, 25, 100]),
-                experiment__uav__failure_rate=rng.choice([0.0, 0.0, 0.2, 0.5]), experiment__uav__fix_range=rng.random() < 0.5)
-    if A in (4, 9):   # planar action sets fly at one altitude: the one every UAV starts at (agent/state_space.py:32)
-        over.update(experiment__constraints__min_altitude=15, experiment__constraints__max_altitude=15)
-    elif rng.random() < 0.3:   # other altitude lattices that hold the start level
-        lo, hi = rng.choice([(10, 15), (15, 20), (10, 20), (5, 20)])
-        over.update(experiment__constraints__min_altitude=lo, experiment__constraints__max_altitude=hi)
-    if name == "small" and rng.random() < 0.4:   # other grid sizes: most are not a multiple of 4 cells wide (one-cell-per-lane kernels)
-        px = rng.choice([11, 12, 13, 14, 16, 17, 18, 19])
-        over.update(sensor__pixel__number_x=px, sensor__pixel__number_y=px)
-    if rng.random() < 0.15:   # the explicit slow path
-        over.update(mapping__prior=rng.choice([0.3, 0.4, 0.45]))
-    seed, ep0, n_envs = rng.getrandbits(40), rng.randrange(1, 5000), (1 if name == "c4" else rng.choice([1, 2, 3]))
-    if name == "small" and n <= 4 and rng.random() < 0.06:
-        n_envs = 48   # a batch large enough for other launch shapes (rows per work item, wavefronts per env)
+    name, over, n_envs, seed, ep0, n, A = random_case(rng)
     try:
         check(name, over, n_envs, seed=seed, first_episode=ep0)
         # every third case also through the greedy planner (K9 + K10) -- not above 15 m: the reference's planner divides by the
