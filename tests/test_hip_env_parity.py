@@ -117,17 +117,17 @@ def _oracle_philox_episode(params, episode, seed, learned_probs=None, truth=None
     ("small", dict(experiment__constraints__min_altitude=15, experiment__constraints__max_altitude=20,
                    experiment__constraints__num_actions=27, experiment__uav__communication_range=10), 2),
 ])
-def test_production_randomness_matches_oracle(name, over, n_envs, seed=0x1234567ABC, first_episode=11):
+def test_production_randomness_matches_oracle(name, over, n_envs, seed=0x1234567ABC, first_episode=11, track_area=True):
     """Philox mode (what bench/training use): device RNG streams, uniform random policy, every step vs the oracle.
     (``seed`` / ``first_episode``: tools/stress_parity.py sweeps random configurations through this same check.)"""
     from ippmarl.vec_env import POLICY_UNIFORM
     params = make_params(name, **over)
-    env = _env(params, n_envs, philox_seed=seed)
+    env = _env(params, n_envs, philox_seed=seed, track_area=track_area)
     eps = [first_episode + 7 * k for k in range(n_envs)]
     env.reset(eps)
     oracles = [_oracle_philox_episode(params, ep, seed) for ep in eps]
     T = env.d.budget + 1
-    feats = name != "default"
+    feats = name != "default" and track_area
     for t in range(T):
         obs = env.build_observations(t, features=feats)
         comm = env.comm.cpu().numpy()
@@ -175,6 +175,18 @@ def test_production_randomness_matches_oracle(name, over, n_envs, seed=0x1234567
         assert_posteriors(final[e], np.array([a["local_map"] for a in ep.agents]), strict=env.d.prior == 0.5, msg=f"final local e={e}")
 
 
+@pytest.mark.parametrize("name,over,n_envs", [
+    ("small", dict(), 5), ("c2", dict(), 3), ("c4", dict(), 1),
+    ("small", dict(experiment__missions__n_agents=12, experiment__uav__communication_range=100), 1),
+    ("small", dict(mapping__prior=0.3), 2),
+    ("small", dict(sensor__pixel__number_x=14, sensor__pixel__number_y=14, experiment__constraints__num_actions=27), 2),
+])
+def test_untracked_env_step_matches_oracle(name, over, n_envs):
+    """The env-only step as bench.py runs it -- VecEnv(track_area=False): K3 in its tile form, the fusion without area
+    tracking, the work list -- through the same every-step comparison with the oracle (maps, masks, actions, rewards)."""
+    test_production_randomness_matches_oracle(name, over, n_envs, seed=0x51C0FFEE11, first_episode=23, track_area=False)
+
+
 @pytest.mark.parametrize("k", range(12))
 def test_random_configurations_match_oracle(k):
     """A fixed dozen of the random configurations tools/stress_parity.py sweeps by the hundred (team size, action set, comm range,
@@ -183,7 +195,7 @@ def test_random_configurations_match_oracle(k):
     import random
     from random_configs import random_case
     name, over, n_envs, seed, ep0, _, _ = random_case(random.Random(7000 + k), pixels=(12, 13, 14, 16, 18, 19))
-    test_production_randomness_matches_oracle(name, over, min(n_envs, 3), seed=seed, first_episode=ep0)
+    test_production_randomness_matches_oracle(name, over, min(n_envs, 3), seed=seed, first_episode=ep0, track_area=k % 2 == 0)
 
 
 def _field_checks(got, want, tag):
