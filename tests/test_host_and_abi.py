@@ -64,6 +64,23 @@ def test_config_validation():
     DerivedConstants(make_params("default", experiment__constraints__min_altitude=10, experiment__constraints__max_altitude=20))
 
 
+def test_random_configurations_are_valid_on_the_host():
+    """Every configuration the parity sweep can draw (tests/random_configs.py) passes the host-side validation and stays inside
+    the compiled limits -- the sweep itself needs the GPU, this keeps its generator honest on CPU."""
+    import random
+    from ippmarl.derived import DerivedConstants
+    from random_configs import random_case
+    rng = random.Random(99)
+    seen = set()
+    for _ in range(300):
+        name, over, n_envs, seed, ep0, n, A = random_case(rng)
+        d = DerivedConstants(make_params(name, **over), philox_seed=seed)
+        assert d.n_agents == n and d.n_actions == A and 1 <= n_envs <= 48 and 15 in d.altitudes
+        assert ep0 * d.env_seed * max(n - 1, 1) < 2 ** 32           # NumPy legacy seeding limit of reset()
+        seen.add((name, d.grid_x, A, d.prior != 0.5, max(d.altitudes) > 15))
+    assert len(seen) > 40    # grid sizes x action sets x prior x altitude lattices actually vary
+
+
 def test_library_loads_and_exports_every_declared_symbol():
     from ippmarl import _ffi
     lib = _ffi.load_library()
