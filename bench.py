@@ -2,8 +2,9 @@
 """bench.py -- agent-env steps/s of the batched multi-UAV environment step on MI355X (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 150 --warmup 30
+    python bench.py --gpus 8 --steps 150 --warmup 30        # starts its own 8 ranks (one per GPU, RCCL) when not under a launcher
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus 8 --steps 150 --warmup 30
+        bench.py --gpus 8 --steps 150 --warmup 30           # the same, under an external launcher
 
 A "step" is one environment step of ALL envs on a rank, three launches: comm matrix + fusion plans + mask/act/move with a
 uniform random valid policy (K1) -> local fusion (K4) and global fusion + reward terms (K5) -> sense + Bayes update at the
@@ -14,10 +15,16 @@ Inputs are synthetic and resident in HBM (truth fields generated on the device).
 shard envs with no data-path collective ("weak" scaling: 1024 envs per GPU).
 
 The JSON line also carries
-  roofline         : the map-update kernel K3 (sense_update): algorithmic bytes = 10 B per footprint cell (4R+4W posterior,
-                     1R truth, 1W measurement code) / HIP-event time of every K3 launch of the timed region
-  roofline_kernels : the same for the fusion launch (K4+K5: 8 B per cell of the union + 1 B per (cell, message)) and, when
-                     training is on, the K6 feature builders
+  roofline         : the map-update kernel K3 (k_sense_tiles): algorithmic bytes = 10 B per footprint cell (4R+4W posterior,
+                     1R truth, 1W measurement code) / the kernel's own begin-to-end duration, taken from HIP
+                     events bound to each dispatch (hipExtLaunchKernelGGL; what rocprofv3's kernel trace reports) over a
+                     separate leg of --roofline-steps env steps run right after the timed region -- so the figure does not
+                     depend on --steps and the timed region carries no events at all;  whole_step = all algorithmic bytes of a
+                     step / ms_per_step / peak
+  roofline_kernels : the same for the fusion launch (K4+K5: 8 B per cell of the union + 1 B per (cell, message)), the small
+                     plan kernel, the reset kernels and, when training is on, the K6 feature builders
+  ranks, rank_devices, collective : who took part (one entry per rank) and the gradient all-reduces RCCL carried in the
+                     COMA leg (backend, calls, bytes)
   cpu_baseline     : the NumPy oracle (a port of the reference's CPU path, parity-pinned against it) stepping the same
                      config on one host core (one env) and on all host cores (64 envs), bounded to ~10 s each; the
                      reference itself as probed in the build container is quoted as reference_probe
@@ -83,6 +90,21 @@ def cpu_baseline(args, seconds=10.0):
             "reference_probe": REFERENCE_PROBE}
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` outside a launcher: re-run this command as N ranks (one per GPU) under
+    torch.distributed.run on a free local port.  The ranks' stdout is ours, so rank 0's JSON line comes out as usual."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def newest_pmc_summary():
     """profiles/rNN/pmc_summary.json of the newest round that has one (written by tools/pmc_summary.py from separate
     rocprofv3 --pmc passes of this command)."""
@@ -105,31 +127,49 @@ def main():
                     help="ground truth: the power-law random field of ground_truths.py:25-40 generated on the device, or "
                          "the half-plane split the reference flies over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-events", type=int, default=4, help="bracket the K3 and fusion launches of every K-th step (and "
-                    "every K-th reset) of the timed region with HIP events for the roofline legs; an event pair costs ~3 us of "
-                    "stream time, so K=1 adds ~13 us to every step; 0 = no brackets")
+    ap.add_argument("--roofline-steps", type=int, default=90, help="env steps (resets included) of the roofline leg that follows "
+                    "the timed region: every K3 / fusion / plan / reset launch of it carries start/stop events bound to the "
+                    "dispatch itself; 0 = no roofline leg")
     ap.add_argument("--train-rounds", type=int, default=2, help="COMA rounds (rollout with the actor + full update) timed after "
                     "the env-only region for the COMA updates/s figure; 0 disables")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI; gloo lets the "
                     "multi-rank code path be exercised on a single GPU)")
     ap.add_argument("--graphs", type=int, default=0, help="replay {plan+K1, K4+K5} of each step from a hipGraph; K3 stays an "
                     "ordinary launch.  Off by default: three launches per step do not need it")
+    ap.add_argument("--rendezvous-only", action="store_true", help="start the ranks, all-reduce the rank ids over --dist-backend, "
+                    "print {\"ranks\": N, ...} and stop before any GPU work (the CPU test of the self-launch)")
     ap.add_argument("--calib", action="store_true", help="PMC calibration: 3 device-to-device copies of the local maps (known "
                     "bytes read and written by a 16 B/lane streaming kernel) before the timed loop")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))   # not under a launcher: start the ranks ourselves and relay rank 0's line
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks (WORLD_SIZE)")
     dist = None
+    if args.rendezvous_only:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo" if args.dist_backend == "nccl" and not torch.cuda.is_available() else args.dist_backend)
+        ids = torch.tensor([rank], dtype=torch.int64)
+        dist.all_reduce(ids)
+        if rank == 0:
+            print(json.dumps({"ranks": dist.get_world_size(), "n_gpus": world, "rank_id_sum": int(ids[0]),
+                              "backend": dist.get_backend()}), flush=True)
+        dist.destroy_process_group()
+        return
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         n_dev = torch.cuda.device_count()
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank % n_dev}"))
+            if n_dev < world:
+                raise SystemExit(f"--gpus {world} with RCCL needs {world} visible GPUs, found {n_dev} "
+                                 "(--dist-backend gloo lets the ranks share a GPU for a dry run of the control flow)")
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
         else:
             dist.init_process_group(args.dist_backend)
         local_rank %= n_dev
@@ -149,19 +189,11 @@ def main():
         env.reset(episode_ids(1, wave[0], E, rank, world))   # disjoint episodes per rank and wave
         wave[0] += 1
 
-    sample = [0]
-
-    def sampled():   # every K-th launch group of the timed region carries event brackets
-        sample[0] += 1
-        return bool(args.profile_events) and sample[0] % args.profile_events == 0
-
-    def one_step(t, timed):
-        env.profile = timed and sampled()
+    def one_step(t):
         if args.graphs:
             env.step_graphed(t)
         else:
             env.steps(t, policy=POLICY_UNIFORM, features=False)
-        env.profile = False
 
     reset()
     if args.graphs:
@@ -177,7 +209,7 @@ def main():
         torch.cuda.synchronize()
     t_in_ep = 0
     for _ in range(args.warmup):
-        one_step(t_in_ep, False)
+        one_step(t_in_ep)
         t_in_ep += 1
         if t_in_ep == T:
             reset()
@@ -190,13 +222,11 @@ def main():
     t0 = time.perf_counter()
     resets_timed = 0
     for _ in range(args.steps):
-        one_step(t_in_ep, True)
+        one_step(t_in_ep)
         t_in_ep += 1
         if t_in_ep == T:
             resets_timed += 1
-            env.profile = sampled()   # the reset's start-position sensing is a K3 launch of the timed region too
             reset()
-            env.profile = False
             t_in_ep = 0
     torch.cuda.synchronize()
     if dist:
@@ -208,19 +238,27 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt[0])
     counters = env.counters()
-    times = env.event_times_us()
     faults = int(env.fault.abs().sum())
     grid = [env.d.grid_x, env.d.grid_y]
 
-    # cost of an empty event bracket on this stream (the bracketed times include it; rocprofv3's kernel trace does not)
-    empty = []
-    for _ in range(64):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        b.record()
-        empty.append((a, b))
-    torch.cuda.synchronize()
-    event_overhead_us = 1e3 * sum(a.elapsed_time(b) for a, b in empty) / len(empty)
+    # Roofline leg: the same loop goes on for --roofline-steps more env steps (resets included) with kernel timing on -- every
+    # launch of the timed classes carries a start/stop event pair bound to its own dispatch (kernel begin -> end, the figure
+    # rocprofv3's kernel trace reports; no barrier packets, nothing to calibrate away) -- and with its own work counters, so
+    # bytes and durations cover exactly the same launches whatever --steps was.
+    times, rl_counters, rl_resets = {}, None, 0
+    if args.roofline_steps > 0 and not args.graphs:
+        env.counters(reset=True)
+        env.profile = True
+        for _ in range(args.roofline_steps):
+            one_step(t_in_ep)
+            t_in_ep += 1
+            if t_in_ep == T:
+                rl_resets += 1
+                reset()
+                t_in_ep = 0
+        env.profile = False
+        times = env.event_times_us()
+        rl_counters = env.counters()
     # second denominator: what a plain 16 B/lane device-to-device copy of the local maps reaches on this box
     stream_copy()
     ca, cb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -234,51 +272,63 @@ def main():
     pmc, pmc_path = newest_pmc_summary()
     pmc_ok = bool(pmc) and pmc.get("envs_per_gpu") == E and pmc.get("n_agents") == N and pmc.get("grid") == grid[0]
 
-    def roofline_entry(kernel, pmc_key, label, bytes_per_launch, bracket, extra=None):
-        if bracket is None or not bracket["launches"]:
+    TIMING = ("HIP start/stop events bound to each dispatch (hipExtLaunchKernelGGL): the kernel's own begin-to-end duration, as "
+              "rocprofv3's kernel trace reports it; no bracket overhead to subtract, so frac_raw == frac")
+
+    def roofline_entry(pmc_key, what, bytes_per_launch, timed, extra=None):
+        if timed is None or not timed["launches"]:
             return None
-        raw_us = bracket["avg_us"]
-        # kernel duration = bracketed time minus the cost of the bracket itself, calibrated above on the same stream; the
-        # uncorrected figures are kept as *_raw (rocprofv3's kernel-only duration of the same command: profiles/rNN/)
-        us = max(raw_us - event_overhead_us, 0.5 * raw_us)
+        us = timed["avg_us"]
         achieved = bytes_per_launch / (us * 1e-6) / 1e9
         traffic = pmc.get(pmc_key, {}).get("hbm_bytes_per_launch") if pmc_ok else None
-        out = {"bound": "hbm", "kernel": label, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        out = {"bound": "hbm", "kernel": timed["kernel"], "what": what, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": achieved / HBM_PEAK_GBS, "frac_raw": achieved / HBM_PEAK_GBS, "traffic": traffic,
                "traffic_source": f"{pmc_path} (static: separate rocprofv3 --pmc passes of this command, not measured in this run)"
                if traffic is not None else None,
-               "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": us, "avg_launch_us_raw": raw_us,
-               "bracketed_launches": bracket["launches"], "empty_event_pair_us": event_overhead_us,
-               "frac_raw": bytes_per_launch / (raw_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+               "algorithmic_bytes_per_launch": bytes_per_launch, "avg_launch_us": us, "min_launch_us": timed["min_us"],
+               "timed_launches": timed["launches"], "timing": TIMING,
                "stream_copy_GBps": copy_gbs, "frac_of_stream_copy": achieved / copy_gbs}
         out.update(extra or {})
         return out
+
+    def fusion_bytes(c):   # 8 B per cell of the union (R+W once) + 1 B per (cell, message) code read
+        return 8 * (c["fuse_local_cells"] + c["fuse_global_cells"]) + c["fuse_local_ops"] + c["fuse_global_ops"]
 
     k3 = times.get("sense")
     fuse = times.get("fuse")
     roofline = roofline_kernels = None
     if k3:
-        # the counters cover every launch of the timed region, the brackets a 1-in-K sample of them
-        k3_launches, fuse_launches = args.steps + resets_timed, args.steps
-        cells = counters["sense_cells"] / k3_launches
-        roofline = roofline_entry("k_sense_update", "k_sense_update", "k_sense_update (K3: sense + Bayes update of the footprint tile)",
-                                  K3_BYTES_PER_CELL * cells, k3,
+        # counters and durations of the roofline leg cover the same launches: its steps' K3 + its resets' start sensing
+        cells = rl_counters["sense_cells"] / k3["launches"]
+        roofline = roofline_entry("k_sense_update", "K3: sense + Bayes update of the footprint tiles", K3_BYTES_PER_CELL * cells, k3,
                                   {"algorithmic_bytes_per_cell": K3_BYTES_PER_CELL, "cells_per_launch": cells,
-                                   "note": "avg_launch_us = HIP-event brackets of the K3 launches of every K-th step of the timed region "
-                                           "(config.event_brackets_every) minus the cost of an "
-                                           "empty event pair measured in the same run; frac_raw keeps the uncorrected figure"})
+                                   "launches": f"{args.roofline_steps} steps + {rl_resets} resets (start-position sensing) right after "
+                                               "the timed region"})
+        # every algorithmic byte of a step of the TIMED region (K3 + fusion; the small plan kernel's ~2.4 MB left out) against
+        # the step's wall time: what the whole step, launch gaps and resets included, makes of the HBM peak
+        step_bytes = (K3_BYTES_PER_CELL * counters["sense_cells"] + fusion_bytes(counters)) / args.steps
+        roofline["whole_step"] = {"algorithmic_bytes_per_step": step_bytes, "ms_per_step": 1e3 * dt / args.steps,
+                                  "achieved": step_bytes / (dt / args.steps) / 1e9,
+                                  "frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS}
         roofline_kernels = [roofline]
     if fuse:
-        lc, lo = counters["fuse_local_cells"], counters["fuse_local_ops"]
-        gc, go = counters["fuse_global_cells"], counters["fuse_global_ops"]
-        by = (8 * (lc + gc) + (lo + go)) / fuse_launches
+        by = fusion_bytes(rl_counters) / fuse["launches"]
         roofline_kernels.append(roofline_entry(
-            "k_fuse_rows", "k_fuse_rows", "k_fuse_rows (K4 local fusion + K5 global fusion and reward terms, one launch)", by, fuse,
+            "k_fuse_rows", "K4 local fusion + K5 global fusion and reward terms, one launch", by, fuse,
             {"algorithmic_bytes": "8 B per cell of the union (R+W once) + 1 B per (cell, message) code read",
-             "local_cells_per_launch": lc / fuse_launches, "global_cells_per_launch": gc / fuse_launches,
-             "message_cells_per_launch": (lo + go) / fuse_launches}))
+             "local_cells_per_launch": rl_counters["fuse_local_cells"] / fuse["launches"],
+             "global_cells_per_launch": rl_counters["fuse_global_cells"] / fuse["launches"],
+             "message_cells_per_launch": (rl_counters["fuse_local_ops"] + rl_counters["fuse_global_ops"]) / fuse["launches"]}))
+    if roofline_kernels is not None:
+        for cls, what in (("plan", "comm matrix + fusion plans + work list + K1, one wavefront per env"),
+                          ("reset", "episode reset: scalars and prior fills (per kernel launch)"),
+                          ("terrain", "random-field synthesis passes (per kernel launch)")):
+            if cls in times:
+                roofline_kernels.append({"kernel": times[cls]["kernel"], "what": what, "avg_launch_us": times[cls]["avg_us"],
+                                         "min_launch_us": times[cls]["min_us"], "timed_launches": times[cls]["launches"],
+                                         "us_per_step": times[cls]["avg_us"] * times[cls]["launches"] / args.roofline_steps})
 
-    coma = None
+    coma = collective = None
     if args.train_rounds > 0:
         # BASELINE configs[2]: full COMA actor + counterfactual critic training on the same env config
         from ippmarl.trainer import COMATrainer
@@ -313,12 +363,13 @@ def main():
         tr.rollout("eval")
         tr.env.profile = False
         kt = tr.env.event_times_us()
-        coma["rollout_kernel_us"] = {k: round(max(v["avg_us"] - event_overhead_us, 0.5 * v["avg_us"]), 2) for k, v in kt.items()}
-        coma["rollout_kernel_us"]["note"] = ("HIP-event brackets minus the empty-bracket cost; sense/fuse here also maintain the "
-                                             "11x11 area sums of every map, which is what lets the K6 builders skip the maps")
+        coma["rollout_kernel_us"] = {k: round(v["avg_us"], 2) for k, v in kt.items()}
+        coma["rollout_kernel_us"]["kernels"] = {k: v["kernel"] for k, v in kt.items()}
+        coma["rollout_kernel_us"]["note"] = ("dispatch-bound start/stop events (kernel-only durations); sense/fuse here also maintain "
+                                             "the 11x11 area sums of every map, which is what lets the K6 builders skip the maps")
         if roofline_kernels is not None and "actor_features" in kt:
             c = tr.env.counters()
-            k6_us = sum(max(kt[k]["avg_us"] - event_overhead_us, 0.5 * kt[k]["avg_us"]) for k in ("actor_features", "critic_features"))
+            k6_us = sum(kt[k]["avg_us"] for k in ("actor_features", "critic_features"))
             roofline_kernels.append({
                 "bound": "hbm", "kernel": "K6 (k_actor_features + k_critic_features) with tracked area sums", "unit": "GB/s",
                 "peak": HBM_PEAK_GBS, "avg_launch_us": k6_us,
@@ -330,6 +381,19 @@ def main():
                         "longer read at all (their area sums are maintained by the kernels that write them), so the 'achieved' "
                         "figure is the rate a streaming implementation would need to match this time and may exceed the peak",
                 "sense_cells_per_step": c["sense_cells"] / tr.T})
+        if world > 1:   # evidence that the gradient exchange really ran over `world` ranks: every rank's device, calls and bytes
+            import socket
+            mine = {"rank": rank, "host": socket.gethostname(), "device": torch.cuda.current_device(),
+                    "name": torch.cuda.get_device_name(), "allreduce_calls": tr.reducer.calls,
+                    "allreduce_bytes": tr.reducer.bytes_reduced}
+            gathered = [None] * world
+            dist.all_gather_object(gathered, mine)
+            collective = {"backend": dist.get_backend(), "library": "RCCL over xGMI" if dist.get_backend() == "nccl" else dist.get_backend(),
+                          "world_size": dist.get_world_size(), "allreduce_calls": tr.reducer.calls,
+                          "allreduce_bytes": tr.reducer.bytes_reduced,
+                          "per_update": {"calls": tr.reducer.calls // (args.train_rounds + 1),
+                                         "bytes": tr.reducer.bytes_reduced // (args.train_rounds + 1)},
+                          "ranks": gathered}
         if world == 1:
             # the reference's own round size for comparison with its 0.164 updates/s: 5 episodes ->
             # 300 transitions per update, 25 + 25 Adam steps on 60-sample minibatches
@@ -364,20 +428,22 @@ def main():
             "config": {"workload": ("BASELINE.json configs[1]: " if is_c1 else "NOT the metric's config (a parity-test shape): ") + shape,
                        "envs_per_gpu": E, "n_agents": N, "grid": grid,
                        "episode_steps": T, "terrain": args.terrain, "parallelism": f"env-sharded x{world} (no data-path collective)",
-                       "launches_per_step": 3, "hip_graphs": bool(args.graphs), "event_brackets_every": args.profile_events},
+                       "launches_per_step": 3, "hip_graphs": bool(args.graphs), "roofline_steps": args.roofline_steps},
+            "ranks": world,
+            "collective": collective if args.train_rounds > 0 else None,
             "faults": faults,
             "cells": counters,
             "roofline": roofline,
             "roofline_kernels": roofline_kernels,
             "coma_training": coma,
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args)
-        elif not args.no_cpu_baseline:
-            out["cpu_baseline"] = None
-        print(json.dumps(out))
-    if dist:
+    if dist:   # every collective is done: the other ranks may leave while rank 0 times the CPU baseline on the host cores
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define IPPM_VERSION 200
+#define IPPM_VERSION 300
 #define IPPM_MAX_AGENTS 16
 #define IPPM_MAX_LATTICE 64 /* lattice points per horizontal axis */
 #define IPPM_MAX_Z 8        /* altitude levels */
@@ -122,6 +122,24 @@ int ippm_ctx_create(const ippm_config* cfg, ippm_ctx** out);
 int ippm_ctx_destroy(ippm_ctx* ctx);
 int ippm_sync(ippm_ctx* ctx, void* stream);
 int ippm_read_counters(ippm_ctx* ctx, ippm_counters* out, int reset, void* stream); /* synchronises */
+
+/* Kernel timing (measurement aid; no reference counterpart).  While enabled, every launch of the classes below carries a
+ * HIP event pair bound to the dispatch itself (hipExtLaunchKernelGGL start/stop events): their difference is the kernel's own
+ * begin-to-end duration -- the figure rocprofv3's kernel trace reports -- with no barrier packet added to the stream.
+ * ippm_read_kernel_times synchronises the stream and returns, for one class, the number of timed launches since the last
+ * reset, their summed and shortest duration in microseconds and the name of the last kernel launched in that class as the
+ * compiler (and rocprofv3) spells it.  At most IPPM_TIMED_CAP launches per class are held between two resetting reads. */
+#define IPPM_T_SENSE 0        /* K3: k_sense_tiles / k_sense_update */
+#define IPPM_T_FUSE 1         /* K4 + K5: k_fuse_rows */
+#define IPPM_T_PLAN 2         /* k_plan_step */
+#define IPPM_T_ACTOR_FEAT 3   /* K6 actor */
+#define IPPM_T_CRITIC_FEAT 4  /* K6 critic */
+#define IPPM_T_RESET 5        /* reset: scalars, truth split, prior fills */
+#define IPPM_T_TERRAIN 6      /* random-field synthesis passes */
+#define IPPM_TIMED_CLASSES 8
+int ippm_kernel_timing(ippm_ctx* ctx, int32_t enable);
+int ippm_read_kernel_times(ippm_ctx* ctx, int32_t cls, int32_t reset, int64_t* launches, double* total_us, double* min_us,
+                           char* name, int32_t name_len, void* stream);
 
 /* ---- reset ---------------------------------------------------------------------------------------
  * ippm_reset_episode replaces Mapping.__init__ -> Simulation.simulate_map -> gaussian_random_field

@@ -1,5 +1,6 @@
 // Context management, error reporting and host-side helpers of libippmarl.so.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -81,6 +82,13 @@ extern "C" int ippm_ctx_create(const ippm_config* cfg, ippm_ctx** out) {
   // 16-byte lane groups need a grid that is a multiple of 4 wide; the area sums additionally want a 4-cell group to span at
   // most two of the 11 column bins (grid_y >= 44).  Everything else takes the one-cell-per-lane instantiations.
   ctx->vec = (c.grid_y % 4 == 0 && c.grid_y >= 4 * IPPM_FEAT) ? 4 : 1;
+  // tuning knobs are read once, here: the size of the caller's work buffer, the plan kernel's item layout and the fusion launch
+  // all follow from them, and a value that changed between two calls would make them disagree
+  auto knob = [](const char* name, int dflt) { const char* v = getenv(name); return v && *v ? atoi(v) : dflt; };
+  ctx->knob_wave_rows = knob("IPPM_FUSE_WAVE_ROWS", 0);
+  ctx->knob_persist = knob("IPPM_FUSE_PERSIST", 0);
+  ctx->knob_nowork = knob("IPPM_FUSE_NOWORK", 0);
+  ctx->knob_split = knob("IPPM_FUSE_SPLIT", 0);
   int rc = ippm_check_hip(hipMalloc(&ctx->dcfg, sizeof(ippm_config)), "hipMalloc(cfg)");
   if (!rc) rc = ippm_check_hip(hipMemcpy(ctx->dcfg, cfg, sizeof(ippm_config), hipMemcpyHostToDevice), "hipMemcpy(cfg)");
   if (!rc) rc = ippm_check_hip(hipMalloc(&ctx->dcounters, IPPM_COUNTER_SLOTS * 8 * sizeof(unsigned long long)), "hipMalloc(counters)");
@@ -94,6 +102,10 @@ extern "C" int ippm_ctx_destroy(ippm_ctx* ctx) {
   if (!ctx) return 0;
   if (ctx->dcfg) (void)hipFree(ctx->dcfg);
   if (ctx->dcounters) (void)hipFree(ctx->dcounters);
+  for (int k = 0; k < IPPM_TIMED_CLASSES; ++k) {
+    for (int i = 0; i < 2 * ctx->ev_made[k]; ++i) (void)hipEventDestroy(ctx->ev[k][i]);
+    delete[] ctx->ev[k];
+  }
   delete ctx;
   return 0;
 }
@@ -101,6 +113,59 @@ extern "C" int ippm_ctx_destroy(ippm_ctx* ctx) {
 extern "C" int ippm_sync(ippm_ctx* ctx, void* stream) {
   (void)ctx;
   IPPM_HIP(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+  return 0;
+}
+
+// ---- kernel timing ----------------------------------------------------------------------------------------------------
+void ippm_timing_events(ippm_ctx* ctx, int cls, const char* name, hipEvent_t* a, hipEvent_t* b) {
+  *a = *b = nullptr;
+  if (cls < 0 || cls >= IPPM_TIMED_CLASSES || ctx->ev_used[cls] >= IPPM_TIMED_CAP) return;
+  if (!ctx->ev[cls]) {
+    ctx->ev[cls] = new hipEvent_t[2 * IPPM_TIMED_CAP];
+    ctx->ev_made[cls] = 0;
+  }
+  const int k = ctx->ev_used[cls];
+  if (k >= ctx->ev_made[cls]) {
+    hipEvent_t ea, eb;
+    if (hipEventCreate(&ea) != hipSuccess) return;
+    if (hipEventCreate(&eb) != hipSuccess) { (void)hipEventDestroy(ea); return; }
+    ctx->ev[cls][2 * k] = ea; ctx->ev[cls][2 * k + 1] = eb;
+    ctx->ev_made[cls] = k + 1;
+  }
+  *a = ctx->ev[cls][2 * k]; *b = ctx->ev[cls][2 * k + 1];
+  ctx->ev_used[cls] = k + 1;
+  ctx->ev_name[cls] = name;
+}
+
+extern "C" int ippm_kernel_timing(ippm_ctx* ctx, int32_t enable) {
+  if (!ctx) { ippm_set_error("ippm_kernel_timing: null context"); return -1; }
+  ctx->timing = enable ? 1 : 0;
+  return 0;
+}
+
+extern "C" int ippm_read_kernel_times(ippm_ctx* ctx, int32_t cls, int32_t reset, int64_t* launches, double* total_us, double* min_us,
+                                      char* name, int32_t name_len, void* stream) {
+  if (!ctx || !launches || !total_us) { ippm_set_error("ippm_read_kernel_times: null argument"); return -1; }
+  if (cls < 0 || cls >= IPPM_TIMED_CLASSES) { ippm_set_error("ippm_read_kernel_times: unknown kernel class"); return -1; }
+  IPPM_HIP(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)));
+  double sum = 0.0, mn = 0.0;
+  const int n = ctx->ev_used[cls];
+  for (int k = 0; k < n; ++k) {
+    float ms = 0.f;
+    IPPM_HIP(hipEventElapsedTime(&ms, ctx->ev[cls][2 * k], ctx->ev[cls][2 * k + 1]));
+    sum += 1e3 * (double)ms;
+    mn = (k == 0 || 1e3 * (double)ms < mn) ? 1e3 * (double)ms : mn;
+  }
+  *launches = n; *total_us = sum;
+  if (min_us) *min_us = mn;
+  if (name && name_len > 0) {
+    // "(k_fuse_rows<4, false, 6, false>)" as written at the launch site -> without the macro's parentheses
+    std::string s = ctx->ev_name[cls] ? ctx->ev_name[cls] : "";
+    if (s.size() >= 2 && s.front() == '(' && s.back() == ')') s = s.substr(1, s.size() - 2);
+    std::strncpy(name, s.c_str(), (size_t)name_len - 1);
+    name[name_len - 1] = 0;
+  }
+  if (reset) ctx->ev_used[cls] = 0;
   return 0;
 }
 

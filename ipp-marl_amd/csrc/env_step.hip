@@ -449,12 +449,12 @@ static int env_int(const char* name, int dflt) {
   return v && *v ? atoi(v) : dflt;
 }
 
-static int fill_f32(float* p, float v, size_t n, hipStream_t st) {
+static int fill_f32(ippm_ctx* ctx, float* p, float v, size_t n, hipStream_t st) {
   if (n == 0) return 0;
   if (n % 4 == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
-    hipLaunchKernelGGL(k_fill_f32x4, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<float4*>(p), v, n / 4);
+    IPPM_LAUNCH(ctx, IPPM_T_RESET, k_fill_f32x4, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), st, reinterpret_cast<float4*>(p), v, n / 4);
   } else {
-    hipLaunchKernelGGL(k_fill_f32, dim3(std::min(4096, grid1(n))), dim3(256), 0, st, p, v, n);
+    IPPM_LAUNCH(ctx, IPPM_T_RESET, k_fill_f32, dim3(std::min(4096, grid1(n))), dim3(256), st, p, v, n);
   }
   IPPM_LAUNCH_CHECK("fill");
   return 0;
@@ -468,17 +468,17 @@ extern "C" int ippm_reset_episode(ippm_ctx* ctx, const int64_t* episode, int32_t
   if (n_envs <= 0) return 0;
   const ippm_config& c = ctx->cfg;
   const int per = c.n_agents + 1;
-  hipLaunchKernelGGL(k_reset_scalars, dim3(grid1((size_t)n_envs * per, 64)), dim3(64), 0, S_(stream), ctx->dcfg, episode, pos,
+  IPPM_LAUNCH(ctx, IPPM_T_RESET, k_reset_scalars, dim3(grid1((size_t)n_envs * per, 64)), dim3(64), S_(stream), ctx->dcfg, episode, pos,
                      split_pct, comm_range_out, ws, sums, area, n_envs);
   IPPM_LAUNCH_CHECK("reset_scalars");
   const size_t cells = (size_t)c.grid_x * c.grid_y;
   if (truth) {
-    hipLaunchKernelGGL(k_fill_truth, dim3(std::min(64, grid1(cells)), n_envs), dim3(256), 0, S_(stream), ctx->dcfg, split_pct,
+    IPPM_LAUNCH(ctx, IPPM_T_RESET, k_fill_truth, dim3(std::min(64, grid1(cells)), n_envs), dim3(256), S_(stream), ctx->dcfg, split_pct,
                        truth, n_envs);
     IPPM_LAUNCH_CHECK("fill_truth");
   }
-  if (local) if (int rc = fill_f32(local, c.logit_prior, cells * n_envs * c.n_agents, S_(stream))) return rc;
-  if (global) if (int rc = fill_f32(global, c.logit_prior, cells * n_envs, S_(stream))) return rc;
+  if (local) if (int rc = fill_f32(ctx, local, c.logit_prior, cells * n_envs * c.n_agents, S_(stream))) return rc;
+  if (global) if (int rc = fill_f32(ctx, global, c.logit_prior, cells * n_envs, S_(stream))) return rc;
   return 0;
 }
 
@@ -553,10 +553,10 @@ extern "C" int ippm_sense_step(ippm_ctx* ctx, const int64_t* episode, const int3
     dim3 grid((unsigned)parts, (unsigned)(agent_sel >= 0 ? 1 : c.n_agents), (unsigned)n_envs);
     int32_t* rect_out = rect_in == rect ? nullptr : rect;
     if (ctx->vec == 4)
-      hipLaunchKernelGGL((k_sense_tiles<4>), grid, block, 0, S_(stream), ctx->dcfg, episode, pos, truth, local, flips, code, rect_in,
+      IPPM_LAUNCH(ctx, IPPM_T_SENSE, (k_sense_tiles<4>), grid, block, S_(stream), ctx->dcfg, episode, pos, truth, local, flips, code, rect_in,
                          rect_out, ws, sums, reward, ctx->dcounters, stage, agent_sel, rows_per_part);
     else
-      hipLaunchKernelGGL((k_sense_tiles<1>), grid, block, 0, S_(stream), ctx->dcfg, episode, pos, truth, local, flips, code, rect_in,
+      IPPM_LAUNCH(ctx, IPPM_T_SENSE, (k_sense_tiles<1>), grid, block, S_(stream), ctx->dcfg, episode, pos, truth, local, flips, code, rect_in,
                          rect_out, ws, sums, reward, ctx->dcounters, stage, agent_sel, rows_per_part);
     IPPM_LAUNCH_CHECK("sense_tiles");
     return 0;
@@ -566,8 +566,8 @@ extern "C" int ippm_sense_step(ippm_ctx* ctx, const int64_t* episode, const int3
   const int unr = env_int("IPPM_UNROLL_K3", 2);
   int32_t* rect_out = rect_in == rect ? nullptr : rect;
 #define IPPM_K3_LAUNCH(V, U, T)                                                                                               \
-  hipLaunchKernelGGL((k_sense_update<V, U, T>), grid, block, 0, S_(stream), ctx->dcfg, episode, pos, truth, local, flips, code, \
-                     rect_in, rect_out, ws, area, sums, reward, ctx->dcounters, stage, agent_sel, split, maps, n_envs)
+  IPPM_LAUNCH(ctx, IPPM_T_SENSE, (k_sense_update<V, U, T>), grid, block, S_(stream), ctx->dcfg, episode, pos, truth, local, flips, code, \
+              rect_in, rect_out, ws, area, sums, reward, ctx->dcounters, stage, agent_sel, split, maps, n_envs)
   if (ctx->vec == 4) {
     if (area) { if (unr >= 2) IPPM_K3_LAUNCH(4, 2, true); else IPPM_K3_LAUNCH(4, 1, true); }
     else if (unr >= 4) IPPM_K3_LAUNCH(4, 4, false);

@@ -465,7 +465,7 @@ extern "C" int ippm_actor_features(ippm_ctx* ctx, const double* area, const uint
   if (n_envs <= 0) return 0;
   const ippm_config& c = ctx->cfg;
   const size_t tile = ippm_tile_bytes(c.tile_stride, ctx->vec);
-  hipLaunchKernelGGL(k_actor_features, dim3(n_envs * c.n_agents), dim3(K6_THREADS), (tile + 3) / 4 * 4, S_(stream), ctx->dcfg, area,
+  IPPM_LAUNCH_SH(ctx, IPPM_T_ACTOR_FEAT, k_actor_features, dim3(n_envs * c.n_agents), dim3(K6_THREADS), (tile + 3) / 4 * 4, S_(stream), ctx->dcfg, area,
                      code, rect, pos, comm, t, obs);
   IPPM_LAUNCH_CHECK("actor_features");
   return 0;
@@ -476,7 +476,7 @@ extern "C" int ippm_critic_features(ippm_ctx* ctx, const double* area, const int
   if (!ctx || !area || !rect || !pos_pre || !action || !obs || !state) { ippm_set_error("ippm_critic_features: null argument"); return -1; }
   if (int rc = feature_checks(ctx, "ippm_critic_features")) return rc;
   if (n_envs <= 0) return 0;
-  hipLaunchKernelGGL(k_critic_features, dim3(n_envs), dim3(K6_THREADS), 0, S_(stream), ctx->dcfg, area, rect, pos_pre, action, obs, state);
+  IPPM_LAUNCH(ctx, IPPM_T_CRITIC_FEAT, k_critic_features, dim3(n_envs), dim3(K6_THREADS), S_(stream), ctx->dcfg, area, rect, pos_pre, action, obs, state);
   IPPM_LAUNCH_CHECK("critic_features");
   return 0;
 }

@@ -480,10 +480,6 @@ __global__ void k_reward_finalize(const ippm_config* __restrict__ c, double* __r
 // ======================================================================================================
 static inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int grid1(size_t n, int b = 256) { return (int)((n + b - 1) / b); }
-static int env_int(const char* name, int dflt) {  // tuning knob; the default is the measured best on MI355X
-  const char* v = getenv(name);
-  return v && *v ? atoi(v) : dflt;
-}
 
 // Rows per work item; the plan kernel (work list) and the fusion must agree, both derive it from (config, n_envs).
 // Sized so that a step yields roughly three items per wavefront slot of the chip (256 CUs x 4 SIMDs x 4 waves): about half
@@ -491,7 +487,7 @@ static int env_int(const char* name, int dflt) {  // tuning knob; the default is
 // same parallelism with shorter per-wavefront latency chains.
 int ippm_fuse_wave_rows(const ippm_ctx* ctx, int n_envs) {
   const int gx = ctx->cfg.grid_x;
-  const int forced = env_int("IPPM_FUSE_WAVE_ROWS", 0);
+  const int forced = ctx->knob_wave_rows;  // IPPM_FUSE_WAVE_ROWS, read at ippm_ctx_create
   int rows = forced;
   if (rows <= 0) {
     const double est_rows = 0.5 * (double)n_envs * (ctx->cfg.n_agents + 1) * 0.6 * gx;
@@ -516,12 +512,12 @@ static int launch_fuse(ippm_ctx* ctx, float* local, float* global, const uint8_t
   // ... and about three items per wavefront on larger grids / teams (8 UAVs x 512^2 x 1024 envs: 16 / 32 / 64 wavefronts per env
   // -> 1211 / 1173 / 1234 us; 4 UAVs x 1024^2: 16 / 64 -> 1577 / 1477 us)
   const int per_env = ((c.n_agents + 1) * chunks + 2) / 3;
-  const int persist = std::max(64, env_int("IPPM_FUSE_PERSIST", std::max(16384, per_env * n_envs_total)));
+  const int persist = std::max(64, ctx->knob_persist > 0 ? ctx->knob_persist : std::max(16384, per_env * n_envs_total));
   const int pgrid = n_envs_total * std::max(1, std::min(persist / std::max(n_envs_total, 1), (c.n_agents + 1) * chunks));
   dim3 grid(work ? (unsigned)pgrid : (unsigned)units * chunks), block(64);
 #define IPPM_FUSE(V, T, NA, SH, MINOPS)                                                                                  \
-  hipLaunchKernelGGL((k_fuse_rows<V, T, NA, SH>), grid, block, 0, st, ctx->dcfg, local, global, code, ws, ws, sums, area, \
-                     ctx->dcounters, work, wave_rows, chunks, MINOPS, local_units, agent_sel, n_envs_total, ippm_work_env_cap(ctx, n_envs_total))
+  IPPM_LAUNCH(ctx, IPPM_T_FUSE, (k_fuse_rows<V, T, NA, SH>), grid, block, st, ctx->dcfg, local, global, code, ws, ws, sums, area, \
+              ctx->dcounters, work, wave_rows, chunks, MINOPS, local_units, agent_sel, n_envs_total, ippm_work_env_cap(ctx, n_envs_total))
 #define IPPM_FUSE_ALL(V, T)                                  \
   do {                                                       \
     if (c.logit_prior != 0.f) {                              \
@@ -586,10 +582,10 @@ extern "C" int ippm_fuse_global_reward(ippm_ctx* ctx, float* global, const uint8
 extern "C" int ippm_fuse_step(ippm_ctx* ctx, float* local, float* global, const uint8_t* code, int32_t* ws, double* sums,
                               double* area, const int32_t* work, int32_t n_envs, void* stream) {
   if (!ctx || !local || !global || !code || !ws || !sums) { ippm_set_error("ippm_fuse_step: null argument"); return -1; }
-  if (env_int("IPPM_FUSE_SPLIT", 0)) {  // measurement aid: K4 and K5 as two launches, so that a kernel trace shows them apart
+  if (ctx->knob_split) {  // measurement aid: K4 and K5 as two launches, so that a kernel trace shows them apart
     if (int rc = launch_fuse(ctx, local, global, code, ws, sums, area, nullptr, n_envs * ctx->cfg.n_agents, 0, -1, n_envs, S_(stream))) return rc;
     return launch_fuse(ctx, local, global, code, ws, sums, area, nullptr, 0, n_envs, -1, n_envs, S_(stream));
   }
-  return launch_fuse(ctx, local, global, code, ws, sums, area, env_int("IPPM_FUSE_NOWORK", 0) ? nullptr : work,
+  return launch_fuse(ctx, local, global, code, ws, sums, area, ctx->knob_nowork ? nullptr : work,
                      n_envs * ctx->cfg.n_agents, n_envs, -1, n_envs, S_(stream));
 }

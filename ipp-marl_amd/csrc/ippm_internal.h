@@ -1,6 +1,7 @@
 // Internal declarations shared by the HIP translation units of libippmarl.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include <string>
@@ -43,12 +44,33 @@
 #define SUM_ACCD 4
 #define SUM_ACCT 5
 
+#define IPPM_TIMED_CAP 4096   // event pairs per kernel class between two reads; launches beyond it go untimed
 struct ippm_ctx {
   ippm_config cfg;           // host copy
   ippm_config* dcfg;         // device copy
   unsigned long long* dcounters;  // device, IPPM_COUNTER_SLOTS x 8 words (summed into ippm_counters on read)
   int vec;                   // 4 when grid_y % 4 == 0 (aligned float4 path), else 1
+  // tuning knobs, resolved ONCE at ippm_ctx_create (the work buffer's size, the plan kernel's item layout and the fusion launch
+  // all derive from them and must agree for the context's lifetime)
+  int knob_wave_rows, knob_persist, knob_nowork, knob_split;
+  // kernel timing (ippm_kernel_timing): per kernel class a pool of event pairs attached to the dispatches themselves
+  int timing;
+  hipEvent_t* ev[IPPM_TIMED_CLASSES];
+  int ev_made[IPPM_TIMED_CLASSES], ev_used[IPPM_TIMED_CLASSES];
+  const char* ev_name[IPPM_TIMED_CLASSES];
 };
+// start/stop events for the next launch of class `cls` (nullptr, nullptr when timing is off or the pool is exhausted)
+void ippm_timing_events(ippm_ctx* ctx, int cls, const char* name, hipEvent_t* a, hipEvent_t* b);
+// Launch with the kernel's own begin/end timestamps recorded when timing is on: hipExtLaunchKernelGGL binds the two events to
+// the dispatch packet (no extra barrier packets on the stream), which is what rocprofv3's kernel trace reports as its duration.
+#define IPPM_LAUNCH_SH(ctx, cls, kern, grid, block, shmem, st, ...)                             \
+  do {                                                                                          \
+    hipEvent_t _ea = nullptr, _eb = nullptr;                                                    \
+    if ((ctx)->timing) ippm_timing_events((ctx), (cls), #kern, &_ea, &_eb);                     \
+    if (_ea) hipExtLaunchKernelGGL(kern, grid, block, shmem, st, _ea, _eb, 0, __VA_ARGS__);     \
+    else hipLaunchKernelGGL(kern, grid, block, shmem, st, __VA_ARGS__);                         \
+  } while (0)
+#define IPPM_LAUNCH(ctx, cls, kern, grid, block, st, ...) IPPM_LAUNCH_SH(ctx, cls, kern, grid, block, 0, st, __VA_ARGS__)
 
 void ippm_set_error(const std::string& msg);
 // k_plan for local (global_maps == 0) or global fusion plans; step_small.hip

@@ -450,7 +450,7 @@ extern "C" int ippm_plan_step(ippm_ctx* ctx, const int64_t* episode, int32_t* po
       return -1;
     }
   }
-  hipLaunchKernelGGL(k_plan_step, dim3(n_envs), dim3(64), 0, S_(stream), ctx->dcfg, episode, pos, comm_range, draws, comm, rect, ws,
+  IPPM_LAUNCH(ctx, IPPM_T_PLAN, k_plan_step, dim3(n_envs), dim3(64), S_(stream), ctx->dcfg, episode, pos, comm_range, draws, comm, rect, ws,
                      t, flags, probs, action_in, policy, mask, action, fault, rect_next, -1, plans ? work : nullptr,
                      ippm_fuse_wave_rows(ctx, n_envs), ippm_work_env_cap(ctx, n_envs));
   IPPM_LAUNCH_CHECK("plan_step");

@@ -368,7 +368,7 @@ extern "C" int ippm_terrain_pack(ippm_ctx* ctx, const float* field, const uint32
   if (n_envs <= 0) return 0;
   const size_t cells = (size_t)ctx->cfg.grid_x * ctx->cfg.grid_y;
   if (range_keys && cells % 4 == 0 && (reinterpret_cast<uintptr_t>(field) & 15) == 0) {
-    hipLaunchKernelGGL(k_terrain_pack_keys4, dim3((unsigned)((cells / 4 + 255) / 256), n_envs), dim3(256), 0, S_(stream), field,
+    IPPM_LAUNCH(ctx, IPPM_T_TERRAIN, k_terrain_pack_keys4, dim3((unsigned)((cells / 4 + 255) / 256), n_envs), dim3(256), S_(stream), field,
                        range_keys, truth, cells, ippm_truth_bytes(ctx->cfg.grid_x, ctx->cfg.grid_y));
     IPPM_LAUNCH_CHECK("terrain_pack_keys4");
     return 0;
@@ -428,16 +428,16 @@ extern "C" int ippm_terrain_field(ippm_ctx* ctx, const int64_t* episode, const f
   float2* work2 = reinterpret_cast<float2*>(work);
 #define LAUNCH_X(N1, N2, Q)                                                                                                  \
   if (spec)                                                                                                                  \
-    hipLaunchKernelGGL((k_terrain_fft_x<N1, N2, Q, false>), dim3((hy + Q - 1) / Q, n_envs), dim3(FourStep<N1, N2, Q>::THREADS), 0, \
+    IPPM_LAUNCH(ctx, IPPM_T_TERRAIN, (k_terrain_fft_x<N1, N2, Q, false>), dim3((hy + Q - 1) / Q, n_envs), dim3(FourStep<N1, N2, Q>::THREADS), \
                        S_(stream), ctx->dcfg, episode, amp, spec2, work2, range_keys);                                                 \
   else                                                                                                                       \
-    hipLaunchKernelGGL((k_terrain_fft_x<N1, N2, Q, true>), dim3((hy + Q - 1) / Q, n_envs), dim3(FourStep<N1, N2, Q>::THREADS), 0, \
+    IPPM_LAUNCH(ctx, IPPM_T_TERRAIN, (k_terrain_fft_x<N1, N2, Q, true>), dim3((hy + Q - 1) / Q, n_envs), dim3(FourStep<N1, N2, Q>::THREADS), \
                        S_(stream), ctx->dcfg, episode, amp, spec2, work2, range_keys)
   TERRAIN_DISPATCH(gx, LAUNCH_X)
 #undef LAUNCH_X
   IPPM_LAUNCH_CHECK("terrain_fft_x");
 #define LAUNCH_Y(N1, N2, Q)                                                                                                  \
-  hipLaunchKernelGGL((k_terrain_fft_y<N1, N2, Q>), dim3(gx / Q, n_envs), dim3(FourStep<N1, N2, Q>::THREADS), 0, S_(stream),   \
+  IPPM_LAUNCH(ctx, IPPM_T_TERRAIN, (k_terrain_fft_y<N1, N2, Q>), dim3(gx / Q, n_envs), dim3(FourStep<N1, N2, Q>::THREADS), S_(stream),   \
                      ctx->dcfg, (const float2*)work2, field, range_keys)
   TERRAIN_DISPATCH(gy, LAUNCH_Y)
 #undef LAUNCH_Y

@@ -17,6 +17,8 @@ LIB_PATH = os.environ.get("IPPMARL_LIB", os.path.join(_HERE, "..", "lib", "libip
 WS_WORDS = 160
 FEAT, ACTOR_PLANES, CRITIC_PLANES = 11, 7, 12
 STEP_COMM, STEP_GLOBAL, STEP_MOVE = 1, 2, 4   # ippm_plan_step flags
+# kernel classes of ippm_read_kernel_times (IPPM_T_*)
+TIMED = {"sense": 0, "fuse": 1, "plan": 2, "actor_features": 3, "critic_features": 4, "reset": 5, "terrain": 6}
 
 
 class IppmConfig(C.Structure):
@@ -54,6 +56,8 @@ PROTOTYPES = {
     "ippm_ctx_destroy": [P],
     "ippm_sync": [P, P],
     "ippm_read_counters": [P, C.POINTER(IppmCounters), C.c_int, P],
+    "ippm_kernel_timing": [P, I32],
+    "ippm_read_kernel_times": [P, I32, I32, P, P, P, P, I32, P],
     "ippm_reset_episode": [P, P, P, P, P, P, P, P, P, P, P, I32, P],
     "ippm_logodds_to_prob": [P, P, P, I64, P],
     "ippm_prob_to_logodds": [P, P, P, I64, P],
@@ -198,6 +202,23 @@ class Context:
 
     def call(self, name: str, *args):
         check(getattr(self.lib, name)(self.handle, *args), name)
+
+    def kernel_timing(self, enable: bool):
+        """Attach begin/end events to every launch of the timed kernel classes (ippm_kernel_timing)."""
+        self.call("ippm_kernel_timing", 1 if enable else 0)
+
+    def kernel_times(self, stream, reset: bool = True) -> dict:
+        """{class: {"launches", "avg_us", "min_us", "kernel"}} of the launches timed since the last reset (synchronises)."""
+        out = {}
+        for name, cls in TIMED.items():
+            n, tot, mn = C.c_int64(0), C.c_double(0.0), C.c_double(0.0)
+            buf = C.create_string_buffer(128)
+            self.call("ippm_read_kernel_times", cls, 1 if reset else 0, C.addressof(n), C.addressof(tot), C.addressof(mn),
+                      C.addressof(buf), 128, stream)
+            if n.value:
+                out[name] = {"launches": int(n.value), "avg_us": tot.value / n.value, "min_us": mn.value,
+                             "kernel": buf.value.decode()}
+        return out
 
     def counters(self, stream, reset: bool = False) -> dict:
         out = IppmCounters()

@@ -27,25 +27,6 @@ from .derived import DerivedConstants
 POLICY_EXPLICIT, POLICY_UNIFORM, POLICY_SAMPLE, POLICY_ARGMAX = 0, 1, 2, 3
 
 
-class _Bracket:
-    """HIP-event bracket around one kernel launch on the current stream (only while ``env.profile`` is set)."""
-
-    def __init__(self, env, name):
-        self.env, self.name = env, name
-
-    def __enter__(self):
-        if self.env.profile:
-            self.a = torch.cuda.Event(enable_timing=True)
-            self.a.record()
-
-    def __exit__(self, *exc):
-        if self.env.profile:
-            b = torch.cuda.Event(enable_timing=True)
-            b.record()
-            self.env.events.setdefault(self.name, []).append((self.a, b))
-        return False
-
-
 class VecEnv:
     def __init__(self, params: Dict, n_envs: int, device: str = "cuda:0", philox_seed: int = 3, terrain: str = "split",
                  track_area: bool = True):
@@ -91,6 +72,7 @@ class VecEnv:
         self.track_area = bool(track_area)
         self.area = z(E, N + 1, _ffi.FEAT * _ffi.FEAT, dtype=torch.float64)
         self.obs = None
+        self._obs_t = None       # step whose actor observations `obs` holds
         self.state = None
         self.t = 0
         # "split": the half-plane truth the reference flies over (ground_truths.py:42-56); "random_field": the
@@ -100,12 +82,23 @@ class VecEnv:
         self.terrain = terrain
         self._field = None
         self._pending_t = None   # step whose fusion (K4 + K5) build_observations has already launched
-        self.profile = False     # bracket the big kernels with HIP events (bench.py's roofline legs)
+        self._profile = False    # time the kernels with events bound to their dispatches (bench.py's roofline legs)
         self._ep_host = None     # pinned staging buffer of reset()'s episode ids, and the event of its last copy
         self._ep_copied = None
-        self.events: Dict[str, list] = {}
 
     # ------------------------------------------------------------------------------------------------
+    @property
+    def profile(self) -> bool:
+        return self._profile
+
+    @profile.setter
+    def profile(self, on: bool):
+        """While set, every launch of the timed kernel classes (K3, fusion, plan, K6, reset, terrain) carries a HIP event pair
+        bound to the dispatch itself (ippm_kernel_timing): kernel-only durations, no barrier packets on the stream."""
+        if bool(on) != self._profile:
+            self.ctx.kernel_timing(bool(on))
+            self._profile = bool(on)
+
     @property
     def stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -192,16 +185,16 @@ class VecEnv:
             self.pos.copy_(torch.as_tensor(start_positions).to(self.device, torch.int32))
         self.t = 0
         self._pending_t = None
+        self._obs_t = None
         self.sense(stage=0, flips=flips)
 
     def sense(self, stage: int, flips: Optional[torch.Tensor] = None, agent: int = -1, close_step: bool = False):
         """K3 at the current positions (stage 0 = start sensing, t+1 = sensing of step t).  ``close_step``: this is the K3
         that ends a batched step -- it takes the footprints K1 projected (rect_next) and completes the step's reward."""
-        with _Bracket(self, "sense"):
-            self.ctx.call("ippm_sense_step", self._p(self.episode), self._p(self.pos), self._p(self.truth), self._p(self.local),
-                          self._p(flips), self._p(self.code), self._p(self.rect_next) if close_step else None, self._p(self.rect),
-                          self._p(self.ws), self._area_arg, self._p(self.sums) if close_step else None,
-                          self._p(self.reward) if close_step else None, stage, agent, self.E, self.stream)
+        self.ctx.call("ippm_sense_step", self._p(self.episode), self._p(self.pos), self._p(self.truth), self._p(self.local),
+                      self._p(flips), self._p(self.code), self._p(self.rect_next) if close_step else None, self._p(self.rect),
+                      self._p(self.ws), self._area_arg, self._p(self.sums) if close_step else None,
+                      self._p(self.reward) if close_step else None, stage, agent, self.E, self.stream)
 
     def comm_matrix(self, t: int, comm_draws: Optional[torch.Tensor] = None):
         self.ctx.call("ippm_comm_matrix", self._p(self.episode), self._p(self.pos), self._p(self.comm_range),
@@ -219,9 +212,8 @@ class VecEnv:
                       self.stream)
 
     def _fuse_step(self):
-        with _Bracket(self, "fuse"):
-            self.ctx.call("ippm_fuse_step", self._p(self.local), self._p(self.glob), self._p(self.code), self._p(self.ws),
-                          self._p(self.sums), self._area_arg, self._p(self.work), self.E, self.stream)
+        self.ctx.call("ippm_fuse_step", self._p(self.local), self._p(self.glob), self._p(self.code), self._p(self.ws),
+                      self._p(self.sums), self._area_arg, self._p(self.work), self.E, self.stream)
 
     def _actor_features(self, t: int):
         if self.obs is None:
@@ -229,9 +221,9 @@ class VecEnv:
                                    device=self.device)
         if not self.track_area:
             self.rebuild_area(local=True, glob=False)
-        with _Bracket(self, "actor_features"):
-            self.ctx.call("ippm_actor_features", self._p(self.area), self._p(self.code), self._p(self.rect), self._p(self.pos),
-                          self._p(self.comm), t, self._p(self.obs), self.E, self.stream)
+        self.ctx.call("ippm_actor_features", self._p(self.area), self._p(self.code), self._p(self.rect), self._p(self.pos),
+                      self._p(self.comm), t, self._p(self.obs), self.E, self.stream)
+        self._obs_t = t
         return self.obs
 
     def build_observations(self, t: int, comm_draws: Optional[torch.Tensor] = None, features: bool = True):
@@ -276,17 +268,17 @@ class VecEnv:
         self._pending_t = None
         state = None
         if features:
-            if self.obs is None:
-                raise _ffi.IppmError("steps(features=True) needs build_observations(features=True) first")
+            if self.obs is None or self._obs_t != t:   # the critic state embeds this step's actor observations
+                raise _ffi.IppmError(f"steps({t}, features=True) needs build_observations({t}, features=True) first "
+                                     f"(observations held: step {self._obs_t})")
             if self.state is None:
                 self.state = torch.empty(self.E, d.n_agents, _ffi.FEAT, _ffi.FEAT, _ffi.CRITIC_PLANES, dtype=torch.float32,
                                          device=self.device)
             if not self.track_area:
                 self.rebuild_area(local=False, glob=True)
             # rect still holds the pre-move (published) footprints: K3 below overwrites it
-            with _Bracket(self, "critic_features"):
-                self.ctx.call("ippm_critic_features", self._p(self.area), self._p(self.rect), self._p(self.pos_pre),
-                              self._p(self.action), self._p(self.obs), self._p(self.state), self.E, self.stream)
+            self.ctx.call("ippm_critic_features", self._p(self.area), self._p(self.rect), self._p(self.pos_pre),
+                          self._p(self.action), self._p(self.obs), self._p(self.state), self.E, self.stream)
             state = self.state
         self.sense(stage=t + 1, flips=flips, close_step=True)
         self.t = t + 1
@@ -341,13 +333,9 @@ class VecEnv:
 
     # ------------------------------------------------------------------------------------------------
     def event_times_us(self, clear: bool = True) -> Dict[str, Dict[str, float]]:
-        """{kernel: {"launches", "avg_us"}} of the brackets recorded while ``profile`` was set (synchronises)."""
-        torch.cuda.synchronize(self.device)
-        out = {k: {"launches": len(v), "avg_us": 1e3 * sum(a.elapsed_time(b) for a, b in v) / max(len(v), 1)}
-               for k, v in self.events.items()}
-        if clear:
-            self.events = {}
-        return out
+        """{kernel class: {"launches", "avg_us", "min_us", "kernel"}} of the launches made while ``profile`` was set
+        (synchronises the stream)."""
+        return self.ctx.kernel_times(self.stream, reset=clear)
 
     def counters(self, reset: bool = False) -> dict:
         return self.ctx.counters(self.stream, reset)

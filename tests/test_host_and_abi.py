@@ -92,9 +92,25 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/ippmarl.h but not exported"
     bound = set(_ffi.PROTOTYPES) | {"ippm_last_error", "ippm_version", "ippm_config_size"}
     assert declared == bound, f"binding and header disagree: {declared ^ bound}"
-    assert lib.ippm_version() == 200
+    assert lib.ippm_version() == 300
     import ctypes
     assert lib.ippm_config_size() == ctypes.sizeof(_ffi.IppmConfig)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` outside a launcher (the driver's command shape) starts N ranks itself: here 2 ranks over gloo
+    that rendezvous on a free local port, all-reduce their rank ids and stop before any GPU work."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only", "--dist-backend", "gloo"],
+                         capture_output=True, text=True, timeout=240, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout    # only rank 0 speaks
+    rec = json.loads(lines[0])
+    assert rec["ranks"] == 2 and rec["n_gpus"] == 2 and rec["rank_id_sum"] == 1 and rec["backend"] == "gloo"
 
 
 def test_missing_library_fails_loudly(monkeypatch):
