@@ -66,6 +66,7 @@ extern "C" {
 #define IPPM_STEP_COMM 1   /* comm matrix + local-fusion plans */
 #define IPPM_STEP_GLOBAL 2 /* global-fusion plan */
 #define IPPM_STEP_MOVE 4   /* K1 mask/act/move (+ footprints of the new positions) */
+#define IPPM_STEP_TILES 8  /* write the work list as one-trip tile items (for ippm_fuse_step WITHOUT area sums) */
 
 /* Derived constants, computed on the host in float64 with the reference's expression order
  * (ippmarl/derived.py) and handed over as plain integers/floats. */
@@ -111,7 +112,8 @@ typedef struct ippm_counters {
   uint64_t fuse_global_cells;  /* K5: cells read+written by global fusion */
   uint64_t fuse_global_ops;
   uint64_t feature_cells;      /* K6: map cells streamed by the feature builders */
-  uint64_t reserved[2];
+  uint64_t reserved[2];        /* [0]: fusion launches that were handed a work list of the other form and skipped it (0 in a
+                                  correct call sequence) */
 } ippm_counters;
 
 const char* ippm_last_error(void);
@@ -222,8 +224,12 @@ int ippm_fuse_global_reward(ippm_ctx* ctx, float* global, const uint8_t* code, c
  *                     Only policies that do not depend on this step's observations (0 explicit, 1 uniform) can share a call
  *                     with COMM/GLOBAL; a learned policy calls MOVE separately after the actor.
  *   work (optional, int32 [ippm_work_words()]): with COMM | GLOBAL the kernel also lists the non-empty work items of the
- *   step's fusion (map, run of rows) for ippm_fuse_step, every env into its own slice (count + items: written, never
- *   accumulated, so there is nothing to clear between steps).
+ *   step's fusion for ippm_fuse_step, every env into its own slice (count + items: written, never accumulated, so there is
+ *   nothing to clear between steps).  Two forms: runs of rows of a plan's hull (map, run) -- consumed by ippm_fuse_step WITH
+ *   area sums -- and, with IPPM_STEP_TILES, self-contained one-trip tile items (rows x column interval x op mask, each at most
+ *   1024 cells) -- consumed by ippm_fuse_step WITHOUT area sums (the env-only step).  The flag must match the ippm_fuse_step
+ *   call that follows; a mismatch fuses nothing and is counted in ippm_counters.reserved[0].  Configs without the tile form
+ *   (grids not a multiple of 4 wide, mapping.prior != 0.5) ignore the flag on both sides.
  * ippm_fuse_step: K4 for all local maps and K5 for all global maps from the plans above, in one launch; keeps `area`
  *   (optional) up to date; leaves the reward sums open (ippm_sense_step or ippm_reward_finalize completes them).  With the
  *   `work` list of the same step's ippm_plan_step a fixed number of resident wavefronts strides over exactly the non-empty

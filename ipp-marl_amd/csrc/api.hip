@@ -89,6 +89,9 @@ extern "C" int ippm_ctx_create(const ippm_config* cfg, ippm_ctx** out) {
   ctx->knob_persist = knob("IPPM_FUSE_PERSIST", 0);
   ctx->knob_nowork = knob("IPPM_FUSE_NOWORK", 0);
   ctx->knob_split = knob("IPPM_FUSE_SPLIT", 0);
+  ctx->knob_tile_waves = knob("IPPM_TILE_WAVES", 0);
+  ctx->knob_plan_builders = knob("IPPM_PLAN_BUILDERS", 0);
+  ctx->tiles = (ctx->vec == 4 && c.logit_prior == 0.f && c.grid_x < 32768 && c.grid_y <= 1024 && !knob("IPPM_NO_TILES", 0)) ? 1 : 0;
   int rc = ippm_check_hip(hipMalloc(&ctx->dcfg, sizeof(ippm_config)), "hipMalloc(cfg)");
   if (!rc) rc = ippm_check_hip(hipMemcpy(ctx->dcfg, cfg, sizeof(ippm_config), hipMemcpyHostToDevice), "hipMemcpy(cfg)");
   if (!rc) rc = ippm_check_hip(hipMalloc(&ctx->dcounters, IPPM_COUNTER_SLOTS * 8 * sizeof(unsigned long long)), "hipMalloc(counters)");
@@ -188,3 +191,12 @@ extern "C" int ippm_read_counters(ippm_ctx* ctx, ippm_counters* out, int reset, 
   if (reset) IPPM_HIP(hipMemset(ctx->dcounters, 0, sizeof(raw)));
   return 0;
 }
+
+#ifdef IPPM_PLAN_STAMPS
+// variant builds only: the raw counter slots (word 7 of each slot holds a phase stamp of k_plan_step's env 0)
+extern "C" int ippm_debug_raw_counters(ippm_ctx* ctx, unsigned long long* out512) {
+  IPPM_HIP(hipDeviceSynchronize());
+  IPPM_HIP(hipMemcpy(out512, ctx->dcounters, IPPM_COUNTER_SLOTS * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return 0;
+}
+#endif

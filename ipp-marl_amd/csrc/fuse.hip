@@ -447,7 +447,7 @@ k_fuse_rows(const ippm_config* __restrict__ c, float* __restrict__ local, float*
   const int n = c->n_agents;
   if (work) {  // gridDim.x is a multiple of the env count: wavefront b serves env b % E, taking every (gridDim.x / E)-th item
     const int env = blockIdx.x % n_envs_total;
-    const int count = work[env];
+    const int count = (work[env] & IPPM_WORK_TILED) ? 0 : work[env];  // a list in the tile form is fuse_tiles.hip's
     const int32_t* items = work + n_envs_total + (size_t)env * env_cap;
     const int step = gridDim.x / n_envs_total;
     for (int i = blockIdx.x / n_envs_total; i < count; i += step) {
@@ -582,6 +582,9 @@ extern "C" int ippm_fuse_global_reward(ippm_ctx* ctx, float* global, const uint8
 extern "C" int ippm_fuse_step(ippm_ctx* ctx, float* local, float* global, const uint8_t* code, int32_t* ws, double* sums,
                               double* area, const int32_t* work, int32_t n_envs, void* stream) {
   if (!ctx || !local || !global || !code || !ws || !sums) { ippm_set_error("ippm_fuse_step: null argument"); return -1; }
+  // without area sums the work list may be in the one-trip tile form (ippm_plan_step with IPPM_STEP_TILES): fuse_tiles.hip
+  if (!area && work && ctx->tiles && !ctx->knob_nowork && !ctx->knob_split)
+    return ippm_launch_fuse_tiles(ctx, local, global, code, ws, sums, work, n_envs, S_(stream));
   if (ctx->knob_split) {  // measurement aid: K4 and K5 as two launches, so that a kernel trace shows them apart
     if (int rc = launch_fuse(ctx, local, global, code, ws, sums, area, nullptr, n_envs * ctx->cfg.n_agents, 0, -1, n_envs, S_(stream))) return rc;
     return launch_fuse(ctx, local, global, code, ws, sums, area, nullptr, 0, n_envs, -1, n_envs, S_(stream));

@@ -1,0 +1,305 @@
+// K4 / K5, one-trip tile form (gfx950): the fusion of ippm_fuse_step when no area sums are tracked -- the form the env-only
+// step and bench.py run.
+//
+//   Mapping.fuse_map(..., "local" / "global")   mapping/mappings.py:80-124
+//   get_global_reward terms (K5)                 utils/reward.py:68-82, utils/state.py:53-121
+//
+// The row walker (fuse.hip) gives every wavefront a run of rows of a plan's hull: per item a work-list entry, then the plan,
+// then the rows two at a time -- about ten dependent memory round trips with two 16-byte loads in flight per lane, and the
+// kernel runs at the speed of those chains (rounds x latency), not of the memory system.  Here the plan kernel
+// (step_small.hip, tile_build_map) hands out self-contained ITEMS: a block of rows of one (slab, column interval) of a plan,
+// at most 64 * slots lane-loads, with the mask of the ops that meet it.  A wavefront does an item in three trips, the first
+// and the last short:
+//   1. the item (16 bytes, scalar; the next item is requested while this one is worked on);
+//   2. the op records of the mask TOGETHER WITH every map cell of the item: the cells' addresses follow from the item alone
+//      -- lane-load t = slot * 64 + lane is row t / W, group t % W of the item, so the lanes are dense whatever the interval's
+//      width (a 90-cell footprint: 23 groups x 11 rows = 253 of 256 lane-loads);
+//   3. the measurement-code bytes of every (slot, op), whose addresses need the op records (a small, cache-resident plane);
+// then the ordered clamp/add chain in registers and one store per slot.  Nothing is carried from item to item except the
+// wavefront's reward and counter sums, so register use is that of one item and the launch is many short independent chains.
+#include <algorithm>
+
+#include "ippm_tiles.h"
+
+typedef unsigned ippm_t_u4 __attribute__((ext_vector_type(4)));
+#define IPPM_T_RSRC(ptr, bytes) __builtin_amdgcn_make_buffer_rsrc((void*)(ptr), 0, (int)(bytes), 0x00020000)
+#define IPPM_T_OOB 0x7FFFFFF0
+#define IPPM_T_FAR (-(1 << 20))   // column of a lane-load past the item's end: no op covers it
+
+__device__ __forceinline__ int t_lane_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ float t_lane_f(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+
+struct TileCtx {
+  float* local;
+  float* global;
+  const uint8_t* code;
+  const int32_t* plan;     // ws, read side
+  int32_t* ws;
+  int n, gx, gy, row_bytes, TB, n_envs;
+  float lc, wt;
+  int lane;
+};
+
+struct TileAcc {   // per wavefront, over all its items (all of one env)
+  float a1, aD;    // sum w(a) (H(b) - H(a)) and sum (w(a) - w(b)) H(b); the increment of T = sum w H is aD - a1
+  unsigned cells_l, ops_l, cells_g, ops_g;
+};
+
+// One item with at most NA ops (spare slots first) and SLOTS loads in flight per lane.
+template <int NA, int SLOTS>
+__device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e, int slot, int x0, int nr, int g0, int W, unsigned active) {
+  const int map_abs = e * (w.n + 1) + slot;
+  const bool is_global = slot == w.n;
+  const int32_t* plan = w.plan + (size_t)map_abs * IPPM_WS_WORDS;
+  const int last_op = plan[WS_PLAN + PL_LAST];
+  const __amdgpu_buffer_rsrc_t rmap =
+      IPPM_T_RSRC(is_global ? w.global + (size_t)e * w.gx * w.gy : w.local + (size_t)(e * w.n + slot) * w.gx * w.gy, (size_t)w.gx * w.gy * 4);
+  const __amdgpu_buffer_rsrc_t rcode = IPPM_T_RSRC(w.code, (size_t)w.n_envs * w.n * w.TB);
+  // ---- trip 2a: the op records of the mask.  Spare slots come FIRST: an empty slot still clips, like every op of the reference
+  // -- a no-op ahead of the first real op, but behind the last it would clip that op's unclamped outputs.
+  // Small plans: uniform addresses, scalar loads, the fields stay in SGPRs.  Larger ones: lane o fetches op o, fields by readlane.
+  constexpr bool SCALAR_OPS = NA <= 6;
+  const int pad = NA - __popc(active);
+  int s_yu[SCALAR_OPS ? NA : 1], s_yd[SCALAR_OPS ? NA : 1], cs[NA];
+  float s_lm0[SCALAR_OPS ? NA : 1], s_lm1[SCALAR_OPS ? NA : 1];
+  int v_yu = 0, v_yd = 0, v_cs = 0;
+  float v_lm0 = 0.f, v_lm1 = 0.f;
+  int keep_slot = -1;
+  int4 va = make_int4(0, 0, 0, 0), vb = make_int4(0, 0, 0, 0);
+  if constexpr (SCALAR_OPS) {
+    unsigned rem = active;
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+      if (k < pad) { s_yu[k] = 0; s_yd[k] = 0; cs[k] = 0; s_lm0[k] = 0.f; s_lm1[k] = 0.f; continue; }
+      const int idx = __ffs(rem) - 1;
+      rem &= rem - 1u;
+      const int4 a = *reinterpret_cast<const int4*>(plan + WS_OPS + idx * OP_WORDS);       // {type, src, lm0, yu}
+      const int4 b = *reinterpret_cast<const int4*>(plan + WS_OPS + idx * OP_WORDS + 4);   // {yd, xl, xr, lm1}
+      const bool isf = a.x != 0;
+      s_yu[k] = a.w; s_yd[k] = b.x;
+      s_lm0[k] = isf ? __int_as_float(a.z) : 0.f;
+      s_lm1[k] = isf ? __int_as_float(b.w) : 0.f;
+      // byte of group (row, g) in the source's code tile = (row * row_bytes + g) + cs; a clamp-only op reads some byte of the
+      // plane and adds 0 either way
+      cs[k] = isf ? (e * w.n + a.y) * w.TB - b.y * w.row_bytes - (a.w >> 2) : 0;
+      keep_slot = idx == last_op ? k : keep_slot;
+    }
+  } else {
+    const int o = min(w.lane, IPPM_MAX_OPS - 1);
+    va = *reinterpret_cast<const int4*>(plan + WS_OPS + o * OP_WORDS);
+    vb = *reinterpret_cast<const int4*>(plan + WS_OPS + o * OP_WORDS + 4);
+  }
+  // ---- trip 2b: every map cell of the item.  Lane-load t = q * 64 + lane -> (row t / W, group t % W); t < 256, W <= 256:
+  // floor(t / W) = (t * (floor(65536 / W) + 1)) >> 16 exactly.
+  const unsigned inv = (unsigned)(65536.0f * __builtin_amdgcn_rcpf((float)W)) + 1u;
+  CellVec<4> mv[SLOTS];
+  int off[SLOTS], coff[SLOTS], ycol[SLOTS];
+#pragma unroll
+  for (int q = 0; q < SLOTS; ++q) {
+    const unsigned t = (unsigned)(q * 64 + w.lane);
+    const int r = (int)((t * inv) >> 16);
+    const int gi = (int)t - r * W;
+    const bool valid = r < nr;
+    const int row = x0 + r, g = g0 + gi;
+    off[q] = valid ? (row * w.gy + g * 4) * 4 : IPPM_T_OOB;
+    coff[q] = row * w.row_bytes + g;
+    ycol[q] = valid ? g * 4 : IPPM_T_FAR;
+    const ippm_t_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rmap, off[q], 0, 0);
+    mv[q].v[0] = __uint_as_float(v.x); mv[q].v[1] = __uint_as_float(v.y); mv[q].v[2] = __uint_as_float(v.z); mv[q].v[3] = __uint_as_float(v.w);
+  }
+  if constexpr (!SCALAR_OPS) {
+    const bool on = w.lane < IPPM_MAX_OPS && ((active >> w.lane) & 1u);
+    const bool isf = on && va.x != 0;
+    v_yu = on ? va.w : 0; v_yd = on ? vb.x : 0;
+    v_lm0 = isf ? __int_as_float(va.z) : 0.f;
+    v_lm1 = isf ? __int_as_float(vb.w) : 0.f;
+    v_cs = isf ? (e * w.n + va.y) * w.TB - vb.y * w.row_bytes - (va.w >> 2) : 0;
+    unsigned rem = active;
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+      if (k < pad) { cs[k] = 0; continue; }
+      const int idx = __ffs(rem) - 1;
+      rem &= rem - 1u;
+      cs[k] = t_lane_i(v_cs, idx);
+      keep_slot = idx == last_op ? k : keep_slot;
+    }
+  }
+  // ---- trip 3: one measurement-code byte per (slot, op)
+  uint32_t cw[SLOTS][NA];
+#pragma unroll
+  for (int q = 0; q < SLOTS; ++q)
+#pragma unroll
+    for (int k = 0; k < NA; ++k) cw[q][k] = __builtin_amdgcn_raw_buffer_load_b8(rcode, coff[q] + cs[k], 0, 0);
+  // ---- the ordered clamp/add chain (mappings.py:80-124 in log-odds): every op clips its input over the whole grid
+  // (mappings.py:110-111), then adds the measurement's log-odds inside its footprint; the outputs of the plan's last op stay
+  // unclamped (its rectangle is remembered as possibly out of range), every other cell was clipped again by a later op.
+  float amax = 0.f;
+  unsigned cells = 0, opcells = 0;
+#pragma unroll
+  for (int q = 0; q < SLOTS; ++q) {
+    float L[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) L[j] = mv[q].v[j];
+    unsigned touched = 0, keepm = 0;
+    unsigned rem = active;
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+      int yu, yd;
+      float lm0, lm1;
+      if constexpr (SCALAR_OPS) { yu = s_yu[k]; yd = s_yd[k]; lm0 = s_lm0[k]; lm1 = s_lm1[k]; }
+      else {
+        if (k < pad) { yu = 0; yd = 0; lm0 = 0.f; lm1 = 0.f; }
+        else {
+          const int idx = __ffs(rem) - 1;
+          rem &= rem - 1u;
+          yu = t_lane_i(v_yu, idx); yd = t_lane_i(v_yd, idx); lm0 = t_lane_f(v_lm0, idx); lm1 = t_lane_f(v_lm1, idx);
+        }
+      }
+      // cells y .. y+3 of my group inside [yu, yd): bits [lo, hi)
+      const int lo = min(max(yu - ycol[q], 0), 4), hi = min(max(yd - ycol[q], 0), 4);
+      const unsigned cm = ((1u << (hi - lo)) - 1u) << lo;
+      touched |= cm;
+      keepm = k == keep_slot ? cm : keepm;
+      opcells += (lm0 != 0.f || lm1 != 0.f) ? __popc(cm) : 0;
+      const uint32_t cwk = cw[q][k];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float lm = ippm_masked(ippm_bitmask(cm, j), ippm_blend(ippm_bitmask(cwk, j), lm1, lm0));
+        L[j] = ippm_clampl(L[j], w.lc) + lm;
+      }
+    }
+    cells += __popc(touched);
+    float out[4];
+    if (keep_slot >= 0) {   // (uniform) the item meets the plan's last op: its cells keep their unclamped outputs
+#pragma unroll
+      for (int j = 0; j < 4; ++j) out[j] = ippm_blend(ippm_bitmask(keepm, j), L[j], ippm_clampl(L[j], w.lc));
+      amax = fmaxf(amax, fmaxf(fmaxf(fabsf(out[0]), fabsf(out[1])), fmaxf(fabsf(out[2]), fabsf(out[3]))));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) out[j] = ippm_clampl(L[j], w.lc);   // |out| <= lc: nothing to remember
+    }
+    {
+      ippm_t_u4 v;
+      v.x = __float_as_uint(out[0]); v.y = __float_as_uint(out[1]); v.z = __float_as_uint(out[2]); v.w = __float_as_uint(out[3]);
+      // a lane-load past the item's end was never in range; a group no op touches cannot occur inside an interval
+      __builtin_amdgcn_raw_buffer_store_b128(v, rmap, off[q], 0, 0);
+    }
+    if (is_global) {
+      // information-gain terms (utils/reward.py:68-82) of the cells the step changed; an untouched cell contributes exact zeros
+      // (same weight, same entropy).  Slots whose touched cells all have weight 0 before and after (believed free, still
+      // believed free) skip the entropies: wave-uniform on spatially coherent terrain.
+      float wa[4], wb[4], wsum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t tm = ippm_bitmask(touched, j);
+        wa[j] = ippm_masked(tm, ippm_weight_l(out[j], w.wt));
+        wb[j] = ippm_masked(tm, ippm_weight_l(mv[q].v[j], w.wt));
+        wsum += wa[j] + wb[j];
+      }
+      if (__any(wsum != 0.f)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float hb = ippm_entropy_l(mv[q].v[j], w.lc), ha = ippm_entropy_l(out[j], w.lc);
+          acc.a1 += wa[j] * (hb - ha);
+          acc.aD += (wa[j] - wb[j]) * hb;
+        }
+      }
+    }
+  }
+  if (__any(amax > w.lc) && w.lane == 0) w.ws[(size_t)map_abs * IPPM_WS_WORDS + WS_FLAG_A] = 1;
+  if (is_global) { acc.cells_g += cells; acc.ops_g += opcells; }
+  else { acc.cells_l += cells; acc.ops_l += opcells; }
+}
+
+// Workgroup = one wavefront; gridDim.x is a multiple of the env count: wavefront b serves env b % E and takes every
+// (gridDim.x / E)-th item of the env's list.
+#ifndef IPPM_TILE_WAVES_PER_EU
+#define IPPM_TILE_WAVES_PER_EU 5
+#endif
+template <int NAMAX>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(IPPM_TILE_WAVES_PER_EU, 8)))
+k_fuse_tiles(const ippm_config* __restrict__ c, float* __restrict__ local, float* __restrict__ global,
+             const uint8_t* __restrict__ code, const int32_t* __restrict__ plan_ro, int32_t* __restrict__ ws,
+             double* __restrict__ sums, unsigned long long* __restrict__ counters, const int32_t* __restrict__ work,
+             int n_envs, int env_cap) {
+  const int env = blockIdx.x, first = blockIdx.y, step = gridDim.y;   // consecutive workgroups = consecutive envs
+  const int4* __restrict__ items = reinterpret_cast<const int4*>(work + ((n_envs + 3) & ~3)) + (size_t)env * env_cap;
+  // count and first item are requested together (the item's address does not depend on the count)
+  const int tag = work[env];
+  int4 it = items[min(first, env_cap - 1)];
+  const int lane = threadIdx.x;
+  if (!(tag & IPPM_WORK_TILED) || (tag & IPPM_WORK_OVERFLOW)) {  // a list of the other form, or one that did not fit: say so
+    if (first == 0 && lane == 0 && counters) atomicAdd(&counters[(env & (IPPM_COUNTER_SLOTS - 1)) * 8 + 6], 1ull);
+    return;
+  }
+  const int count = tag & IPPM_WORK_COUNT;
+  if (first >= count) return;
+  TileCtx w;
+  w.local = local; w.global = global; w.code = code; w.plan = plan_ro; w.ws = ws;
+  w.n = c->n_agents; w.gx = c->grid_x; w.gy = c->grid_y;
+  w.row_bytes = c->tile_stride >> 2;
+  w.TB = (int)ippm_tile_bytes(c->tile_stride, 4);
+  w.n_envs = n_envs;
+  w.lc = c->logit_clip; w.wt = c->logit_weight_thr;
+  w.lane = lane;
+  TileAcc acc;
+  acc.a1 = acc.aD = 0.f;
+  acc.cells_l = acc.ops_l = acc.cells_g = acc.ops_g = 0;
+  for (int i = first; i < count; i += step) {
+    const int4 nx = items[min(i + step, env_cap - 1)];  // the next item travels while this one is worked on
+    const int slot = (unsigned)it.w >> 24, x0 = it.y & 0xFFFF, nr = it.y >> 16, g0 = it.z & 0xFFFF, W = it.z >> 16;
+    const unsigned active = (unsigned)it.w & 0x00FFFFFFu;
+    const int na = __popc(active);
+    if (na == 1) tile_item<1, 4>(w, acc, env, slot, x0, nr, g0, W, active);
+    else if (na == 2) tile_item<2, 4>(w, acc, env, slot, x0, nr, g0, W, active);
+    else if (na == 3) tile_item<3, 4>(w, acc, env, slot, x0, nr, g0, W, active);
+    else if (na == 4) tile_item<4, 4>(w, acc, env, slot, x0, nr, g0, W, active);
+    else if (NAMAX <= 6 || na <= 6) tile_item<(NAMAX < 6 ? NAMAX : 6), 2>(w, acc, env, slot, x0, nr, g0, W, active);
+    else if (na <= 8) tile_item<8, 2>(w, acc, env, slot, x0, nr, g0, W, active);
+    else if (NAMAX <= 10 || na <= 10) tile_item<10, 2>(w, acc, env, slot, x0, nr, g0, W, active);
+    else if (na <= 14) tile_item<14, 1>(w, acc, env, slot, x0, nr, g0, W, active);
+    else tile_item<18, 1>(w, acc, env, slot, x0, nr, g0, W, active);
+    it = nx;
+  }
+  // the wavefront's reward terms and work counters: one atomic per quantity
+  const float cl = ippm_wave_sum((float)acc.cells_l), ol = ippm_wave_sum((float)acc.ops_l);
+  const float cg = ippm_wave_sum((float)acc.cells_g), og = ippm_wave_sum((float)acc.ops_g);
+  double a1 = (double)acc.a1, aD = (double)acc.aD;   // the 64 lane sums are added up in float64
+  if (cg > 0.f) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a1 += __shfl_xor(a1, o, 64); aD += __shfl_xor(aD, o, 64); }
+  }
+  if (lane < 3) {
+    // sum (w(a) H(a) - w(b) H(b)) = sum (w(a) - w(b)) H(b) - sum w(a) (H(b) - H(a))
+    const double v = lane == 0 ? a1 : (lane == 1 ? aD : aD - a1);
+    if (cg > 0.f && sums && v != 0.0) atomicAdd(&sums[(size_t)env * 8 + SUM_ACC1 + lane], v);
+  } else if (lane < 7 && counters) {
+    const float v = lane == 3 ? cl : (lane == 4 ? ol : (lane == 5 ? cg : og));
+    if (v > 0.f) atomicAdd(&counters[((env + first) & (IPPM_COUNTER_SLOTS - 1)) * 8 + 1 + (lane - 3)], (unsigned long long)v);
+  }
+}
+
+// ippm_fuse_step without area sums on a config that has the tile form (ippm_ctx::tiles); `work` must have been written by
+// ippm_plan_step with IPPM_STEP_TILES.
+int ippm_launch_fuse_tiles(ippm_ctx* ctx, float* local, float* global, const uint8_t* code, int32_t* ws, double* sums,
+                           const int32_t* work, int n_envs, hipStream_t st) {
+  const ippm_config& c = ctx->cfg;
+  const int max_ops = c.n_agents + 1;
+  const int env_cap = ippm_tile_env_cap(ctx);
+  // wavefronts per env: about three items each.  An item is <= 256 lane-loads (1024 cells); a step touches roughly half of the
+  // maps over a third of their cells.
+  const double est_items = 0.5 * (c.n_agents + 1) * (double)c.grid_x * c.grid_y / 3.0 / (256.0 * ippm_tile_slots(max_ops));
+  int per_env = ctx->knob_tile_waves > 0 ? ctx->knob_tile_waves : (int)std::max(4.0, std::min(256.0, est_items / 3.0));
+  per_env = std::max(1, std::min(per_env, env_cap));
+  // a launch smaller than the chip's wave slots leaves CUs idle: small batches take more wavefronts per env
+  while ((long long)per_env * n_envs < 16384 && per_env * 2 <= env_cap && per_env < 256) per_env *= 2;
+  dim3 grid((unsigned)n_envs, (unsigned)per_env), block(64);
+  if (max_ops <= 6)
+    IPPM_LAUNCH(ctx, IPPM_T_FUSE, (k_fuse_tiles<6>), grid, block, st, ctx->dcfg, local, global, code, ws, ws, sums, ctx->dcounters, work, n_envs, env_cap);
+  else if (max_ops <= 10)
+    IPPM_LAUNCH(ctx, IPPM_T_FUSE, (k_fuse_tiles<10>), grid, block, st, ctx->dcfg, local, global, code, ws, ws, sums, ctx->dcounters, work, n_envs, env_cap);
+  else
+    IPPM_LAUNCH(ctx, IPPM_T_FUSE, (k_fuse_tiles<18>), grid, block, st, ctx->dcfg, local, global, code, ws, ws, sums, ctx->dcounters, work, n_envs, env_cap);
+  IPPM_LAUNCH_CHECK("fuse_tiles");
+  return 0;
+}

@@ -52,7 +52,8 @@ struct ippm_ctx {
   int vec;                   // 4 when grid_y % 4 == 0 (aligned float4 path), else 1
   // tuning knobs, resolved ONCE at ippm_ctx_create (the work buffer's size, the plan kernel's item layout and the fusion launch
   // all derive from them and must agree for the context's lifetime)
-  int knob_wave_rows, knob_persist, knob_nowork, knob_split;
+  int knob_wave_rows, knob_persist, knob_nowork, knob_split, knob_tile_waves, knob_plan_builders;
+  int tiles;                 // the config can take the one-trip tile form of the fusion (16-byte lane groups, prior 0.5)
   // kernel timing (ippm_kernel_timing): per kernel class a pool of event pairs attached to the dispatches themselves
   int timing;
   hipEvent_t* ev[IPPM_TIMED_CLASSES];
@@ -79,6 +80,16 @@ void ippm_set_error(const std::string& msg);
 // nothing to clear between steps), the fusion's resident wavefronts b serve env b % E.
 int ippm_fuse_wave_rows(const ippm_ctx* ctx, int n_envs);  // rows per work item (fuse.hip)
 int ippm_work_env_cap(const ippm_ctx* ctx, int n_envs);    // items an env's slice can hold
+// The tile form of the list (IPPM_STEP_TILES; fuse_tiles.hip): [E] counts tagged IPPM_WORK_TILED, then from word (E + 3) & ~3 on
+// [E][cap] items of 4 words {env, x0 | rows << 16, first group | groups << 16, op mask | map slot << 24}, cap = ippm_tile_env_cap().
+int ippm_tile_env_cap(const ippm_ctx* ctx);
+int ippm_launch_fuse_tiles(ippm_ctx* ctx, float* local, float* global, const uint8_t* code, int32_t* ws, double* sums,
+                           const int32_t* work, int n_envs, hipStream_t st);   // fuse_tiles.hip
+#define IPPM_WORK_TILED 0x40000000     // tag of a count written in the tile form (a kernel of the other form skips the list)
+#define IPPM_WORK_OVERFLOW 0x20000000  // the env's items did not fit (never, by the bound of ippm_tile_env_cap)
+#define IPPM_WORK_COUNT 0x0FFFFFFF
+// loads in flight per lane of a tile item, by the number of ops that meet it (the code bytes of every op are in flight too)
+__host__ __device__ inline int ippm_tile_slots(int na) { return na <= 4 ? 4 : (na <= 10 ? 2 : 1); }
 int ippm_launch_plan(ippm_ctx* ctx, const int32_t* rect, const int32_t* pos, const uint8_t* comm, int32_t* ws, int global_maps,
                      int n_envs, int agent_sel, hipStream_t st);
 int ippm_check_hip(hipError_t err, const char* what);

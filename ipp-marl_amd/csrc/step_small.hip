@@ -4,6 +4,8 @@
 // step (plan(global), comm+plan(local), K1, reward finalize, each 5-18 us with 4-11 us gaps).  Here one wavefront per env
 // does all of it in ONE launch (k_plan_step): lanes = agents for the comm rows and the plans, lanes = actions for the
 // mask work of K1, the agent loop of K1 stays serial (agent i is masked against the already-moved j < i).
+#include <algorithm>
+
 #include "ippm_internal.h"
 
 // ======================================================================================================
@@ -60,8 +62,9 @@ __global__ void k_comm(const ippm_config* __restrict__ c, const int64_t* __restr
 // deferred-clamp state (the reference's full-grid input clip, applied only where it can matter)
 // ======================================================================================================
 __device__ __forceinline__ void plan_push(const ippm_config* __restrict__ c, int32_t* w, int& nops, int type, int src, int alt,
-                                          const int32_t* r, int& x0, int& x1, int& y0, int& y1) {
+                                          const int32_t* r, int& x0, int& x1, int& y0, int& y1, int4* s_ops) {
   if (r[3] <= r[2] || r[1] <= r[0]) return;
+  if (s_ops) s_ops[nops] = make_int4(r[0], r[1], r[2], r[3]);  // LDS mirror of the rectangle for the tile builder
   int32_t* op = w + WS_OPS + nops * OP_WORDS;
   op[OP_TYPE] = type; op[OP_SRC] = src;
   // the measurement's log-odds ride in the op record: the fusion kernel needs no dependent table lookup
@@ -77,7 +80,8 @@ __device__ __forceinline__ void plan_push(const ippm_config* __restrict__ c, int
 // rect_e = the env's [N,4] published footprints, st = the map's first 6 workspace words (deferred-clamp state), both possibly
 // prefetched by the caller (global memory or LDS / registers).
 __device__ __forceinline__ int plan_map(const ippm_config* __restrict__ c, const int32_t* rect_e, const int32_t* pos_e, uint32_t recv,
-                                         int32_t* __restrict__ ws, int global_maps, int e, int i, const int32_t* st) {
+                                         int32_t* __restrict__ ws, int global_maps, int e, int i, const int32_t* st,
+                                         int4* s_ops = nullptr, int32_t* s_nops = nullptr) {
   const int n = c->n_agents;
   int32_t* w = ws + (size_t)(e * (n + 1) + i) * IPPM_WS_WORDS;
   int nops = 0, x0 = 1 << 30, x1 = -1, y0 = 1 << 30, y1 = -1;
@@ -101,17 +105,18 @@ __device__ __forceinline__ int plan_map(const ippm_config* __restrict__ c, const
       w[WS_FLAG_S] = 0;
     }
     hdr[PL_NOPS] = 0;
+    if (s_nops) *s_nops = 0;
     return 0;
   }
-  if (st[WS_FLAG_A]) plan_push(c, w, nops, 0, -1, 0, st + WS_RECT_A, x0, x1, y0, y1);
-  if (!global_maps && st[WS_FLAG_S]) plan_push(c, w, nops, 0, -1, 0, rect_e + i * 4, x0, x1, y0, y1);
+  if (st[WS_FLAG_A]) plan_push(c, w, nops, 0, -1, 0, st + WS_RECT_A, x0, x1, y0, y1, s_ops);
+  if (!global_maps && st[WS_FLAG_S]) plan_push(c, w, nops, 0, -1, 0, rect_e + i * 4, x0, x1, y0, y1, s_ops);
   int last_op = -1;
   for (int j = 0; j < n; ++j) {
     bool take = global_maps ? true : (j != i && ((recv >> j) & 1u) != 0);
     if (!take) continue;
     const int32_t* rj = rect_e + j * 4;
     int before = nops;
-    plan_push(c, w, nops, 1, j, ippm_alt_index(c, pos_e[j * 3 + 2]), rj, x0, x1, y0, y1);
+    plan_push(c, w, nops, 1, j, ippm_alt_index(c, pos_e[j * 3 + 2]), rj, x0, x1, y0, y1, s_ops);
     if (j == last_src) {
       last_op = nops > before ? nops - 1 : -1;  // an empty last footprint leaves no unclamped outputs
       for (int q = 0; q < 4; ++q) w[WS_RECT_A + q] = rj[q];
@@ -120,6 +125,7 @@ __device__ __forceinline__ int plan_map(const ippm_config* __restrict__ c, const
   w[WS_FLAG_A] = 0;  // set again by the fusion kernel if the last op leaves out-of-range values
   w[WS_FLAG_S] = 0;
   hdr[PL_NOPS] = nops;
+  if (s_nops) *s_nops = nops;
   if (whole && nops > 0) { x0 = 0; x1 = c->grid_x; y0 = 0; y1 = c->grid_y; }
   hdr[PL_X0] = x0; hdr[PL_X1] = x1; hdr[PL_Y0] = y0; hdr[PL_Y1] = y1;
   hdr[PL_LAST] = last_op;
@@ -141,6 +147,113 @@ __global__ void k_plan(const ippm_config* __restrict__ c, const int32_t* __restr
   int32_t st[6];
   for (int q = 0; q < 6; ++q) st[q] = ws[(size_t)(e * (n + 1) + i) * IPPM_WS_WORDS + q];
   plan_map(c, rect + (size_t)e * n * 4, pos + (size_t)e * n * 3, recv, ws, global_maps, e, i, st);
+}
+
+// ======================================================================================================
+// One-trip tile items of the fusion (fuse_tiles.hip), built here so that the fusion's wavefronts start from a self-contained
+// item instead of deriving rows and columns from the plan: trip 1 = the item, trip 2 = op records + every map cell of the item.
+//
+// The ops of a plan are rectangles.  Along x the set of ops covering a row changes only at rectangle edges (SLABS); inside a
+// slab the covered columns are the union of the active ops' column ranges, i.e. a few disjoint INTERVALS of 4-cell groups.
+// An item is a block of rows of one (slab, interval): at most 64 * slots lane-loads of 16 bytes (slots = 4, 2 or 1 loads in
+// flight per lane, by the number of ops that meet the interval), with the mask of exactly those ops.  Every cell of the union
+// belongs to exactly one item; gaps between side-by-side rectangles belong to none.
+// Wave-cooperative per map: lane l ranks edge l (rank sort + one ds_permute, as the row walker did per item), lane s then owns
+// slab s and merges the intervals of the ops sorted by their first column; a first pass counts the slabs' items (prefix sum
+// over lanes), a second writes them.
+// ======================================================================================================
+__device__ __forceinline__ int tb_lane_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+
+// items of rows [xa, xb) x groups [g0, g1) with the ops of `mask`: counted, and written to dst when emit
+__device__ __forceinline__ int tile_items_of_interval(bool emit, int4* dst, int room, int env, int slot, int xa, int xb, int g0, int g1,
+                                                      unsigned mask) {
+  const int W = g1 - g0, rows = xb - xa;
+  const int sl = ippm_tile_slots(__popc(mask));          // 4, 2 or 1
+  const int cap = 64 * sl;
+  const int nch = (W + cap - 1) / cap;                   // column chunks (1 unless the interval is wider than an item)
+  const int Wc = nch == 1 ? W : (W + nch - 1) / nch;
+  // exact floor(cap / Wc) and ceil(rows / rpi) through one float reciprocal each (operands < 2^12: never within 1e-4 of an integer
+  // boundary after the +0.5)
+  const int rpi = max(1, (int)(((float)cap + 0.5f) * __builtin_amdgcn_rcpf((float)Wc)));
+  const int nrb = (int)(((float)(rows + rpi - 1) + 0.5f) * __builtin_amdgcn_rcpf((float)rpi));
+  if (emit) {
+    int k = 0;
+    for (int rb = 0; rb < nrb; ++rb) {
+      const int x0 = xa + rb * rpi, nr = min(rpi, xb - x0);
+      for (int ch = 0; ch < nch; ++ch, ++k) {
+        const int g = g0 + ch * Wc, w = min(Wc, g1 - g);
+        if (k < room) dst[k] = make_int4(env, x0 | (nr << 16), g | (w << 16), (int)(mask | ((unsigned)slot << 24)));
+      }
+    }
+  }
+  return nch * nrb;
+}
+
+// my slab's items: walk the plan's ops in ascending first column, merging their group ranges into intervals
+__device__ __forceinline__ int tile_walk_slab(bool emit, int4* dst, int room, int env, int slot, bool slab_on, int xa, int xb, int nops,
+                                              int order, int r_yu, int r_yd, int r_xl, int r_xr) {
+  int cnt = 0, g0 = 0, g1 = -1;
+  unsigned mask = 0;
+  for (int r = 0; r < nops; ++r) {
+    const int o = tb_lane_i(order, r);  // op with the r-th smallest first column
+    const int yu = tb_lane_i(r_yu, o), yd = tb_lane_i(r_yd, o), xl = tb_lane_i(r_xl, o), xr = tb_lane_i(r_xr, o);
+    const bool in = slab_on && xl <= xa && xa < xr;
+    const int lo = yu >> 2, hi = (yd + 3) >> 2;
+    if (in) {
+      if (mask != 0 && lo > g1) {  // a gap of at least one group: the interval so far is complete
+        cnt += tile_items_of_interval(emit, dst + cnt, room - cnt, env, slot, xa, xb, g0, g1, mask);
+        mask = 0;
+      }
+      if (mask == 0) { g0 = lo; g1 = hi; }
+      else g1 = max(g1, hi);
+      mask |= 1u << o;
+    }
+  }
+  if (mask != 0) cnt += tile_items_of_interval(emit, dst + cnt, room - cnt, env, slot, xa, xb, g0, g1, mask);
+  return cnt;
+}
+
+// All items of one map's plan (nops > 0, uniform) into the env's list.  s_ops: the plan's rectangles in LDS.
+__device__ __forceinline__ void tile_build_map(const int4* s_ops, int nops, int env, int slot, int4* items, int env_cap, int32_t* s_items,
+                                               int lane) {
+  const int n_edges = 2 * nops;
+  int4 rc = make_int4(0, 0, 0, 0);
+  if (lane < nops) rc = s_ops[lane];
+  const int r_yu = rc.x, r_yd = rc.y, r_xl = rc.z, r_xr = rc.w;
+  // lane l holds edge l = xl / xr of op l >> 1
+  int edge = 0;
+  {
+    const int o = min(lane >> 1, IPPM_MAX_OPS - 1);
+    const int exl = __builtin_amdgcn_ds_bpermute(o << 2, r_xl), exr = __builtin_amdgcn_ds_bpermute(o << 2, r_xr);
+    edge = (lane & 1) ? exr : exl;
+  }
+  int rank = 0, orank = 0;
+  for (int j = 0; j < n_edges; ++j) {
+    const int ej = tb_lane_i(edge, j);
+    rank += (ej < edge || (ej == edge && j < lane)) ? 1 : 0;
+  }
+  for (int j = 0; j < nops; ++j) {
+    const int yj = tb_lane_i(r_yu, j);
+    orank += (yj < r_yu || (yj == r_yu && j < lane)) ? 1 : 0;
+  }
+  const int sorted = __builtin_amdgcn_ds_permute((lane < n_edges ? rank : lane) << 2, edge);  // lane `rank` receives my edge
+  const int order = __builtin_amdgcn_ds_permute((lane < nops ? orank : lane) << 2, lane);      // lane r receives the op of rank r
+  const int xa = sorted;
+  int xb = __builtin_amdgcn_ds_bpermute(min(lane + 1, 63) << 2, sorted);
+  const bool slab_on = lane + 1 < n_edges && xb > xa;
+  if (!slab_on) xb = xa;
+  const int cnt = tile_walk_slab(false, nullptr, 0, env, slot, slab_on, xa, xb, nops, order, r_yu, r_yd, r_xl, r_xr);
+  int before = 0, total = 0;
+  for (int j = 0; j + 1 < n_edges; ++j) {
+    const int v = tb_lane_i(cnt, j);
+    before += j < lane ? v : 0;
+    total += v;
+  }
+  if (total == 0) return;
+  int base = 0;
+  if (lane == 0) base = atomicAdd(s_items, total);   // where this map's items start in the env's list
+  base = __builtin_amdgcn_readfirstlane(base);
+  tile_walk_slab(true, items + base + before, env_cap - base - before, env, slot, slab_on, xa, xb, nops, order, r_yu, r_yd, r_xl, r_xr);
 }
 
 // ======================================================================================================
@@ -240,14 +353,22 @@ __global__ void k_action_mask(const ippm_config* __restrict__ c, const int32_t* 
   for (int q = 0; q < A; ++q) mask_out[(size_t)b * A + q] = (m >> q) & 1u;
 }
 
-// K1 for one env by one wavefront (blockDim.x == 64).  s_pos: the env's positions in LDS, updated in place.
+// LDS hand-over between the lanes of ONE wavefront (K1 runs on wavefront 0 of the plan kernel's workgroup while the others build
+// tile items, so a workgroup barrier is not available here): DS operations of a wavefront execute in program order, the fence
+// only keeps the compiler from moving them.
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// K1 for one env by one wavefront (lanes 0..63 of wavefront 0).  s_pos: the env's positions in LDS, updated in place.
 // get_action_mask -> apply_collision_mask -> action choice -> action_to_position (action_space.py:25-589,
 // actor/network.py:90-96, coma_wrapper.py:97-104)
 __device__ void k1_env(const ippm_config* __restrict__ c, int64_t ep, int32_t* s_pos, const float* __restrict__ probs_e,
                        const int32_t* __restrict__ action_in_e, int policy, int t, uint8_t* __restrict__ mask_e,
                        int32_t* __restrict__ action_e, int32_t* __restrict__ fault_e) {
   const int n = c->n_agents, A = c->n_actions, s = c->spacing;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const uint32_t k0 = (uint32_t)c->philox_seed, k1 = (uint32_t)(c->philox_seed >> 32);
   int flt = 0;
   // Off the serial chain, up front: every agent's boundary mask (its position does not change before its own move; lanes =
@@ -262,7 +383,7 @@ __device__ void k1_env(const ippm_config* __restrict__ c, int64_t ep, int32_t* s
   }
   if ((policy == 1 || policy == 2) && lane < n)
     word_mine = ippm_philox(0u, (uint32_t)ep, ippm_stream_word((uint32_t)lane, (uint32_t)t, IPPM_DOMAIN_ACTION), (uint32_t)(ep >> 32), k0, k1).v[0];
-  __syncthreads();
+  wave_sync_lds();
   for (int i = 0; i < n; ++i) {
     const int px = s_pos[i * 3], py = s_pos[i * 3 + 1], pz = s_pos[i * 3 + 2];
     const uint32_t bmask = (uint32_t)__builtin_amdgcn_readlane((int)bmask_mine, i);
@@ -311,13 +432,13 @@ __device__ void k1_env(const ippm_config* __restrict__ c, int64_t ep, int32_t* s
     if (a < 0 || a >= A) a = bmask ? __ffs(bmask) - 1 : 0;  // keep the state sane: first boundary-valid action
     int dx, dy, dz;
     action_offset(A, a, s, dx, dy, dz);
-    __syncthreads();  // every lane has read agent i's old position
+    wave_sync_lds();  // every lane has read agent i's old position
     if (lane == 0) {
       s_pos[i * 3] = px + dx; s_pos[i * 3 + 1] = py + dy; s_pos[i * 3 + 2] = pz + dz;
       action_e[i] = a;
     }
     if (lane < A) mask_e[(size_t)i * A + lane] = (m >> lane) & 1u;
-    __syncthreads();
+    wave_sync_lds();
   }
   if (fault_e && lane == 0) *fault_e = flt;
 }
@@ -330,51 +451,104 @@ __device__ void k1_env(const ippm_config* __restrict__ c, int64_t ep, int32_t* s
 //                    starts with its rectangle in hand instead of a pos -> lattice index -> centre table chain
 // comm and the plans read the pre-move positions (LDS copy taken before K1 writes anything).
 // ======================================================================================================
-__global__ void __launch_bounds__(64)
+#ifdef IPPM_PLAN_STAMPS   // variant builds: env 0 leaves wall-clock stamps of its phases in word 7 of the counter slots
+#define PLAN_STAMP(k) do { if (blockIdx.x == 0 && lane == 0 && stamps) stamps[((wv * 8 + (k)) & 63) * 8 + 7] = wall_clock64(); \
+    if (blockIdx.x == gridDim.x - 1 && wv == 0 && lane == 0 && stamps) stamps[(48 + (k)) * 8 + 7] = wall_clock64(); \
+    if (blockIdx.x == gridDim.x / 2 && wv == 0 && lane == 0 && stamps) stamps[(56 + (k)) * 8 + 7] = wall_clock64(); } while (0)
+#else
+#define PLAN_STAMP(k) do { } while (0)
+#endif
+#define IPPM_PLAN_BUILDERS 6   // most wavefronts that build tile items next to wavefront 0 (maps are dealt out round-robin)
+#define IPPM_PLAN_BUILDERS_DEFAULT 3   // measured at 1024 envs x 4 UAVs: 1 / 2 / 3 / 5 builders -> 32.6 / 25.8 / 21.1 / 26.5 us (16 wavefronts
+                                       // per CU is what one round of the launch holds; a sixth wavefront per env makes it two rounds)
+__global__ void __launch_bounds__(64 * (1 + IPPM_PLAN_BUILDERS))
 k_plan_step(const ippm_config* __restrict__ c, const int64_t* __restrict__ episode, int32_t* __restrict__ pos,
             const float* __restrict__ comm_range, const double* __restrict__ draws, uint8_t* __restrict__ comm,
             const int32_t* __restrict__ rect, int32_t* __restrict__ ws, int t, int flags, const float* __restrict__ probs,
             const int32_t* __restrict__ action_in, int policy, uint8_t* __restrict__ mask, int32_t* __restrict__ action,
             int32_t* __restrict__ fault, int32_t* __restrict__ rect_next, int agent_sel, int32_t* __restrict__ work,
-            int wave_rows, int env_cap) {
-  const int e = blockIdx.x, lane = threadIdx.x;
+            int wave_rows, int env_cap, unsigned long long* __restrict__ stamps) {
+  // Wavefront 0 does what the kernel always did (comm, plans, K1).  With a tile-form work list the workgroup carries builder
+  // wavefronts as well: once the plans are in LDS they cut them into one-trip items (a map each, round-robin) while wavefront 0
+  // goes on with K1.  One wavefront per SIMD runs ~2.5 ns per instruction; the items of five plans took 19 us in line.
+  const int e = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int n = c->n_agents, A = c->n_actions;
   __shared__ int32_t s_pos[IPPM_MAX_AGENTS * 3];
   __shared__ int32_t s_rect[IPPM_MAX_AGENTS * 4];
-  int32_t* pg = pos + (size_t)e * n * 3;
+  __shared__ int4 s_ops[(IPPM_MAX_AGENTS + 1) * IPPM_MAX_OPS];   // the op rectangles of every plan, for the tile builders
+  __shared__ int32_t s_nops[IPPM_MAX_AGENTS + 1];
+  __shared__ int32_t s_items, s_done;                            // items handed out so far; builders that have finished
   const bool plans = (flags & (IPPM_STEP_COMM | IPPM_STEP_GLOBAL)) != 0;
-  // everything this wavefront will read is requested now, in one round trip: positions, published footprints, the
-  // deferred-clamp state of my map (lane i: local map i, lane n: the global map)
-  if (lane < n * 3) s_pos[lane] = pg[lane];
-  if (plans && lane < n * 4) s_rect[lane] = rect[(size_t)e * n * 4 + lane];
+  const bool tiled = (flags & IPPM_STEP_TILES) != 0 && work && plans;
+  const int builders = (int)(blockDim.x >> 6) - 1;
+  int32_t* pg = pos + (size_t)e * n * 3;
   int32_t st[6] = {0, 0, 0, 0, 0, 0};
-  if (plans && lane <= n)
-    for (int q = 0; q < 6; ++q) st[q] = ws[(size_t)(e * (n + 1) + lane) * IPPM_WS_WORDS + q];
-  __syncthreads();
-  int hull_rows = 0;
-  if ((flags & IPPM_STEP_COMM) && lane < n) {
-    const uint32_t recv = comm_row(c, episode, s_pos, comm_range, draws, comm, t, e, lane);
-    if (agent_sel < 0 || agent_sel == lane) hull_rows = plan_map(c, s_rect, s_pos, recv, ws, 0, e, lane, st);
-  }
-  if ((flags & IPPM_STEP_GLOBAL) && lane == n) hull_rows = plan_map(c, s_rect, s_pos, 0u, ws, 1, e, n, st);
-  // work items of this env's plans into the env's own slice of the list (exclusive scan of the lanes' item counts)
-  if (work && plans) {
-    const int items = (hull_rows + wave_rows - 1) / wave_rows;
-    // the global map's runs go first (they carry the reward arithmetic: longest items first balances the env's wavefronts)
-    const int g_items = __builtin_amdgcn_readlane(items, n);
-    int before = lane == n ? 0 : g_items, total = g_items;
-    for (int j = 0; j < n; ++j) {
-      const int v = __builtin_amdgcn_readlane(items, j);
-      before += (j < lane && lane != n) ? v : 0;
-      total += v;
+  PLAN_STAMP(0);
+  if (wv == 0) {
+    // everything this wavefront will read is requested now, in one round trip: positions, published footprints, the
+    // deferred-clamp state of my map (lane i: local map i, lane n: the global map)
+    if (lane <= n) s_nops[lane] = 0;
+    if (lane == 0) { s_items = 0; s_done = 0; }
+    if (lane < n * 3) s_pos[lane] = pg[lane];
+    if (plans && lane < n * 4) s_rect[lane] = rect[(size_t)e * n * 4 + lane];
+    if (plans && lane <= n)
+      for (int q = 0; q < 6; ++q) st[q] = ws[(size_t)(e * (n + 1) + lane) * IPPM_WS_WORDS + q];
+    wave_sync_lds();
+    PLAN_STAMP(1);
+    int hull_rows = 0;
+    if ((flags & IPPM_STEP_COMM) && lane < n) {
+      const uint32_t recv = comm_row(c, episode, s_pos, comm_range, draws, comm, t, e, lane);
+      if (agent_sel < 0 || agent_sel == lane)
+        hull_rows = plan_map(c, s_rect, s_pos, recv, ws, 0, e, lane, st, tiled ? s_ops + lane * IPPM_MAX_OPS : nullptr, tiled ? s_nops + lane : nullptr);
     }
-    if (lane == 0) work[e] = total;
-    int32_t* dst = work + gridDim.x + (size_t)e * env_cap + before;
-    if (lane <= n)
-      for (int k = 0; k < items; ++k) dst[k] = ((e * (n + 1) + lane) << 8) | k;
+    if ((flags & IPPM_STEP_GLOBAL) && lane == n)
+      hull_rows = plan_map(c, s_rect, s_pos, 0u, ws, 1, e, n, st, tiled ? s_ops + n * IPPM_MAX_OPS : nullptr, tiled ? s_nops + n : nullptr);
+    // row-run form of the work list: items of this env's plans into the env's own slice (exclusive scan of the lanes' counts)
+    if (work && plans && !tiled) {
+      const int items = (hull_rows + wave_rows - 1) / wave_rows;
+      // the global map's runs go first (they carry the reward arithmetic: longest items first balances the env's wavefronts)
+      const int g_items = __builtin_amdgcn_readlane(items, n);
+      int before = lane == n ? 0 : g_items, total = g_items;
+      for (int j = 0; j < n; ++j) {
+        const int v = __builtin_amdgcn_readlane(items, j);
+        before += (j < lane && lane != n) ? v : 0;
+        total += v;
+      }
+      if (lane == 0) work[e] = total;
+      int32_t* dst = work + gridDim.x + (size_t)e * env_cap + before;
+      if (lane <= n)
+        for (int k = 0; k < items; ++k) dst[k] = ((e * (n + 1) + lane) << 8) | k;
+    }
   }
+  PLAN_STAMP(2);
+  if (tiled) {
+    __syncthreads();   // the plans are in LDS (the only workgroup barrier: K1 below syncs within its wavefront)
+    if (wv > 0 || builders == 0) {
+      // Tile items: builder b takes maps b, b + builders, ...; a map's items go wherever the env's running count says (an LDS
+      // atomic per map), so no builder waits for another; the last one to finish writes the env's count.
+      int4* items = reinterpret_cast<int4*>(work + ((gridDim.x + 3) & ~3)) + (size_t)e * env_cap;
+      const int nb = max(builders, 1), b = builders ? wv - 1 : 0;
+      PLAN_STAMP(3);
+      for (int mm = b; mm <= n; mm += nb) {
+        const int m = mm == 0 ? n : mm - 1;   // the global map's items come early: they carry the reward arithmetic
+        const int nops = __builtin_amdgcn_readfirstlane(s_nops[m]);
+        if (nops > 0) tile_build_map(s_ops + m * IPPM_MAX_OPS, nops, e, m, items, env_cap, &s_items, lane);
+      }
+      PLAN_STAMP(4);
+      int last = 0;
+      if (lane == 0) last = atomicAdd(&s_done, 1) == nb - 1 ? 1 : 0;
+      last = __builtin_amdgcn_readfirstlane(last);
+      if (last && lane == 0) {
+        // (the capacity bound of ippm_tile_env_cap covers every plan; a list that would not fit is cut and reported)
+        const int total = atomicAdd(&s_items, 0);
+        work[e] = min(total, env_cap) | IPPM_WORK_TILED | (total > env_cap ? IPPM_WORK_OVERFLOW : 0);
+      }
+    }
+  }
+  if (wv != 0) return;
   if (flags & IPPM_STEP_MOVE) {
-    __syncthreads();
+    wave_sync_lds();
+    PLAN_STAMP(5);
     k1_env(c, episode ? episode[e] : 0, s_pos, probs ? probs + (size_t)e * n * A : nullptr,
            action_in ? action_in + (size_t)e * n : nullptr, policy, t, mask + (size_t)e * n * A, action + (size_t)e * n,
            fault ? fault + e : nullptr);
@@ -385,6 +559,7 @@ k_plan_step(const ippm_config* __restrict__ c, const int64_t* __restrict__ episo
       int32_t* r = rect_next + (size_t)(e * n + lane) * 4;
       r[0] = cl[0]; r[1] = cl[1]; r[2] = cl[2]; r[3] = cl[3];
     }
+    PLAN_STAMP(6);
   }
 }
 
@@ -420,9 +595,24 @@ int ippm_work_env_cap(const ippm_ctx* ctx, int n_envs) {
   return (ctx->cfg.n_agents + 1) * chunks;
 }
 
+// Tile items an env's slice can hold.  Per map: every full item covers more than half of its capacity of 64 * slots groups,
+// capacity >= that of the config's largest plan, and the items are disjoint, so there are at most
+// gx * G / (32 * slots(max_ops)) of them (G = groups per row); each (slab, interval) pair adds at most one partial row block
+// per column chunk: <= max_ops * (2 max_ops - 1) * ceil(G / 64).
+int ippm_tile_env_cap(const ippm_ctx* ctx) {
+  const ippm_config& c = ctx->cfg;
+  const int max_ops = c.n_agents + 1;
+  const int G = (c.grid_y + 3) / 4;
+  const int full = (c.grid_x * G + 32 * ippm_tile_slots(max_ops) - 1) / (32 * ippm_tile_slots(max_ops));
+  const int partial = max_ops * (2 * max_ops - 1) * ((G + 63) / 64);
+  return (c.n_agents + 1) * (full + partial);
+}
+
 extern "C" int ippm_work_words(ippm_ctx* ctx, int32_t n_envs, int64_t* words) {
   if (!ctx || !words || n_envs < 0) { ippm_set_error("ippm_work_words: bad argument"); return -1; }
-  *words = (int64_t)n_envs * (1 + ippm_work_env_cap(ctx, n_envs));
+  const int64_t rows_form = (int64_t)n_envs * (1 + ippm_work_env_cap(ctx, n_envs));
+  const int64_t tile_form = ctx->tiles ? (int64_t)((n_envs + 3) & ~3) + (int64_t)n_envs * ippm_tile_env_cap(ctx) * 4 : 0;
+  *words = std::max(rows_form, tile_form);   // either form of the list fits (ippm_plan_step's IPPM_STEP_TILES chooses)
   return 0;
 }
 
@@ -431,7 +621,8 @@ extern "C" int ippm_plan_step(ippm_ctx* ctx, const int64_t* episode, int32_t* po
                               const int32_t* action_in, int32_t policy, uint8_t* mask, int32_t* action, int32_t* fault,
                               int32_t* rect_next, int32_t* work, int32_t n_envs, void* stream) {
   if (!ctx || !pos) { ippm_set_error("ippm_plan_step: null argument"); return -1; }
-  if ((flags & (IPPM_STEP_COMM | IPPM_STEP_GLOBAL | IPPM_STEP_MOVE)) == 0 || (flags & ~7)) { ippm_set_error("ippm_plan_step: bad flags"); return -1; }
+  if ((flags & (IPPM_STEP_COMM | IPPM_STEP_GLOBAL | IPPM_STEP_MOVE)) == 0 || (flags & ~15)) { ippm_set_error("ippm_plan_step: bad flags"); return -1; }
+  if ((flags & IPPM_STEP_TILES) && !ctx->tiles) flags &= ~IPPM_STEP_TILES;   // configs without the tile form keep the row-run list
   if ((flags & IPPM_STEP_COMM) && (!comm || !rect || !ws)) { ippm_set_error("ippm_plan_step: comm/plan needs comm, rect, ws"); return -1; }
   if ((flags & IPPM_STEP_COMM) && !draws && !episode) { ippm_set_error("ippm_plan_step: Philox draws need the episode ids"); return -1; }
   if ((flags & IPPM_STEP_GLOBAL) && (!rect || !ws)) { ippm_set_error("ippm_plan_step: global plan needs rect, ws"); return -1; }
@@ -450,9 +641,12 @@ extern "C" int ippm_plan_step(ippm_ctx* ctx, const int64_t* episode, int32_t* po
       return -1;
     }
   }
-  IPPM_LAUNCH(ctx, IPPM_T_PLAN, k_plan_step, dim3(n_envs), dim3(64), S_(stream), ctx->dcfg, episode, pos, comm_range, draws, comm, rect, ws,
+  const bool tile_list = plans && work && (flags & IPPM_STEP_TILES);
+  const int plan_waves = tile_list ? 1 + std::min(ctx->cfg.n_agents + 1, ctx->knob_plan_builders > 0 ? std::min(ctx->knob_plan_builders, IPPM_PLAN_BUILDERS) : IPPM_PLAN_BUILDERS_DEFAULT) : 1;
+  IPPM_LAUNCH(ctx, IPPM_T_PLAN, k_plan_step, dim3(n_envs), dim3(64 * plan_waves), S_(stream), ctx->dcfg, episode, pos, comm_range, draws, comm, rect, ws,
                      t, flags, probs, action_in, policy, mask, action, fault, rect_next, -1, plans ? work : nullptr,
-                     ippm_fuse_wave_rows(ctx, n_envs), ippm_work_env_cap(ctx, n_envs));
+                     ippm_fuse_wave_rows(ctx, n_envs), (flags & IPPM_STEP_TILES) ? ippm_tile_env_cap(ctx) : ippm_work_env_cap(ctx, n_envs),
+                     ctx->dcounters);
   IPPM_LAUNCH_CHECK("plan_step");
   return 0;
 }

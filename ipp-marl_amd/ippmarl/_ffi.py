@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IPPMARL_LIB", os.path.join(_HERE, "..", "lib", "libippmarl.so"))
 WS_WORDS = 160
 FEAT, ACTOR_PLANES, CRITIC_PLANES = 11, 7, 12
-STEP_COMM, STEP_GLOBAL, STEP_MOVE = 1, 2, 4   # ippm_plan_step flags
+STEP_COMM, STEP_GLOBAL, STEP_MOVE, STEP_TILES = 1, 2, 4, 8   # ippm_plan_step flags
 # kernel classes of ippm_read_kernel_times (IPPM_T_*)
 TIMED = {"sense": 0, "fuse": 1, "plan": 2, "actor_features": 3, "critic_features": 4, "reset": 5, "terrain": 6}
 
@@ -223,7 +223,9 @@ class Context:
     def counters(self, stream, reset: bool = False) -> dict:
         out = IppmCounters()
         check(self.lib.ippm_read_counters(self.handle, C.byref(out), 1 if reset else 0, stream), "ippm_read_counters")
-        return {k: int(getattr(out, k)) for k, _ in IppmCounters._fields_ if k != "reserved"}
+        res = {k: int(getattr(out, k)) for k, _ in IppmCounters._fields_ if k != "reserved"}
+        res["work_list_rejects"] = int(out.reserved[0])   # fusion launches handed a work list of the other form (must stay 0)
+        return res
 
 
 # ---- host helpers (usable without a GPU) ------------------------------------------------------------

@@ -206,6 +206,8 @@ class VecEnv:
                       self._p(self.comm), self._p(self.ws), agent, self.E, self.stream)
 
     def _plan_step(self, t: int, flags: int, comm_draws=None, policy: int = 0, probs=None, actions=None):
+        if not self.track_area and flags & (_ffi.STEP_COMM | _ffi.STEP_GLOBAL):
+            flags |= _ffi.STEP_TILES   # the fusion without area sums takes the work list as one-trip tile items
         self.ctx.call("ippm_plan_step", self._p(self.episode), self._p(self.pos), self._p(self.comm_range), self._p(comm_draws),
                       self._p(self.comm), self._p(self.rect), self._p(self.ws), t, flags, self._p(probs), self._p(actions), policy,
                       self._p(self.mask), self._p(self.action), self._p(self.fault), self._p(self.rect_next), self._p(self.work), self.E,

@@ -11,7 +11,7 @@ for cfg in "$@"; do
 import json
 try:
     d=json.loads(open("$OUT/bench_$name.json").read().strip().splitlines()[-1])
-    print("$cfg", {k:round(d[k],4) for k in ("value","ms_per_step")}, [(r["kernel"][:12], round(r["avg_launch_us"],1), round(r["frac"],3)) for r in (d.get("roofline_kernels") or [])], (d.get("coma_training") or {}).get("rollout_kernel_us"), (d.get("coma_training") or {}).get("rollout_agent_env_steps_per_s"))
+    print("$cfg", {k:round(d[k],4) for k in ("value","ms_per_step")}, [(r["kernel"][:12], round(r["avg_launch_us"],1), round(r.get("frac", 0),3)) for r in (d.get("roofline_kernels") or [])], (d.get("coma_training") or {}).get("rollout_kernel_us"), (d.get("coma_training") or {}).get("rollout_agent_env_steps_per_s"))
 except Exception as e:
     print("$cfg failed", e, open("$OUT/bench_$name.err").read()[-500:])
 PY

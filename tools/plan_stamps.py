@@ -1,0 +1,33 @@
+"""Phase stamps of k_plan_step (variant library built with -DIPPM_PLAN_STAMPS): IPPMARL_LIB=.../libippmarl_stamps.so python tools/plan_stamps.py"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ipp-marl_amd"))
+sys.path.insert(0, ROOT)
+from bench import bench_params  # noqa: E402
+from ippmarl.vec_env import VecEnv, POLICY_UNIFORM  # noqa: E402
+
+
+class A:
+    agents, grid = 4, 256
+
+
+env = VecEnv(bench_params(A), 1024, philox_seed=3, terrain="split", track_area=False)
+env.reset(list(range(1, 1025)))
+names = ["start", "loaded", "plans done", "builder start", "builder done", "K1 start", "K1 done"]
+for t in range(8):
+    env.steps(t, policy=POLICY_UNIFORM, features=False)
+    raw = np.zeros(512, dtype=np.uint64)
+    env.ctx.lib.ippm_debug_raw_counters(env.ctx.handle, C.c_void_p(raw.ctypes.data))
+    st = raw.reshape(64, 8)[:, 7].astype(np.int64)
+    t0 = st[0]
+    line = []
+    for wv in (0, 1, 6, 7):   # 6 / 7: wavefront 0 of the last / the middle env
+        ks = {0: (0, 1, 2, 5, 6), 6: (0, 1, 2, 5, 6), 7: (0, 1, 2, 5, 6)}.get(wv, (0, 2, 3, 4))
+        line.append(f"w{wv}: " + " ".join(f"{names[k]}={(st[wv * 8 + k] - t0) / 100.0:.1f}us" for k in ks if st[wv * 8 + k]))
+    print(f"t={t}  " + " | ".join(line))
