@@ -142,9 +142,18 @@ class _ConvTrunk(nn.Module):
             return self.activation(out + conv.bias.view(1, -1, 1, 1))
         return self.activation(conv2d(x, conv.weight, conv.bias))
 
+    # conv1's activation [B, 256, 7, 7] float32 is 50 176 bytes per sample: 2^31 bytes at 42 799 samples, 2^32 at 85 598, and
+    # the library's convolution kernels address their tensors with 32-bit byte offsets (measured: one forward pass over 131 072
+    # critic states returns the results of samples 85 598.. wrapped onto samples 0..: wrong Q values, no error).  Larger batches go
+    # through in slices.
+    MAX_SAMPLES = 32768
+
     def trunk(self, x: torch.Tensor):
         if x.dim() == 3:
             x = x.unsqueeze(0)
+        if x.shape[0] > self.MAX_SAMPLES:
+            parts = [self.trunk(x[lo:lo + self.MAX_SAMPLES]) for lo in range(0, x.shape[0], self.MAX_SAMPLES)]
+            return torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
         x = x.permute(0, 3, 1, 2)  # NHWC storage -> logical NCHW (channels_last strides, no copy)
         h = self._conv_relu(self.conv1, x, False)
         h = self._conv_relu(self.conv2, h, CONV2_BWD_DATA_AS_GEMM and h.requires_grad)

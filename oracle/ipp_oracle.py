@@ -625,6 +625,13 @@ class OracleEpisode:
             else:
                 observations.append(None)
         fused_local = [self.agents[i]["local_map"].copy() for i in range(n)]
+        # the 11 x 11 area averages that decide the class weights of the feature planes (actor planes 3, 4; critic plane 8): a
+        # test that meets a whole-class-weight difference can check that the deciding average sits ON a threshold (0.499 / 0.501)
+        decide_local = decide_fp = None
+        if self.build_features:
+            dsize = (d.space_y, d.space_x)
+            decide_local = [area_resize(self.agents[i]["local_map"].astype(np.float64), dsize) for i in range(n)]
+            decide_fp = [area_resize(np.asarray(published[i]["footprint_img"], dtype=np.float64), dsize) for i in range(n)]
         # ---- steps: global fusion, sequential act/move/sense, critic input, reward
         critic_map = fuse_map(d, self.global_map, published, None, "global")
         moved, actions, masks = [], [], []
@@ -648,7 +655,10 @@ class OracleEpisode:
                    rects=np.array([published[i]["rect"] for i in range(n)]),
                    next_rects=np.array([self.agents[i]["rect"] for i in range(n)]),
                    relative_reward=float(rel), absolute_reward=float(abs_), s1=s1, s2=s2,
-                   done=(t == d.budget), fused_local=fused_local, global_map=critic_map.copy())
+                   done=(t == d.budget), fused_local=fused_local, global_map=critic_map.copy(),
+                   sensed_local=[self.agents[i]["local_map"].copy() for i in range(n)],   # after this step's sensing
+                   decide_local=decide_local, decide_fp=decide_fp,
+                   decide_global=area_resize(critic_map.astype(np.float64), (d.space_y, d.space_x)) if self.build_features else None)
         self.log.append(rec)
         return rec
 

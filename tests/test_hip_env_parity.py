@@ -7,7 +7,7 @@ import pytest
 
 import ipp_oracle as O
 from configs import make_params
-from conftest import assert_posteriors, unpack_correctness
+from conftest import REFERENCE_QUANTISATION_CELLS as RQ, assert_features_or_ties, assert_posteriors, unpack_correctness
 from test_oracle_golden import EPISODES
 
 torch = pytest.importorskip("torch")
@@ -70,11 +70,11 @@ def test_golden_episode_replay(golden, tag):
         np.testing.assert_allclose(state[0].cpu().numpy(), fx["state"][t], rtol=RTOL, atol=2e-6, err_msg=f"state t={t}")
         assert done == bool(fx["done"][t, 0])
         if t == 0:
-            assert_posteriors(env.posterior_global()[0].cpu().numpy(), fx["global_t0"], strict=False, msg="global t=0")
+            assert_posteriors(env.posterior_global()[0].cpu().numpy(), fx["global_t0"], strict=False, msg="global t=0", allow=RQ.get((tag, "global_t0"), []))
         if t == 7:
-            assert_posteriors(env.posterior_global()[0].cpu().numpy(), fx["global_t7"], strict=False, msg="global t=7")
-    assert_posteriors(env.posterior_local()[0].cpu().numpy(), fx["final_local"], strict=False, msg="final local")
-    assert_posteriors(env.posterior_global()[0].cpu().numpy(), fx["final_global"], strict=False, msg="final global")
+            assert_posteriors(env.posterior_global()[0].cpu().numpy(), fx["global_t7"], strict=False, msg="global t=7", allow=RQ.get((tag, "global_t7"), []))
+    assert_posteriors(env.posterior_local()[0].cpu().numpy(), fx["final_local"], strict=False, msg="final local", allow=RQ.get((tag, "final_local"), []))
+    assert_posteriors(env.posterior_global()[0].cpu().numpy(), fx["final_global"], strict=False, msg="final global", allow=RQ.get((tag, "final_global"), []))
 
 
 def _oracle_philox_episode(params, episode, seed, learned_probs=None, truth=None):
@@ -117,9 +117,13 @@ def _oracle_philox_episode(params, episode, seed, learned_probs=None, truth=None
     ("small", dict(experiment__constraints__min_altitude=15, experiment__constraints__max_altitude=20,
                    experiment__constraints__num_actions=27, experiment__uav__communication_range=10), 2),
 ])
-def test_production_randomness_matches_oracle(name, over, n_envs, seed=0x1234567ABC, first_episode=11, track_area=True):
+def test_production_randomness_matches_oracle(name, over, n_envs, seed=0x1234567ABC, first_episode=11, track_area=True,
+                                              fused_step=False):
     """Philox mode (what bench/training use): device RNG streams, uniform random policy, every step vs the oracle.
-    (``seed`` / ``first_episode``: tools/stress_parity.py sweeps random configurations through this same check.)"""
+    (``seed`` / ``first_episode``: tools/stress_parity.py sweeps random configurations through this same check.)
+    ``fused_step``: ``steps()`` alone, i.e. ONE plan launch (comm + plans + work list + K1) -> fusion -> K3, the exact launch
+    sequence bench.py times; the locally fused maps cannot be looked at between fusion and sensing then, so the local maps are
+    compared after the step's sensing instead.  Returns the number of class-weight threshold ties met (conftest)."""
     from ippmarl.vec_env import POLICY_UNIFORM
     params = make_params(name, **over)
     env = _env(params, n_envs, philox_seed=seed, track_area=track_area)
@@ -127,13 +131,18 @@ def test_production_randomness_matches_oracle(name, over, n_envs, seed=0x1234567
     env.reset(eps)
     oracles = [_oracle_philox_episode(params, ep, seed) for ep in eps]
     T = env.d.budget + 1
-    feats = name != "default" and track_area
+    feats = name != "default" and track_area and not fused_step
+    ties = 0
     for t in range(T):
-        obs = env.build_observations(t, features=feats)
-        comm = env.comm.cpu().numpy()
-        local = env.posterior_local().cpu().numpy()
+        if fused_step:
+            obs = local = None
+        else:
+            obs = env.build_observations(t, features=feats)
+            local = env.posterior_local().cpu().numpy()
         reward, done, state = env.steps(t, policy=POLICY_UNIFORM, features=feats)
+        comm = env.comm.cpu().numpy()   # (written by the plan launch from the pre-move positions in either form)
         glob = env.posterior_global().cpu().numpy()
+        sensed = env.posterior_local().cpu().numpy() if fused_step else None
         for e, (ep, log) in enumerate(oracles):
             rec = log[t]
             n = env.d.n_agents
@@ -148,7 +157,10 @@ def test_production_randomness_matches_oracle(name, over, n_envs, seed=0x1234567
             # (prior != 0.5: every message shifts every cell of the float32 log-odds maps; after dozens of whole-grid adds a few
             #  cells per 100 000 sit just above 1e-5 -- there the bound is >= 99.99 % of the cells within 1e-5, all within 5e-5)
             strict = env.d.prior == 0.5
-            assert_posteriors(local[e], np.array(rec["fused_local"]), strict=strict, msg=f"fused local t={t} e={e}")
+            if fused_step:
+                assert_posteriors(sensed[e], np.array(rec["sensed_local"]), strict=strict, msg=f"local after sensing t={t} e={e}")
+            else:
+                assert_posteriors(local[e], np.array(rec["fused_local"]), strict=strict, msg=f"fused local t={t} e={e}")
             assert_posteriors(glob[e], rec["global_map"], strict=strict, msg=f"global t={t} e={e}")
             # (prior != 0.5, the explicit slow path: every cell of the grid changes at every fusion and enters the reward sums,
             #  so the 1e-5 the cell values are held to shows up undiminished in the sums: 5e-5 on returns and sums there)
@@ -170,11 +182,17 @@ def test_production_randomness_matches_oracle(name, over, n_envs, seed=0x1234567
             np.testing.assert_allclose(env.sums[e, :2].cpu().numpy(), [rec["s1"], rec["s2"]], rtol=rt, atol=1e-6 + s_scale * abs(rec["s2"]))
             if feats:   # (prior != 0.5: the area sums take a small change of EVERY cell at every fusion: 6e-6 absolute there)
                 fa = 2e-6 if env.d.prior == 0.5 and not noise_free else 6e-6   # (noise-free: float32 increments of size 1/2)
-                np.testing.assert_allclose(obs[e].cpu().numpy(), np.array(rec["observations"]), rtol=RTOL, atol=fa)
-                np.testing.assert_allclose(state[e].cpu().numpy(), np.array(rec["states"]), rtol=RTOL, atol=fa)
+                got_obs, got_state = obs[e].cpu().numpy(), state[e].cpu().numpy()
+                for i in range(n):   # a differing element must be a proven class-weight threshold tie (conftest)
+                    dec = {3: rec["decide_local"][i], 4: rec["decide_fp"][i]}
+                    ties += assert_features_or_ties(got_obs[i], rec["observations"][i], dec, RTOL, fa, f"obs t={t} e={e} i={i}")
+                    dec[8] = rec["decide_global"]
+                    ties += assert_features_or_ties(got_state[i], rec["states"][i], dec, RTOL, fa, f"state t={t} e={e} i={i}")
     final = env.posterior_local().cpu().numpy()
     for e, (ep, log) in enumerate(oracles):
         assert_posteriors(final[e], np.array([a["local_map"] for a in ep.agents]), strict=env.d.prior == 0.5, msg=f"final local e={e}")
+    assert env.counters()["work_list_rejects"] == 0
+    return ties
 
 
 @pytest.mark.parametrize("name,over,n_envs", [
@@ -183,21 +201,41 @@ def test_production_randomness_matches_oracle(name, over, n_envs, seed=0x1234567
     ("small", dict(mapping__prior=0.3), 2),
     ("small", dict(sensor__pixel__number_x=14, sensor__pixel__number_y=14, experiment__constraints__num_actions=27), 2),
 ])
-def test_untracked_env_step_matches_oracle(name, over, n_envs):
-    """The env-only step as bench.py runs it -- VecEnv(track_area=False): K3 in its tile form, the fusion without area
-    tracking, the work list -- through the same every-step comparison with the oracle (maps, masks, actions, rewards)."""
-    test_production_randomness_matches_oracle(name, over, n_envs, seed=0x51C0FFEE11, first_episode=23, track_area=False)
+@pytest.mark.parametrize("fused_step", [False, True])
+def test_untracked_env_step_matches_oracle(name, over, n_envs, fused_step):
+    """The env-only step as bench.py runs it -- VecEnv(track_area=False): K3 in its tile form, the fusion in one-trip tile
+    items from the plan kernel's work list -- through the same every-step comparison with the oracle (maps, masks, actions,
+    rewards); ``fused_step`` = ``steps()`` alone, the single-plan-launch sequence of bench.py's timed loop."""
+    test_production_randomness_matches_oracle(name, over, n_envs, seed=0x51C0FFEE11, first_episode=23, track_area=False,
+                                              fused_step=fused_step)
+
+
+def test_class_weight_threshold_ties_are_proven_ties():
+    """17 pixels per footprint: the footprint plane's area average lands on 0.501 exactly (0.5 + 0.125 * 20 / 2500) several
+    times per episode (tools/find_tie_case.py: 4 such bins in episode 11 under this seed, 6 in episode 18).  The device may
+    fall on either side there; the comparison admits a whole-class-weight difference only where the oracle's deciding average
+    is within 32 ulp of the threshold, and everywhere else holds the usual 1e-5."""
+    over = dict(sensor__pixel__number_x=17, sensor__pixel__number_y=17)
+    params = make_params("small", **over)
+    # the ties are there (so the rule is exercised whether or not the device happens to flip one of them)
+    ep, log = _oracle_philox_episode(params, 11, 100)
+    on_threshold = sum(int((np.minimum(np.abs(v - 0.499), np.abs(v - 0.501)) <= 32 * 2.0 ** -53).sum())
+                       for rec in log for v in rec["decide_fp"])
+    assert on_threshold >= 4
+    ties = test_production_randomness_matches_oracle("small", over, 2, seed=100, first_episode=11)
+    assert 0 <= ties <= 2 * on_threshold + 16   # (env 1 = episode 18 has its own)
 
 
 @pytest.mark.parametrize("k", range(12))
 def test_random_configurations_match_oracle(k):
     """A fixed dozen of the random configurations tools/stress_parity.py sweeps by the hundred (team size, action set, comm range,
-    link failures, altitude lattice, grid size, prior, batch size all drawn at random) through the check above.  17 pixels per
-    footprint is left to the tool: there an area average lands exactly on a class-weight threshold in about one episode of 15."""
+    link failures, altitude lattice, grid size, prior, batch size all drawn at random) through the check above (17 pixels per
+    footprint included: class-weight threshold ties are recognised as such by the comparison itself, see conftest)."""
     import random
     from random_configs import random_case
-    name, over, n_envs, seed, ep0, _, _ = random_case(random.Random(7000 + k), pixels=(12, 13, 14, 16, 18, 19))
-    test_production_randomness_matches_oracle(name, over, min(n_envs, 3), seed=seed, first_episode=ep0, track_area=k % 2 == 0)
+    name, over, n_envs, seed, ep0, _, _ = random_case(random.Random(7000 + k), pixels=(12, 13, 14, 16, 17, 18, 19))   # (11: footprint image < 11 cells)
+    test_production_randomness_matches_oracle(name, over, min(n_envs, 3), seed=seed, first_episode=ep0, track_area=k % 2 == 0,
+                                              fused_step=k % 4 == 3)
 
 
 def _field_checks(got, want, tag):
@@ -350,48 +388,64 @@ def test_saturation_and_deferred_clamp():
     assert_posteriors(env.posterior_local()[0].cpu().numpy(), np.array([a["local_map"] for a in ep.agents]), strict=True, msg="final local")
 
 
-def test_full_size_properties():
-    """BASELINE config 2 size (1024 envs x 4 UAVs x 256^2): size-independent checks."""
+@pytest.mark.parametrize("name,over,E,bench_form", [
+    ("c2", dict(), 1024, False),   # BASELINE config 2 at full size, two plan launches per step (the training sequence), area sums tracked
+    ("c2", dict(), 1024, True),    # ... and exactly as bench.py times it: track_area=False, steps() alone (tile-item fusion)
+    ("c4", dict(), 1024, True),    # config 4's per-GPU shape: 1024 envs x 8 UAVs x 512^2 (9.4 GB of maps, 9-op plans)
+    ("c5", dict(experiment__missions__n_agents=16), 64, True),  # a config 5 batch: 64 envs x 16 UAVs x 1024^2, 27 actions, per-episode comm range
+])
+def test_full_size_properties(name, over, E, bench_form):
+    """Full BASELINE sizes: size-independent checks (the oracle takes seconds per env-step at these shapes)."""
     from ippmarl.vec_env import POLICY_UNIFORM
-    params = make_params("c2")
-    E = 1024
-    env = _env(params, E)
+    params = make_params(name, **over)
+    env = _env(params, E, track_area=not bench_form)
     eps = np.arange(1, E + 1)
-    small = _env(params, 8)
-    pick = np.array([1, 2, 3, 500, 501, 777, 1000, 1024])
+    small = _env(params, 8, track_area=not bench_form)
+    pick = np.array([1, 2, 3, E // 2 - 12, E // 2 - 11, (3 * E) // 4 + 9, E - 24, E])
+    d = env.d
+
+    def episode(e):
+        returns = torch.zeros(e.E, device=e.device)
+        for t in range(d.budget + 1):
+            if not bench_form:
+                e.build_observations(t, features=False)
+            r, _, _ = e.steps(t, policy=POLICY_UNIFORM, features=False)
+            returns += r[:, 0]
+        return returns
+
     small.reset(pick)
     env.reset(eps)
-    returns = torch.zeros(E, device=env.device)
-    for t in range(env.d.budget + 1):
-        env.build_observations(t, features=False)
-        small.build_observations(t, features=False)
-        r, _, _ = env.steps(t, policy=POLICY_UNIFORM, features=False)
-        small.steps(t, policy=POLICY_UNIFORM, features=False)
-        returns += r[:, 0]
-        assert int(env.fault.abs().sum()) == 0
-    # (1) sharding independence: an episode's trajectory does not depend on the batch it runs in (bit-exact)
+    returns = episode(env)
+    small_returns = episode(small)
+    assert int(env.fault.abs().sum()) == 0
+    assert env.counters()["work_list_rejects"] == 0 and small.counters()["work_list_rejects"] == 0
+    # (1) sharding independence: an episode's trajectory does not depend on the batch it runs in -- maps, positions and
+    # measurement codes bit for bit; the returns to the summation order of the float64 reward atomics
     assert torch.equal(env.local[pick - 1], small.local)
     assert torch.equal(env.glob[pick - 1], small.glob)
     assert torch.equal(env.pos[pick - 1], small.pos)
+    assert torch.equal(env.code[pick - 1], small.code)
+    torch.testing.assert_close(returns[pick - 1], small_returns, rtol=1e-6, atol=1e-6)
     # (2) the incrementally maintained weighted entropy T equals a full-grid recomputation
     full = torch.zeros(E, dtype=torch.float64, device=env.device)
     env.ctx.call("ippm_weighted_entropy", env._p(env.glob), None, 1, env._p(full), E, env.stream)
-    torch.testing.assert_close(env.sums[:, 2], full, rtol=1e-6, atol=1e-3)
+    torch.testing.assert_close(env.sums[:, 2], full, rtol=1e-6, atol=1e-3 * (d.grid_x / 256.0) ** 2)
     # (3) beliefs stay finite log-odds; posteriors are probabilities
     assert bool(torch.isfinite(env.local).all()) and bool(torch.isfinite(env.glob).all())
     pg = env.posterior_global()
     assert float(pg.min()) > 0.0 and float(pg.max()) < 1.0
     assert bool(torch.isfinite(returns).all())
+    del pg
     # (4) positions stay on the lattice and inside the world
     p = env.pos.cpu().numpy()
-    assert (p[..., :2] % 5 == 0).all() and p[..., :2].min() >= 0 and p[..., :2].max() <= 50
-    assert set(np.unique(p[..., 2])) <= {5, 10, 15}
+    assert (p[..., :2] % d.spacing == 0).all() and p[..., :2].min() >= 0
+    assert p[..., 0].max() <= d.x_dim_m and p[..., 1].max() <= d.y_dim_m
+    assert set(np.unique(p[..., 2])) <= set(int(z) for z in d.altitudes)
     # (5) determinism: same episodes again -> identical bits
     env.reset(eps)
-    for t in range(env.d.budget + 1):
-        env.build_observations(t, features=False)
-        env.steps(t, policy=POLICY_UNIFORM, features=False)
+    episode(env)
     assert torch.equal(env.glob[pick - 1], small.glob)
+    assert torch.equal(env.local[pick - 1], small.local)
 
 
 def test_td_lambda_and_advantage_kernels(golden):

@@ -59,8 +59,9 @@ def test_actor_and_critic_step_match_reference(golden):
     np.testing.assert_allclose([am[k] for k in ACTOR_TAGS[7:]], fx["actor_metrics"][7:], rtol=3e-2, atol=1e-6)
 
 
-# c2 x 64 envs: BASELINE config 3 at its real grid; c4 x 8 envs: config 4's per-GPU shape (8 UAVs, 512 x 512)
-@pytest.mark.parametrize("name,n_envs", [("small", 6), ("c2", 64), ("c4", 8)])
+# c2 x 64 envs: BASELINE config 3 at its real grid, and c2 x 1024: config 3 at its real size (the round bench.py times:
+# 61 440 transitions per wave); c4 x 8 envs: config 4's per-GPU shape (8 UAVs, 512 x 512)
+@pytest.mark.parametrize("name,n_envs", [("small", 6), ("c2", 64), ("c4", 8), ("c2", 1024)])
 def test_trainer_round_and_td_chains(name, n_envs):
     from ippmarl.trainer import COMATrainer
     params = make_params(name)
@@ -73,16 +74,18 @@ def test_trainer_round_and_td_chains(name, n_envs):
     # TD(lambda) through the kernel == the oracle's literal restatement on each (env, agent) chain
     td, dr = tr.td_targets()
     td = td.view(W, T, E, N).cpu().numpy()
-    states = tr.buf_state[:W].reshape(-1, 11, 11, 12)
-    with torch.no_grad():
-        q, _ = tr.frozen_target(states)
-    q_sel = q.gather(1, tr.buf_action[:W].reshape(-1, 1).long()).view(W, T, E, N).cpu().numpy()
     rew = tr.buf_reward[:W].cpu().numpy()
     g, lam = params["networks"]["gamma"], params["networks"]["lambda"]
     dones = [t == T - 1 for _ in range(W) for t in range(T)]
-    for e in (0, 3, 5):
+    for e in ((0, 3, 5) if E < 100 else (0, 3, 5, E // 2, E // 2 + 1, E - 7, E - 2, E - 1)):   # 8 sampled envs at full size
         for i in (0, N - 1):
-            want, _ = O.td_lambda_targets(rew[:, :, e].reshape(-1), dones, q_sel[:, :, e, i].reshape(-1), g, lam)
+            # Q of this chain's own W * T states, evaluated on their own (not sliced out of one forward pass over the whole
+            # buffer: at 1024 envs that is 131 072 samples whose conv1 activations pass 4 GB, where the library's 32-bit
+            # buffer offsets wrap -- the reason COMATrainer.td_targets feeds the critic 16 384 samples at a time)
+            with torch.no_grad():
+                q, _ = tr.frozen_target(tr.buf_state[:W, :, e, i].reshape(W * T, 11, 11, 12).contiguous())
+            q_sel = q.gather(1, tr.buf_action[:W, :, e, i].reshape(-1, 1).long()).view(-1).cpu().numpy()
+            want, _ = O.td_lambda_targets(rew[:, :, e].reshape(-1), dones, q_sel, g, lam)
             np.testing.assert_allclose(td[:, :, e, i].reshape(-1), want, rtol=2e-5, atol=2e-6)
     assert td[1, 0].max() == 0.0 and td[1, 0].min() == 0.0  # first step of a later episode in the chain
     before = [p.detach().clone() for p in tr.actor.parameters()]
@@ -373,3 +376,18 @@ def test_fused_bias_relu_equals_separate_passes():
         assert set(g0) == set(g1)
         for n in g0:
             torch.testing.assert_close(g1[n], g0[n], rtol=2e-4, atol=2e-5 * float(g0[n].abs().max()), msg=n)
+
+
+def test_forward_pass_over_a_whole_buffer_is_sliced():
+    """131 072 critic states in one call (the whole buffer of a 1024-env round): conv1's activations would pass 4 GB, where the
+    library's 32-bit buffer offsets wrap and samples 85 598.. land on samples 0..; the trunk slices such batches, so the
+    result equals the per-slice evaluation everywhere."""
+    from ippmarl.networks import CriticNetwork
+    torch.manual_seed(3)
+    net = CriticNetwork(make_params("c2")).cuda().eval()
+    x = torch.rand(131072, 11, 11, 12, device="cuda")
+    with torch.no_grad():
+        whole, _ = net(x)
+        for lo in (0, 40000, 85598, 120000):
+            part, _ = net(x[lo:lo + 4096])
+            torch.testing.assert_close(whole[lo:lo + 4096], part, rtol=1e-5, atol=1e-6)

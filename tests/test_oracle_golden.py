@@ -202,7 +202,7 @@ def test_philox_known_answer():
 def test_exact_mode_differs_only_by_reference_quantisation(golden, tag):
     """The oracle's exact-float64 mode (what the GPU path is held to at 1e-5, every cell) against the reference's
     own output: identical integers, and floats that differ only by the reference's float32 map re-quantisation."""
-    from conftest import assert_posteriors
+    from conftest import REFERENCE_QUANTISATION_CELLS as RQ, assert_posteriors
     fx = golden(tag)
     params = make_params(EPISODES[tag]["name"], **EPISODES[tag]["over"])
     d = O.Derived(params)
@@ -218,8 +218,8 @@ def test_exact_mode_differs_only_by_reference_quantisation(golden, tag):
         assert np.array_equal(rec["masks"], fx["masks"][t])
         np.testing.assert_allclose(rec["relative_reward"], fx["rewards"][t, 0], rtol=RTOL, atol=1e-6)
         np.testing.assert_allclose(np.array(rec["observations"]), fx["obs"][t], rtol=RTOL, atol=1e-6)
-    assert_posteriors(np.array([a["local_map"] for a in ep.agents]), fx["final_local"], strict=False, msg="final local")
-    assert_posteriors(ep.global_map, fx["final_global"], strict=False, msg="final global")
+    assert_posteriors(np.array([a["local_map"] for a in ep.agents]), fx["final_local"], strict=False, msg="final local", allow=RQ.get((tag, "final_local"), []))
+    assert_posteriors(ep.global_map, fx["final_global"], strict=False, msg="final global", allow=RQ.get((tag, "final_global"), []))
 
 
 IG_CASES = {"ig_c1_e1": dict(name="c1", over={}), "ig_small3_e4": dict(name="small", over=dict(experiment__missions__n_agents=3))}

@@ -21,7 +21,10 @@ ties = 0
 for k in range(n_cases):
     name, over, n_envs, seed, ep0, n, A = random_case(rng)
     try:
-        check(name, over, n_envs, seed=seed, first_episode=ep0, track_area=k % 4 != 1)   # every fourth case: the untracked kernels
+        # every fourth case: the untracked kernels (tile-item fusion), half of those as steps() alone (bench.py's launch sequence)
+        # (class-weight threshold ties are recognised by the comparison itself -- tests/conftest.py::assert_features_or_ties admits a
+        #  whole-class-weight difference only where the oracle's deciding area average is within 32 ulp of 0.499 / 0.501 -- and counted)
+        ties += check(name, over, n_envs, seed=seed, first_episode=ep0, track_area=k % 4 != 1, fused_step=k % 8 == 5)
         # every third case also through the greedy planner (K9 + K10) -- not above 15 m: the reference's planner divides by the
         # sensor noise, which its sensor model sets to 0 there (ZeroDivisionError in IG_baseline.py, as in the oracle)
         if over.get("mapping__prior", 0.5) == 0.5 and k % 3 == 0 and over.get("experiment__constraints__max_altitude", 15) <= 15:
@@ -31,17 +34,7 @@ for k in range(n_cases):
         if "footprint image smaller than 11 cells" in msg:   # a documented restriction: footprint images are only ever shrunk to 11 x 11
             print(f"case {k}: skipped ({exc})", flush=True)
             continue
-        # The class-weight planes are discontinuous at p = 0.499 / 0.501.  With small integer grids an area average can land on a
-        # threshold EXACTLY in rational arithmetic (0.5 + 0.125 k / N = 0.501); which side it falls on is then decided by the last
-        # bit of whoever computes it (cv2 in the reference, float64 in the oracle, integer counts + one float here): a lone
-        # element off by a whole class weight is that tie, not a defect.  Counted and shown, not hidden.
-        import re
-        m = re.search(r"Mismatched elements: (\d+) / (\d+)", msg)
-        if m and int(m.group(1)) <= 2 and ("0.4999" in msg or "0.99999" in msg):
-            ties += 1
-            print(f"case {k}: threshold tie in a class-weight plane ({m.group(0)}): {over}", flush=True)
-            continue
         raise
     print(f"case {k}: {name} px={over.get('sensor__pixel__number_x', '-')} prior={over.get('mapping__prior', 0.5)} N={n} A={A} range={over['experiment__uav__communication_range']} fail={over['experiment__uav__failure_rate']} "
           f"fix={over['experiment__uav__fix_range']} envs={n_envs} ok ({time.time() - t0:.0f}s)", flush=True)
-print("all", n_cases, "cases match the oracle;", ties, "of them up to one threshold tie")
+print("all", n_cases, "cases match the oracle;", ties, "feature elements sat on a proven class-weight threshold tie")
