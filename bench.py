@@ -401,19 +401,29 @@ def main():
             torch.cuda.empty_cache()
             per_episode = T * N
             ref_envs = max(1, -(-params["networks"]["batch_size"] * params["networks"]["batch_number"] // per_episode))
-            tr = COMATrainer(params, ref_envs, device=device, philox_seed=3, terrain=args.terrain)
+            tr = COMATrainer(params, ref_envs, device=device, philox_seed=3, terrain=args.terrain, graphs=True)
             tr.rollout("train")
             tr.update()
             torch.cuda.synchronize()
-            rounds = 5
-            c0 = time.perf_counter()
-            for _ in range(rounds):
-                tr.rollout("train")
-                stats = tr.update()
-            torch.cuda.synchronize()
-            cdt = time.perf_counter() - c0
-            coma["reference_sized_round"] = {"updates_per_s": rounds / cdt, "transitions_per_update": stats["transitions"],
-                                             "envs": ref_envs, "adam_steps_per_update": stats["adam_steps"]}
+
+            def timed_rounds(rounds):
+                c0 = time.perf_counter()
+                for _ in range(rounds):
+                    tr.rollout("train")
+                    st = tr.update()
+                torch.cuda.synchronize()
+                return rounds / (time.perf_counter() - c0), st
+
+            eager_rate, _ = timed_rounds(5)
+            # this round is ~3000 launches of a few microseconds each: recorded into hipGraphs (16 rollout-step graphs + one graph
+            # of the whole update: TD targets and the 25 + 25 Adam steps), it runs at the kernels' pace instead of Python's
+            tr.capture_graphs()
+            timed_rounds(2)
+            rate, stats = timed_rounds(20)
+            coma["reference_sized_round"] = {"updates_per_s": rate, "updates_per_s_eager": eager_rate,
+                                             "transitions_per_update": stats["transitions"], "envs": ref_envs,
+                                             "adam_steps_per_update": stats["adam_steps"],
+                                             "hip_graphs": "16 rollout-step graphs + 1 update graph per round (COMATrainer.capture_graphs)"}
     if rank == 0:
         total_steps = E * N * args.steps * world
         is_c1 = (N, grid[0], E) == (4, 256, 1024)

@@ -89,7 +89,11 @@ typedef struct ippm_config {
   float logit_meas[IPPM_MAX_Z][2];    /* ln(y/(1-y)) in float32 for y = f32(round(noise,3)), f32(round(1-noise,3)) */
   float meas_value[IPPM_MAX_Z][2];    /* the two measurement values themselves (simulations.py:47-51) */
   uint32_t flip_threshold[IPPM_MAX_Z];/* observation flipped iff philox word < threshold = floor(noise*2^32) */
-  float prior;                        /* mapping.prior; != 0.5 takes the explicit full-grid slow path of the fusion */
+  float prior;                        /* mapping.prior; != 0.5 takes the explicit full-grid slow path of the fusion.
+                                         Stated tolerances off the default (DESIGN.md sections 3, 7; the host binding warns once):
+                                         prior != 0.5: posteriors 5e-5 (99.99 % of cells 1e-5), rewards / sums 5e-5;
+                                         altitudes outside {5, 10, 15} m (noise-free sensor): rewards 2e-4 when area sums are
+                                         tracked (float32 lane sums of the row walker), 1e-5 in the env-only tile form */
   float clip_lo, clip_hi;             /* 1e-4, 0.9999 (mappings.py:110-111, state.py:119-120) */
   float logit_prior;                  /* ln(prior/(1-prior)); 0 for the default prior 0.5 */
   float logit_clip;                   /* ln(clip_hi/(1-clip_hi)) = 9.21024...; the clip is symmetric in log-odds */

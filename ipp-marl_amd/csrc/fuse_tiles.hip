@@ -41,7 +41,10 @@ struct TileCtx {
 };
 
 struct TileAcc {   // per wavefront, over all its items (all of one env)
-  float a1, aD;    // sum w(a) (H(b) - H(a)) and sum (w(a) - w(b)) H(b); the increment of T = sum w H is aD - a1
+  // sum w(a) (H(b) - H(a)) and sum (w(a) - w(b)) H(b); the increment of T = sum w H is aD - a1.  float64 per lane, fed with the
+  // float32 sum of a slot's four cells: where measurements are noise-free the terms are of size 1 with both signs and the sums
+  // are what is left after they cancel -- float32 lane sums over a few dozen cells showed at 2e-4 in the returns there
+  double a1, aD;
   unsigned cells_l, ops_l, cells_g, ops_g;
 };
 
@@ -197,12 +200,15 @@ __device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e,
         wsum += wa[j] + wb[j];
       }
       if (__any(wsum != 0.f)) {
+        float s1 = 0.f, sD = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float hb = ippm_entropy_l(mv[q].v[j], w.lc), ha = ippm_entropy_l(out[j], w.lc);
-          acc.a1 += wa[j] * (hb - ha);
-          acc.aD += (wa[j] - wb[j]) * hb;
+          s1 += wa[j] * (hb - ha);
+          sD += (wa[j] - wb[j]) * hb;
         }
+        acc.a1 += (double)s1;
+        acc.aD += (double)sD;
       }
     }
   }
@@ -243,7 +249,7 @@ k_fuse_tiles(const ippm_config* __restrict__ c, float* __restrict__ local, float
   w.lc = c->logit_clip; w.wt = c->logit_weight_thr;
   w.lane = lane;
   TileAcc acc;
-  acc.a1 = acc.aD = 0.f;
+  acc.a1 = acc.aD = 0.0;
   acc.cells_l = acc.ops_l = acc.cells_g = acc.ops_g = 0;
   for (int i = first; i < count; i += step) {
     const int4 nx = items[min(i + step, env_cap - 1)];  // the next item travels while this one is worked on
@@ -264,7 +270,7 @@ k_fuse_tiles(const ippm_config* __restrict__ c, float* __restrict__ local, float
   // the wavefront's reward terms and work counters: one atomic per quantity
   const float cl = ippm_wave_sum((float)acc.cells_l), ol = ippm_wave_sum((float)acc.ops_l);
   const float cg = ippm_wave_sum((float)acc.cells_g), og = ippm_wave_sum((float)acc.ops_g);
-  double a1 = (double)acc.a1, aD = (double)acc.aD;   // the 64 lane sums are added up in float64
+  double a1 = acc.a1, aD = acc.aD;
   if (cg > 0.f) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { a1 += __shfl_xor(a1, o, 64); aD += __shfl_xor(aD, o, 64); }

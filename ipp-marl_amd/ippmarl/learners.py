@@ -13,8 +13,17 @@ import torch
 from . import _ffi
 
 
+def _adam(parameters, lr: float, capturable: bool):
+    """Adam as the reference configures it (actor/learner.py:27, critic/learner.py:37).  ``capturable`` (hipGraph rounds): the
+    step counter lives on the device and the whole update of a net is ONE fused kernel instead of ~10 multi-tensor launches per
+    step -- the recorded round is nothing but small launches, so their number is its duration."""
+    if capturable:
+        return torch.optim.Adam(parameters, lr=lr, capturable=True, fused=True)
+    return torch.optim.Adam(parameters, lr=lr)
+
+
 class CriticLearner:
-    def __init__(self, params: Dict, critic, device):
+    def __init__(self, params: Dict, critic, device, capturable: bool = False):
         self.params = params
         self.critic = critic.to(device)
         self.device = device
@@ -25,7 +34,8 @@ class CriticLearner:
         self.lr = net["critic"]["learning_rate"]
         self.target_update_mode = net["critic"]["target_update_mode"]
         self.tau = net["critic"]["tau"]
-        self.optimizer = torch.optim.Adam(self.critic.parameters(), lr=self.lr)
+        # capturable: the step count lives on the device, so that optimizer steps can be recorded into a hipGraph (trainer.capture_graphs)
+        self.optimizer = _adam(self.critic.parameters(), self.lr, capturable)
         self.optimizer.zero_grad()
         self.collect = False   # keep the tensors ippmarl.metrics.critic_metrics needs in self.last
         self.last = None
@@ -73,14 +83,14 @@ class CriticLearner:
 
 
 class ActorLearner:
-    def __init__(self, params: Dict, actor, device, ctx: Optional[_ffi.Context] = None):
+    def __init__(self, params: Dict, actor, device, ctx: Optional[_ffi.Context] = None, capturable: bool = False):
         self.params = params
         self.actor = actor.to(device)
         self.device = device
         self.ctx = ctx
         self.n_actions = params["experiment"]["constraints"]["num_actions"]
         self.lr = params["networks"]["actor"]["learning_rate"]
-        self.optimizer = torch.optim.Adam(self.actor.parameters(), lr=self.lr)
+        self.optimizer = _adam(self.actor.parameters(), self.lr, capturable)
         self.optimizer.zero_grad()
         self.collect = False
         self.last = None

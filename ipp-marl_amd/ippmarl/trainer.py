@@ -22,7 +22,7 @@ from .vec_env import VecEnv, POLICY_ARGMAX, POLICY_SAMPLE
 class COMATrainer:
     def __init__(self, params: Dict, n_envs: int, device: str = "cuda:0", philox_seed: int = 3, waves_per_update: int = 1,
                  quirks: str = "reference", rank: int = 0, world: int = 1, first_episode: int = 1,
-                 terrain: str = "split"):
+                 terrain: str = "split", graphs: bool = False):
         self.params = params
         self.env = VecEnv(params, n_envs, device=device, philox_seed=philox_seed, terrain=terrain)
         self.device = self.env.device
@@ -39,8 +39,13 @@ class COMATrainer:
         # the reference builds TD targets with a deepcopy of the critic taken at construction that is
         # never synchronised; quirks="fixed" uses the learner's synchronised target network instead
         self.frozen_target = copy.deepcopy(self.critic).to(self.device).eval()
-        self.actor_learner = ActorLearner(params, self.actor, self.device, ctx=self.env.ctx)
-        self.critic_learner = CriticLearner(params, self.critic, self.device)
+        # graphs: the round is launch-bound at small env counts (the reference's own 5 episodes per round: ~3000 launches of a
+        # few microseconds of work each, Python between them); capture_graphs() records every rollout step and the whole update
+        # into hipGraphs.  The optimizers then keep their step counters on the device.
+        self.graphs = bool(graphs)
+        self._step_graphs = self._update_graph = None
+        self.actor_learner = ActorLearner(params, self.actor, self.device, ctx=self.env.ctx, capturable=self.graphs)
+        self.critic_learner = CriticLearner(params, self.critic, self.device, capturable=self.graphs)
         for m in (self.actor, self.critic, self.critic_learner.target_critic, self.frozen_target):
             broadcast_module(m)
         # gradients of both nets live in one flat buffer (critic, then actor): the data-parallel average is one all-reduce of a
@@ -57,6 +62,9 @@ class COMATrainer:
         self.filled = 0        # waves currently in the buffer
         self.train_step = 0
         self.eps = epsilon_schedule(params, 0)
+        self.eps_dev = torch.full((), float(self.eps), dtype=torch.float32, device=dev)   # epsilon as the graphs read it
+        self.ret = torch.zeros(E, device=dev)
+        self.abs_ret = torch.zeros(E, device=dev)
         self.keep_rollout_log = False
         self.last_rollout = None
         self.last_diagnostics = None
@@ -68,25 +76,18 @@ class COMATrainer:
         eps_ids = episode_ids(self.first_episode, self.wave, self.E, self.rank, self.world)
         # the reference anneals epsilon with the episode index (actor/network.py:53-58); one wave = E episodes
         self.eps = epsilon_schedule(self.params, int(eps_ids[0]))
+        self.eps_dev.fill_(float(self.eps))
         env.reset(eps_ids)
         w = self.filled
-        ret = torch.zeros(self.E, device=self.device)
-        abs_ret = torch.zeros(self.E, device=self.device)
+        ret, abs_ret = self.ret.zero_(), self.abs_ret.zero_()
         policy = POLICY_ARGMAX if mode == "eval" else POLICY_SAMPLE
         step_rewards, step_actions, step_altitudes = [], [], []
+        replay = self._step_graphs is not None and mode == "train" and w == 0 and not self.keep_rollout_log
         for t in range(self.T):
-            obs = env.build_observations(t)
-            with torch.no_grad():
-                probs, _ = self.actor(obs.view(self.E * self.N, 11, 11, 7), self.eps)
-            reward, done, state = env.steps(t, policy=policy, probs=probs.view(self.E, self.N, self.A))
-            if mode == "train":
-                self.buf_obs[w, t].copy_(obs)
-                self.buf_state[w, t].copy_(state)
-                self.buf_action[w, t].copy_(env.action)
-                self.buf_mask[w, t].copy_(env.mask)
-                self.buf_reward[w, t].copy_(reward[:, 0])
-            ret += reward[:, 0]
-            abs_ret += reward[:, 1]
+            if replay:
+                self._step_graphs[t].replay()
+                continue
+            reward = self._rollout_step(t, w, policy, mode == "train", self.eps_dev if self.graphs else self.eps)
             if self.keep_rollout_log:
                 step_rewards.append(reward[:, 0].clone())
                 step_actions.append(env.action.clone())
@@ -100,6 +101,60 @@ class COMATrainer:
             self.filled += 1
         return {"episode_return": float(ret.mean()), "absolute_return": float(abs_ret.mean()), "eps": self.eps,
                 "faults": int(env.fault.ne(0).sum())}
+
+    def _rollout_step(self, t: int, w: int, policy: int, store: bool, eps):
+        """One lock-step env step of all E envs: observations -> actor -> move + sense (+ the transition into the buffer)."""
+        env = self.env
+        obs = env.build_observations(t)
+        with torch.no_grad():
+            probs, _ = self.actor(obs.view(self.E * self.N, 11, 11, 7), eps)
+        reward, done, state = env.steps(t, policy=policy, probs=probs.view(self.E, self.N, self.A))
+        if store:
+            self.buf_obs[w, t].copy_(obs)
+            self.buf_state[w, t].copy_(state)
+            self.buf_action[w, t].copy_(env.action)
+            self.buf_mask[w, t].copy_(env.mask)
+            self.buf_reward[w, t].copy_(reward[:, 0])
+        self.ret += reward[:, 0]
+        self.abs_ret += reward[:, 1]
+        return reward
+
+    def capture_graphs(self):
+        """Records the launch-bound round into hipGraphs: one graph per rollout step t of a training wave (the step number is an
+        argument of several kernels, everything else -- episode numbers, epsilon, every array -- is read from fixed device
+        buffers) and one graph for the whole update (TD targets + data_passes x batch_number minibatch steps of both nets, the
+        minibatch permutations read from a fixed buffer that update() refills).  Needs one eager round first (MIOpen's kernel
+        selection, allocator warm-up); waves_per_update = 1, hard target updates, one rank."""
+        if not self.graphs:
+            raise _ffi.IppmError("COMATrainer(graphs=True) is needed: captured optimizer steps keep their counters on the device")
+        if self.waves_per_update != 1 or self.world != 1 or self.critic_learner.target_update_mode != "hard":
+            raise _ffi.IppmError("capture_graphs: one wave per update, one rank and hard target updates only")
+        env = self.env
+        env.profile = False
+        torch.cuda.synchronize(self.device)
+        saved = {k: getattr(env, k).clone() for k in ("local", "glob", "ws", "sums", "pos", "pos_pre", "comm", "mask", "action", "fault",
+                                                       "reward", "area", "rect", "rect_next", "code", "work")}
+        stream = torch.cuda.Stream(device=self.device)
+        graphs = []
+        for t in range(self.T):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream):
+                self._rollout_step(t, 0, POLICY_SAMPLE, True, self.eps_dev)
+            graphs.append(g)
+        n = self.T * self.E * self.N
+        self._perms = torch.stack([torch.randperm(n, device=self.device) for _ in range(self.data_passes)])
+        self._loss_out = torch.zeros(2, device=self.device)
+        filled, self.filled = self.filled, 1
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            closs, aloss = self._update_compute(self._perms, self.eps_dev, False)
+            self._loss_out[0].copy_(closs)
+            self._loss_out[1].copy_(aloss)
+        self.filled = filled
+        torch.cuda.synchronize(self.device)
+        for k, v in saved.items():   # capture does not execute; keep the env's state untouched in any case
+            getattr(env, k).copy_(v)
+        self._step_graphs, self._update_graph = graphs, g
 
     # ------------------------------------------------------------------------------------------------
     def td_targets(self):
@@ -136,6 +191,29 @@ class COMATrainer:
         W, T, E, N = self.filled, self.T, self.E, self.N
         assert W > 0, "update() needs at least one rollout wave"
         n = W * T * E * N
+        if self._update_graph is not None and W == 1 and not diagnostics:
+            # the recorded round: hard target copy (a host-side decision) first, fresh permutations into the graph's buffer, replay
+            self.critic_learner.update_target_network(self.train_step, 0)
+            for dp in range(self.data_passes):
+                self._perms[dp].copy_(torch.randperm(n, device=self.device))
+            self._update_graph.replay()
+            self.train_step += 1
+            self.filled = 0
+            closs, aloss = self._loss_out.tolist()
+            return {"critic_loss": closs, "actor_loss": aloss, "transitions": n * self.world,
+                    "adam_steps": 2 * self.data_passes * self.batch_number, "train_step": self.train_step}
+        closs, aloss = self._update_compute(None, self.eps_dev if self.graphs else self.eps, diagnostics)
+        self.filled = 0
+        return {"critic_loss": float(closs), "actor_loss": float(aloss), "transitions": n * self.world,
+                "adam_steps": 2 * self.data_passes * self.batch_number, "train_step": self.train_step}
+
+    def _update_compute(self, perms, eps, diagnostics: bool):
+        """The arithmetic of one round.  ``perms`` None: eager (draws the minibatch permutations, syncs the target network and
+        counts train steps as it goes); a [data_passes, n] tensor: the form capture_graphs records (those host-side pieces are
+        done by update() around the replay)."""
+        W, T, E, N = self.filled, self.T, self.E, self.N
+        n = W * T * E * N
+        eager = perms is None
         td, dr = self.td_targets()
         obs = self.buf_obs[:W].reshape(n, 11, 11, 7)
         states = self.buf_state[:W].reshape(n, 11, 11, 12)
@@ -144,8 +222,9 @@ class COMATrainer:
         bs = n // self.batch_number
         closs = aloss = torch.zeros((), device=self.device)
         for data_pass in range(self.data_passes):
-            perm = torch.randperm(n, device=self.device)
-            self.critic_learner.update_target_network(self.train_step, data_pass)
+            perm = torch.randperm(n, device=self.device) if eager else perms[data_pass]
+            if eager:
+                self.critic_learner.update_target_network(self.train_step, data_pass)
             collect = diagnostics and data_pass == 0
             self.critic_learner.collect = self.actor_learner.collect = collect
             crit_rec, act_rec = [], []
@@ -160,7 +239,7 @@ class COMATrainer:
             for b in range(self.batch_number):
                 if collect:
                     crit_rec.append(dict(self.critic_learner.last, discounted=dr[idx[b]]))
-                aloss, _ = self.actor_learner.backward(obs[idx[b]], actions[idx[b]], masks[idx[b]], q_b, self.eps)
+                aloss, _ = self.actor_learner.backward(obs[idx[b]], actions[idx[b]], masks[idx[b]], q_b, eps)
                 if collect:
                     act_rec.append(self.actor_learner.last)
                 if b + 1 < self.batch_number:
@@ -174,15 +253,13 @@ class COMATrainer:
             if collect:
                 from . import metrics
                 with torch.no_grad():
-                    after = [self.actor(obs[perm[b * bs:(b + 1) * bs]], self.eps)[0] for b in range(self.batch_number)]
+                    after = [self.actor(obs[perm[b * bs:(b + 1) * bs]], eps)[0] for b in range(self.batch_number)]
                 self.last_diagnostics = dict(metrics.critic_metrics(crit_rec, self.critic))
                 self.last_diagnostics.update(metrics.actor_metrics(act_rec, self.actor, after))
                 self.critic_learner.collect = self.actor_learner.collect = False
-            if data_pass == 0:
+            if data_pass == 0 and eager:
                 self.train_step += 1
-        self.filled = 0
-        return {"critic_loss": float(closs), "actor_loss": float(aloss), "transitions": n * self.world,
-                "adam_steps": 2 * self.data_passes * self.batch_number, "train_step": self.train_step}
+        return closs, aloss
 
     def train(self, n_updates: int, log=None):
         history = []

@@ -391,3 +391,50 @@ def test_forward_pass_over_a_whole_buffer_is_sliced():
         for lo in (0, 40000, 85598, 120000):
             part, _ = net(x[lo:lo + 4096])
             torch.testing.assert_close(whole[lo:lo + 4096], part, rtol=1e-5, atol=1e-6)
+
+
+def test_recorded_round_equals_eager_round():
+    """COMATrainer.capture_graphs(): a round replayed from hipGraphs (16 rollout-step graphs + one graph of TD targets and the
+    25 + 25 Adam steps) is the round run launch by launch: the rollout bit for bit (transitions, maps); the weights as closely
+    as two launch-by-launch runs agree with each other (the gradient kernels sum with float atomics, so even those differ in the
+    last bits, and Adam's normalised step turns a last-bit change of a near-zero gradient into a visible one)."""
+    from ippmarl.trainer import COMATrainer
+    params = make_params("small")
+
+    def trainer():
+        torch.manual_seed(11)
+        return COMATrainer(params, n_envs=5, first_episode=3, graphs=True)
+
+    eager, eager2, rec = trainer(), trainer(), trainer()
+    trio = (eager, eager2, rec)
+    for tr in trio:   # first round launch by launch on all (kernel selection, allocator)
+        torch.manual_seed(12)
+        tr.rollout("train")
+        tr.update()
+    rec.capture_graphs()
+
+    def flat(net):
+        return torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+
+    for rnd in range(2):
+        before = flat(eager.actor).clone(), flat(eager.critic).clone()
+        bufs = []
+        for tr in trio:
+            torch.manual_seed(20 + rnd)   # the minibatch permutations
+            s = tr.rollout("train")
+            assert s["faults"] == 0
+            bufs.append({k: getattr(tr, k).clone() for k in ("buf_obs", "buf_state", "buf_action", "buf_mask", "buf_reward")})
+            stats = tr.update()
+            assert stats["adam_steps"] == 50 and np.isfinite(stats["critic_loss"]) and np.isfinite(stats["actor_loss"])
+        if rnd == 0:   # (from the second round on the three weight sets differ in their last bits, and so do the rollouts)
+            for k in bufs[0]:
+                assert torch.equal(bufs[0][k], bufs[2][k]), k
+            assert torch.equal(eager.env.local, rec.env.local) and torch.equal(eager.env.glob, rec.env.glob)
+        for net, b in (("actor", before[0]), ("critic", before[1])):
+            e1, e2, r = flat(getattr(eager, net)), flat(getattr(eager2, net)), flat(getattr(rec, net))
+            moved = float((e1 - b).norm())
+            assert moved > 0
+            d_ee, d_er = float((e1 - e2).norm()), float((e1 - r).norm())
+            # (a wrong permutation, a missed step or a stale buffer would put d_er at the size of `moved` itself)
+            assert d_er <= max(10.0 * d_ee, 5e-2 * moved), (rnd, net, d_er, d_ee, moved)
+    assert eager.train_step == rec.train_step == 3
