@@ -89,11 +89,12 @@ typedef struct ippm_config {
   float logit_meas[IPPM_MAX_Z][2];    /* ln(y/(1-y)) in float32 for y = f32(round(noise,3)), f32(round(1-noise,3)) */
   float meas_value[IPPM_MAX_Z][2];    /* the two measurement values themselves (simulations.py:47-51) */
   uint32_t flip_threshold[IPPM_MAX_Z];/* observation flipped iff philox word < threshold = floor(noise*2^32) */
-  float prior;                        /* mapping.prior; != 0.5 takes the explicit full-grid slow path of the fusion.
-                                         Stated tolerances off the default (DESIGN.md sections 3, 7; the host binding warns once):
-                                         prior != 0.5: posteriors 5e-5 (99.99 % of cells 1e-5), rewards / sums 5e-5;
-                                         altitudes outside {5, 10, 15} m (noise-free sensor): rewards 2e-4 when area sums are
-                                         tracked (float32 lane sums of the row walker), 1e-5 in the env-only tile form */
+  float prior;                        /* mapping.prior; != 0.5 takes the explicit full-grid path of the fusion (every message shifts
+                                         every cell; chain in float64 registers, one rounding per fusion: maps and returns at 1e-5
+                                         like the default).  Stated tolerance off the default (the host binding
+                                         warns once): altitudes outside {5, 10, 15} m (noise-free sensor): returns 2e-4 when area
+                                         sums are tracked or prior != 0.5 (float32 lane sums of the row walker), 1e-5 in the
+                                         env-only tile form */
   float clip_lo, clip_hi;             /* 1e-4, 0.9999 (mappings.py:110-111, state.py:119-120) */
   float logit_prior;                  /* ln(prior/(1-prior)); 0 for the default prior 0.5 */
   float logit_clip;                   /* ln(clip_hi/(1-clip_hi)) = 9.21024...; the clip is symmetric in log-odds */
@@ -104,6 +105,8 @@ typedef struct ippm_config {
   double gamma, lambda_;              /* TD(lambda) (batch_memory.py:17-21) */
   float logit_noise[IPPM_MAX_Z];      /* ln((1-noise)/noise) from the float64 noise level: the hypothetical updates of
                                          IG_baseline.get_individual_ig use the scalar noise, not a float32 measurement */
+  double logit_prior_f64;             /* ln(prior/(1-prior)) in float64, as mappings.py:114 forms it from the Python float: the
+                                         whole-grid path of prior != 0.5 runs its chain in float64 registers */
 } ippm_config;
 
 typedef struct ippm_ctx ippm_ctx;

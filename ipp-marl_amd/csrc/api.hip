@@ -79,9 +79,12 @@ extern "C" int ippm_ctx_create(const ippm_config* cfg, ippm_ctx** out) {
   ippm_ctx* ctx = new ippm_ctx();
   std::memset(ctx, 0, sizeof(*ctx));
   ctx->cfg = c;
-  // 16-byte lane groups need a grid that is a multiple of 4 wide; the area sums additionally want a 4-cell group to span at
-  // most two of the 11 column bins (grid_y >= 44).  Everything else takes the one-cell-per-lane instantiations.
-  ctx->vec = (c.grid_y % 4 == 0 && c.grid_y >= 4 * IPPM_FEAT) ? 4 : 1;
+  // 16-byte lane groups (4 grid-aligned cells of a row) for every grid whose 4-cell groups span at most two of the 11 column
+  // bins of the area sums (grid_y >= 44); narrower grids take the one-cell-per-lane instantiations.  The grid need not be a
+  // multiple of 4 wide: rows then start at addresses that are only 4-byte aligned (gfx950 serves 16-byte accesses there,
+  // tools/probe/unaligned_probe.cpp), the last group of a row hangs over into the next row and is stored cell by cell, and a
+  // group's four Philox words / truth bits straddle two counter values / two bytes (the reference's default 493 x 493).
+  ctx->vec = (c.grid_y >= 4 * IPPM_FEAT) ? 4 : 1;
   // tuning knobs are read once, here: the size of the caller's work buffer, the plan kernel's item layout and the fusion launch
   // all follow from them, and a value that changed between two calls would make them disagree
   auto knob = [](const char* name, int dflt) { const char* v = getenv(name); return v && *v ? atoi(v) : dflt; };

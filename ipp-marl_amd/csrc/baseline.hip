@@ -28,7 +28,11 @@ __device__ __forceinline__ void ig_action_offset(int A, int a, int s, int& dx, i
 __device__ __forceinline__ float ig_entropy_from_e(float a, float e, float& rd) {  // H of |L| = a, e = exp(-a); rd = 1/(1+e)
   const float d = 1.0f + e;
   rd = __builtin_amdgcn_rcpf(d);
-  return __log2f(d) + (a * 1.44269504f) * (e * rd);
+  // log2(1 + e): for a saturated cell e = 1e-4, and 1 + e rounded to float32 keeps only three digits of e -- the series
+  // log2(e_) (e - e^2/2 + e^3/3 - e^4/4) below 2^-6 (remainder < 2e-10) keeps them all.  It matters here and not in the reward
+  // terms: a candidate over cells that are all saturated has a gain made of nothing but such entropies' differences.
+  const float lg = e < 0.015625f ? e * (1.44269504f + e * (-0.72134752f + e * (0.48089835f - 0.36067376f * e))) : __log2f(d);
+  return lg + (a * 1.44269504f) * (e * rd);
 }
 __device__ __forceinline__ float ig_cell(float l, float ln, float kp, float km, float ec, float lc, float wt) {
   const float a = fabsf(l), e = __expf(-a), re = __builtin_amdgcn_rcpf(e);
@@ -37,6 +41,8 @@ __device__ __forceinline__ float ig_cell(float l, float ln, float kp, float km, 
   float rd;
   const float hh = ig_entropy_from_e(a, e, rd);
   const float pb = pos ? rd : e * rd;                  // sigmoid(l)
+  const float qb = pos ? e * rd : rd;                  // 1 - sigmoid(l), formed directly: `1.f - pb` of a saturated cell (pb = 0.9999)
+                                                       // keeps 3 digits, and its branch then carries the whole gain of the cell
   const float l1 = l + ln, l0 = l - ln;
   // exp(-|l +- ln|), floored at exp(-clip) like the entropy's clipped argument
   const float e1 = fmaxf(l1 >= 0.f ? en * km : ep * kp, ec), e0 = fmaxf(l0 >= 0.f ? en * kp : ep * km, ec);
@@ -46,7 +52,7 @@ __device__ __forceinline__ float ig_cell(float l, float ln, float kp, float km, 
   const float s1 = l1 >= 0.f ? rd1 : e1 * rd1, s0 = l0 >= 0.f ? rd0 : e0 * rd0;
   const float cw1 = l1 > wt ? 1.f : (l1 < -wt ? 0.f : s1);
   const float cw0 = l0 > wt ? 1.f : (l0 < -wt ? 0.f : s0);
-  return pb * (hh - h1) * cw1 + (1.f - pb) * (hh - h0) * cw0;
+  return pb * (hh - h1) * cw1 + qb * (hh - h0) * cw0;
 }
 
 // K9: one workgroup per (env, agent, action)
@@ -69,7 +75,7 @@ k_ig_candidates(const ippm_config* __restrict__ c, const float* __restrict__ loc
   const float kp = __expf(ln), km = __expf(-ln), ec = __expf(-c->logit_clip);
   const float lc = c->logit_clip, wt = c->logit_weight_thr;
   const float* map = local + (size_t)(e * n + i) * gx * gy;
-  const bool vec = (gy & 3) == 0;
+  const bool vec = gy >= 4;   // 16-byte groups at any row alignment; a row's last group is read cell by cell
   const int y0 = vec ? (yu & ~3) : yu;
   const int step = vec ? 4 : 1;
   const int groups = (yd - y0 + step - 1) / step;
@@ -79,15 +85,15 @@ k_ig_candidates(const ippm_config* __restrict__ c, const float* __restrict__ loc
     const int row = idx / groups, gi = idx - row * groups;
     const int x = xl + row, y = y0 + gi * step;
     float v[4];
-    if (vec) { const float4 t = *reinterpret_cast<const float4*>(map + (size_t)x * gy + y); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    if (vec && y + 4 <= gy) { const float4 t = *reinterpret_cast<const float4*>(map + (size_t)x * gy + y); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    else if (vec) { for (int q = 0; q < 4; ++q) v[q] = y + q < gy ? map[(size_t)x * gy + y + q] : 0.f; }
     else v[0] = map[(size_t)x * gy + y];
-    float part = 0.f;
     for (int q = 0; q < step; ++q) {
       if (y + q < yu || y + q >= yd) continue;
-      // IG_baseline.py:236-268 in log-odds: belief clipped once, hypothetical posteriors L +- ln
-      part += ig_cell(ippm_clampl(v[q], lc), ln, kp, km, ec, lc, wt);
+      // IG_baseline.py:236-268 in log-odds: belief clipped once, hypothetical posteriors L +- ln.  Every cell goes into the
+      // float64 sum on its own: a float32 partial over the group showed at 2e-5 on a candidate whose gain nearly cancels
+      acc += (double)ig_cell(ippm_clampl(v[q], lc), ln, kp, km, ec, lc, wt);
     }
-    acc += (double)part;
   }
   // deterministic block reduction in float64
   __shared__ double s[256];

@@ -222,8 +222,8 @@ k_sense_update(const ippm_config* __restrict__ c, const int64_t* __restrict__ ep
         tw[u] = 0; fw[u] = 0;
         if (rr < r1) {
           const size_t cell = (size_t)(xl + rr) * gy + y;
-          m[u] = load_cells<VEC>(map + cell);
-          tw[u] = VEC == 4 ? ippm_truth4(tr, cell) : ippm_truth1(tr, cell);
+          m[u] = load_cells_row<VEC>(map + (size_t)(xl + rr) * gy, y, gy);
+          tw[u] = VEC == 4 ? ippm_truth4(tr, cell, ippm_truth_bytes(gx, gy)) : ippm_truth1(tr, cell);
           if (fl) fw[u] = load_bits<VEC>(fl, rr, y - tile_y0, S);
         }
       }
@@ -232,8 +232,8 @@ k_sense_update(const ippm_config* __restrict__ c, const int64_t* __restrict__ ep
         const int rr = row + u * stride;
         if (rr >= r1) continue;
         const size_t cell = (size_t)(xl + rr) * gy + y;
-        Philox4 ph;
-        if (!fl && VEC == 4) ph = ippm_philox((uint32_t)(cell >> 2), (uint32_t)ep, sw, (uint32_t)(ep >> 32), k0, k1);
+        uint32_t phbits = 0;
+        if (!fl && VEC == 4) phbits = philox_flip_bits4((uint32_t)cell, (uint32_t)ep, sw, (uint32_t)(ep >> 32), k0, k1, thr, (gy & 3) != 0);
         uint32_t cw = 0;
         float d[VEC];
 #pragma unroll
@@ -242,7 +242,7 @@ k_sense_update(const ippm_config* __restrict__ c, const int64_t* __restrict__ ep
           const bool in = (unsigned)(y + q - yu) < (unsigned)w;
           uint32_t flip;
           if (fl) flip = (fw[u] >> q) & 1u;
-          else if (VEC == 4) flip = ph.v[q] < thr ? 1u : 0u;
+          else if (VEC == 4) flip = (phbits >> q) & 1u;
           else {
             Philox4 p1 = ippm_philox((uint32_t)((cell + q) >> 2), (uint32_t)ep, sw, (uint32_t)(ep >> 32), k0, k1);
             flip = p1.v[(cell + q) & 3] < thr ? 1u : 0u;
@@ -256,7 +256,7 @@ k_sense_update(const ippm_config* __restrict__ c, const int64_t* __restrict__ ep
           cw |= (in ? obs : 0u) << q;
           if (TRACK) d[q] = in ? sigmoid_diff(l, old) : 0.f;
         }
-        store_cells<VEC>(map + cell, m[u]);
+        store_cells_row<VEC>(map + (size_t)(xl + rr) * gy, y, gy, m[u]);
         store_bits<VEC>(cd, rr, y - tile_y0, S, cw);
         if (TRACK) area_row<VEC>(acc, s_area, ac, xl + rr, gx, inv_gx, d);
       }
@@ -327,6 +327,7 @@ k_sense_tiles(const ippm_config* __restrict__ c, const int64_t* __restrict__ epi
   const float lc = c->logit_clip;
   const int y0 = yu & ~(VEC - 1), tile_y0 = yu & ~3;
   const int groups = (yd - y0 + VEC - 1) / VEC;
+  const bool mis = VEC == 4 && (gy & 3) != 0;   // rows start at addresses that are only 4-byte aligned
   int shift = 3;
   while (shift < 6 && ((groups + (1 << shift) - 1) >> shift) > CH) ++shift;
   const int lpr = 1 << shift, rpw = 64 >> shift;
@@ -362,7 +363,9 @@ k_sense_tiles(const ippm_config* __restrict__ c, const int64_t* __restrict__ epi
         } else {
           m[q].v[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rmap, on[q] ? cell * 4 : IPPM_K3_OOB, 0, IPPM_K3_LOAD_AUX));
         }
-        tw[q] = __builtin_amdgcn_raw_buffer_load_b8(rtruth, on[q] ? (cell >> 3) : IPPM_K3_OOB, 0, 0);
+        // (grids not a multiple of 4 wide: a group's four truth bits may straddle a byte -- two bytes at any byte address)
+        tw[q] = mis ? (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rtruth, on[q] ? (cell >> 3) : IPPM_K3_OOB, 0, 0)
+                    : (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rtruth, on[q] ? (cell >> 3) : IPPM_K3_OOB, 0, 0);
         fw[q] = flips ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rflip, on[q] ? (int)tile_index<VEC>(row, y - tile_y0, S) : IPPM_K3_OOB, 0, 0)
                       : 0u;
       }
@@ -372,13 +375,12 @@ k_sense_tiles(const ippm_config* __restrict__ c, const int64_t* __restrict__ epi
         const int gidx = gbase + gl + q * lpr;
         const int y = y0 + gidx * VEC;
         const int cell = cellv[q];
-        const uint32_t tbits = VEC == 4 ? (tw[q] >> (cell & 4)) & 0xFu : (tw[q] >> (cell & 7)) & 1u;
+        const uint32_t tbits = VEC == 4 ? (tw[q] >> (cell & 7)) & 0xFu : (tw[q] >> (cell & 7)) & 1u;
         uint32_t flipbits;
         if (flips) {
           flipbits = fw[q] & (VEC == 4 ? 0xFu : 1u);
         } else if (VEC == 4) {
-          const Philox4 ph = ippm_philox((uint32_t)(cell >> 2), (uint32_t)ep, sw, (uint32_t)(ep >> 32), k0, k1);
-          flipbits = (ph.v[0] < thr ? 1u : 0u) | (ph.v[1] < thr ? 2u : 0u) | (ph.v[2] < thr ? 4u : 0u) | (ph.v[3] < thr ? 8u : 0u);
+          flipbits = philox_flip_bits4((uint32_t)cell, (uint32_t)ep, sw, (uint32_t)(ep >> 32), k0, k1, thr, mis);
         } else {
           const Philox4 ph = ippm_philox((uint32_t)(cell >> 2), (uint32_t)ep, sw, (uint32_t)(ep >> 32), k0, k1);
           const int s4 = cell & 3;
@@ -403,7 +405,14 @@ k_sense_tiles(const ippm_config* __restrict__ c, const int64_t* __restrict__ epi
           ippm_k3_u4 t;
           t.x = __float_as_uint(m[q].v[0]); t.y = __float_as_uint(m[q].v[1 % VEC]);
           t.z = __float_as_uint(m[q].v[2 % VEC]); t.w = __float_as_uint(m[q].v[3 % VEC]);
-          __builtin_amdgcn_raw_buffer_store_b128(t, rmap, off, 0, IPPM_K3_STORE_AUX);
+          // the last group of a row that is not a multiple of 4 wide hangs over into the next row: its cells go out one by one
+          const bool tail = mis && y + 4 > gy;
+          __builtin_amdgcn_raw_buffer_store_b128(t, rmap, tail ? IPPM_K3_OOB : off, 0, IPPM_K3_STORE_AUX);
+          if (mis) {
+            __builtin_amdgcn_raw_buffer_store_b32(t.x, rmap, tail ? off : IPPM_K3_OOB, 0, IPPM_K3_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b32(t.y, rmap, tail && y + 1 < gy ? off + 4 : IPPM_K3_OOB, 0, IPPM_K3_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b32(t.z, rmap, tail && y + 2 < gy ? off + 8 : IPPM_K3_OOB, 0, IPPM_K3_STORE_AUX);
+          }
         } else {
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m[q].v[0]), rmap, off, 0, IPPM_K3_STORE_AUX);
         }

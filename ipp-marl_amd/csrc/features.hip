@@ -58,7 +58,7 @@ k_area_sums(const float* __restrict__ maps, double* __restrict__ area, int gx, i
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         const int rr = row + u * stride;
-        if (rr < r1) v[u] = load_cells<VEC>(map + (size_t)rr * gy + y);
+        if (rr < r1) v[u] = load_cells_row<VEC>(map + (size_t)rr * gy, y, gy);
       }
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
@@ -66,7 +66,7 @@ k_area_sums(const float* __restrict__ maps, double* __restrict__ area, int gx, i
         if (rr >= r1) continue;
         float d[VEC];
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) d[q] = SIGMOID ? ippm_sigmoid(v[u].v[q]) : v[u].v[q];
+        for (int q = 0; q < VEC; ++q) d[q] = y + q < gy ? (SIGMOID ? ippm_sigmoid(v[u].v[q]) : v[u].v[q]) : 0.f;   // (a row's last group may hang over)
         area_row<VEC>(acc, s_area, ac, rr, gx, inv_gx, d);
       }
     }
@@ -185,7 +185,7 @@ k_actor_features(const ippm_config* __restrict__ c, const double* __restrict__ a
   __shared__ float s_F[FEAT2];
   __shared__ int s_c1[FEAT2], s_call[FEAT2];  // footprint image: 11-scaled weight of the "occupied" cells / of all pasted cells
   const int tid = threadIdx.x;
-  const int vec = (gy & 3) == 0 && gy >= 4 * IPPM_FEAT ? 4 : 1;
+  const int vec = gy >= 4 * IPPM_FEAT ? 4 : 1;   // as ippm_ctx::vec
   const int tile_bytes = (int)ippm_tile_bytes(S, vec);
   // up-front loads
   const uint32_t* cd32 = reinterpret_cast<const uint32_t*>(code + (size_t)(e * n + i) * tile_bytes);
@@ -408,7 +408,7 @@ static int launch_area_sums(const float* maps, double* area, int rows, int cols,
                             int slot0, bool sigmoid, hipStream_t st) {
   const int chunk_rows = 32;
   dim3 grid((rows + chunk_rows - 1) / chunk_rows, n_maps), block(256);
-  const bool v4 = cols % 4 == 0 && cols >= 4 * IPPM_FEAT && (reinterpret_cast<uintptr_t>(maps) & 15) == 0;
+  const bool v4 = cols >= 4 * IPPM_FEAT;   // 16-byte groups at any row alignment (a row's last group is read cell by cell)
 #define IPPM_AS(V, SG) \
   hipLaunchKernelGGL((k_area_sums<V, SG>), grid, block, 0, st, maps, area, rows, cols, chunk_rows, maps_per_env, slots_per_env, slot0)
   if (v4) { if (sigmoid) IPPM_AS(4, true); else IPPM_AS(4, false); }

@@ -23,6 +23,7 @@
 // saved-exec branches by the compiler, 5x slower again: IPPM_OPAQUE below.)
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "ippm_tiles.h"
 
@@ -53,6 +54,7 @@ struct WaveCtx {   // what a wave needs while it walks its rows
   double* sums_env;  // this env's reward sums (global map only), nullptr otherwise
   int gx, gy, row_bytes;
   float lc, wt, lp, inv_gx, inv_gy;
+  double lp64;       // logit(prior) as the reference holds it (a Python float): the SHIFT chain subtracts it per message
   int lane;
   int last_op;
   unsigned fusemask;
@@ -117,7 +119,7 @@ __device__ __forceinline__ void walk_slab(const WaveCtx& w, const OpTable& t, Wa
   int yu[NA], yd[NA];
   int cshift[NA];      // uniform part of a slot's code byte offset; a huge value (-> out of range, reads 0) for slots without bits
   float lm0[NA], lm1[NA];
-  float lpk[NA];       // SHIFT: logit(prior) for the slots that are messages
+  double lpk[SHIFT ? NA : 1];   // SHIFT: logit(prior) for the slots that are messages
   // SHIFT: every cell of the grid enters the reward sums with a tiny H(b) - H(a); these are summed in float64 and go out
   // at the end of the slab (kept out of WaveAcc: the common path must not carry six more registers)
   double sd1 = 0.0, sdD = 0.0, sdT = 0.0;
@@ -135,7 +137,7 @@ __device__ __forceinline__ void walk_slab(const WaveCtx& w, const OpTable& t, Wa
     cshift[k] = lane_i(t.cs, idx);
     const bool rin = !SHIFT || (idx < 32 && ((rowin >> idx) & 1u));
     if (SHIFT && !rin) { yu[k] = 0; yd[k] = 0; cshift[k] = 0x7F000000; }  // a message whose footprint misses these rows: shift only
-    lpk[k] = SHIFT && k >= pad ? w.lp : 0.f;
+    if (SHIFT) lpk[SHIFT ? k : 0] = k >= pad ? w.lp64 : 0.0;
     keep_slot = (idx == w.last_op) ? k : keep_slot;
   }
   const RowGeom g = fit_geom<VEC>(ya, yb, xe - x, 1);
@@ -149,13 +151,16 @@ __device__ __forceinline__ void walk_slab(const WaveCtx& w, const OpTable& t, Wa
     // of them carry a measurement, which keep their unclamped output
     unsigned cm[NA];
     unsigned touched = 0, keepm = 0, ops_here = 0;
+    // cells of my group that exist in this row (a row's last group hangs over into the next row when the grid is not a multiple of
+    // VEC wide); only the whole-row walk of SHIFT can meet cells no op's columns exclude
+    const unsigned vm = SHIFT ? (1u << min(max(w.gy - y, 0), VEC)) - 1u : QM;
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
       unsigned mq = 0;
 #pragma unroll
       for (int q = 0; q < VEC; ++q) mq |= ((unsigned)(y + q - yu[k]) < (unsigned)(yd[k] - yu[k])) ? (1u << q) : 0u;
       cm[k] = mq;
-      const unsigned inm = SHIFT ? (k >= pad ? QM : 0u) : mq;
+      const unsigned inm = SHIFT ? (k >= pad ? vm : 0u) : mq;
       touched |= inm;
       ops_here += __popc(inm);
       keepm = (k == keep_slot) ? mq : keepm;
@@ -192,7 +197,12 @@ __device__ __forceinline__ void walk_slab(const WaveCtx& w, const OpTable& t, Wa
         const bool valid = u == 0 || row0 + u < re;
         const int row = row0 + u;
         CellVec<VEC>& mv = mvu[u];
-        float L[VEC], bsave[VEC];
+        // SHIFT: the chain runs in float64 registers and is rounded once, at the store -- there every message of the plan adds
+        // to every cell of the grid, and with a float32 rounding per message (7 UAVs x 16 steps = 112 of them) 0.04 % of the cells
+        // drifted past 1e-5; one rounding per fusion keeps all of them inside
+        using LT = typename std::conditional<SHIFT, double, float>::type;
+        LT L[VEC];
+        float bsave[VEC];
 #pragma unroll
         for (int q = 0; q < VEC; ++q) { L[q] = mv.v[q]; bsave[q] = mv.v[q]; }
         // Ordered clamp/add chain (mappings.py:80-124 in log-odds): every op of the reference clips its input over the WHOLE
@@ -206,7 +216,8 @@ __device__ __forceinline__ void walk_slab(const WaveCtx& w, const OpTable& t, Wa
 #pragma unroll
           for (int q = 0; q < VEC; ++q) {
             const float lm = ippm_masked(ippm_bitmask(cm[k], q), ippm_blend(ippm_bitmask(cw, q), lm1[k], lm0[k]));
-            L[q] = ippm_clampl(L[q], w.lc) + (SHIFT ? lm - lpk[k] : lm);
+            if (SHIFT) L[q] = fmin(fmax((double)L[q], -(double)w.lc), (double)w.lc) + ((double)lm - lpk[SHIFT ? k : 0]);
+            else L[q] = ippm_clampl((float)L[q], w.lc) + lm;
           }
         }
 #else
@@ -217,12 +228,26 @@ __device__ __forceinline__ void walk_slab(const WaveCtx& w, const OpTable& t, Wa
         float d[VEC];
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
-          const float a = ippm_blend(ippm_bitmask(keepm, q), L[q], ippm_clampl(L[q], w.lc));
+          const float a = ippm_blend(ippm_bitmask(keepm, q), (float)L[q], (float)(SHIFT ? fmin(fmax((double)L[q], -(double)w.lc), (double)w.lc)
+                                                                                             : (double)ippm_clampl((float)L[q], w.lc)));
           amax = fmaxf(amax, fabsf(a));
           mv.v[q] = a;
-          if (TRACK) d[q] = valid ? sigmoid_diff(a, bsave[q]) : 0.f;
+          if (TRACK) d[q] = valid && (!SHIFT || ((vm >> q) & 1u)) ? sigmoid_diff(a, bsave[q]) : 0.f;
         }
-        buf_store_cells<VEC>(w.map, valid ? row * gybyte + ybyte : 0x7FFFFFF0, mv);
+        {
+          const int soff = valid ? row * gybyte + ybyte : 0x7FFFFFF0;
+          if (VEC == 4 && (w.gy & 3) != 0) {
+            // (uniform) rows are not a multiple of 4 wide: the last group of a row hangs over into the next row -- its cells go
+            // out one by one, another lane owns the rest
+            const bool tail = y + 4 > w.gy;
+            buf_store_cells<VEC>(w.map, tail ? 0x7FFFFFF0 : soff, mv);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mv.v[0]), w.map, tail ? soff : 0x7FFFFFF0, 0, IPPM_FUSE_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mv.v[1 % VEC]), w.map, tail && y + 1 < w.gy ? soff + 4 : 0x7FFFFFF0, 0, IPPM_FUSE_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mv.v[2 % VEC]), w.map, tail && y + 2 < w.gy ? soff + 8 : 0x7FFFFFF0, 0, IPPM_FUSE_STORE_AUX);
+          } else {
+            buf_store_cells<VEC>(w.map, soff, mv);
+          }
+        }
         if (TRACK) area_row<VEC>(acc, w.s_area, ac, min(row, re - 1), w.gx, w.inv_gx, d);
 #ifndef IPPM_X_NOREWARD
         if (w.is_global) {
@@ -232,8 +257,9 @@ __device__ __forceinline__ void walk_slab(const WaveCtx& w, const OpTable& t, Wa
           float wa[VEC], wb[VEC], wsum = 0.f;
 #pragma unroll
           for (int q = 0; q < VEC; ++q) {
-            wa[q] = valid ? ippm_weight_l(mv.v[q], w.wt) : 0.f;
-            wb[q] = valid ? ippm_weight_l(bsave[q], w.wt) : 0.f;
+            const bool here = valid && (!SHIFT || ((vm >> q) & 1u));
+            wa[q] = here ? ippm_weight_l(mv.v[q], w.wt) : 0.f;
+            wb[q] = here ? ippm_weight_l(bsave[q], w.wt) : 0.f;
             wsum += wa[q] + wb[q];
           }
           if (__any(wsum != 0.f)) {
@@ -359,6 +385,7 @@ __device__ __forceinline__ void fuse_item(const ippm_config* __restrict__ c, flo
   w.code = IPPM_RSRC(code, (size_t)n_envs_total * n * TB);
   w.s_area = s_area;
   w.lc = c->logit_clip; w.wt = c->logit_weight_thr; w.lp = c->logit_prior;
+  w.lp64 = c->logit_prior_f64;
   w.inv_gx = w.inv_gy = 0.f;
   w.lane = lane;
   w.last_op = last_op;

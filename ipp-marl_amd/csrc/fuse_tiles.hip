@@ -185,7 +185,17 @@ __device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e,
       ippm_t_u4 v;
       v.x = __float_as_uint(out[0]); v.y = __float_as_uint(out[1]); v.z = __float_as_uint(out[2]); v.w = __float_as_uint(out[3]);
       // a lane-load past the item's end was never in range; a group no op touches cannot occur inside an interval
-      __builtin_amdgcn_raw_buffer_store_b128(v, rmap, off[q], 0, 0);
+      if ((w.gy & 3) != 0) {
+        // (uniform) rows are not a multiple of 4 wide: the last group of a row hangs over into the next row -- its cells go out
+        // one by one, another lane owns the rest
+        const bool tail = ycol[q] + 4 > w.gy;
+        __builtin_amdgcn_raw_buffer_store_b128(v, rmap, tail ? IPPM_T_OOB : off[q], 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(v.x, rmap, tail ? off[q] : IPPM_T_OOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(v.y, rmap, tail && ycol[q] + 1 < w.gy ? off[q] + 4 : IPPM_T_OOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(v.z, rmap, tail && ycol[q] + 2 < w.gy ? off[q] + 8 : IPPM_T_OOB, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b128(v, rmap, off[q], 0, 0);
+      }
     }
     if (is_global) {
       // information-gain terms (utils/reward.py:68-82) of the cells the step changed; an untouched cell contributes exact zeros

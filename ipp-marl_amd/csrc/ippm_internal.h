@@ -49,7 +49,7 @@ struct ippm_ctx {
   ippm_config cfg;           // host copy
   ippm_config* dcfg;         // device copy
   unsigned long long* dcounters;  // device, IPPM_COUNTER_SLOTS x 8 words (summed into ippm_counters on read)
-  int vec;                   // 4 when grid_y % 4 == 0 (aligned float4 path), else 1
+  int vec;                   // 4: 16-byte lane groups (grid_y >= 44), else 1
   // tuning knobs, resolved ONCE at ippm_ctx_create (the work buffer's size, the plan kernel's item layout and the fusion launch
   // all derive from them and must agree for the context's lifetime)
   int knob_wave_rows, knob_persist, knob_nowork, knob_split, knob_tile_waves, knob_plan_builders;
@@ -108,8 +108,11 @@ int ippm_check_hip(hipError_t err, const char* what);
 // code / flips tiles: the 4 observation bits of a lane's 4-cell group share one byte (low nibble) when the grid is a
 // multiple of 4 wide (row stride S/4 bytes); otherwise one byte per cell (row stride S).  Measured on MI355X: the
 // 1-byte-per-cell planes cost 27 % of K3's time for 20 % of its bytes; packed they cost 7 % (tools/probe).
-__device__ __forceinline__ uint32_t ippm_truth4(const uint8_t* tr, size_t lin) {  // lin % 4 == 0: cells lin..lin+3
-  return (tr[lin >> 3] >> (lin & 4)) & 0xFu;
+__device__ __forceinline__ uint32_t ippm_truth4(const uint8_t* tr, size_t lin, size_t nbytes) {  // cells lin..lin+3, any alignment
+  const size_t b = lin >> 3;
+  uint32_t w = tr[b];
+  if ((lin & 7) > 4 && b + 1 < nbytes) w |= (uint32_t)tr[b + 1] << 8;   // the group straddles a byte (grids not a multiple of 4 wide)
+  return (w >> (lin & 7)) & 0xFu;
 }
 __device__ __forceinline__ uint32_t ippm_truth1(const uint8_t* tr, size_t lin) { return (tr[lin >> 3] >> (lin & 7)) & 1u; }
 __host__ __device__ __forceinline__ size_t ippm_truth_bytes(int gx, int gy) { return (((size_t)gx * gy + 31) / 32) * 4; }

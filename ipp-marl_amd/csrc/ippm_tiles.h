@@ -70,6 +70,37 @@ __device__ __forceinline__ void store_cells(float* p, const CellVec<VEC>& r) {
     p[0] = r.v[0];
   }
 }
+// The last group of a row of a grid that is not a multiple of VEC wide hangs over into the next row (or past the map): those
+// cells read as 0 and are never written (another lane owns them).
+template <int VEC>
+__device__ __forceinline__ CellVec<VEC> load_cells_row(const float* rowp, int y, int gy) {
+  if (VEC == 1 || y + VEC <= gy) return load_cells<VEC>(rowp + y);
+  CellVec<VEC> r;
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) r.v[q] = y + q < gy ? rowp[y + q] : 0.f;
+  return r;
+}
+template <int VEC>
+__device__ __forceinline__ void store_cells_row(float* rowp, int y, int gy, const CellVec<VEC>& r) {
+  if (VEC == 1 || y + VEC <= gy) { store_cells<VEC>(rowp + y, r); return; }
+#pragma unroll
+  for (int q = 0; q < VEC; ++q)
+    if (y + q < gy) rowp[y + q] = r.v[q];
+}
+// The four flip decisions of a group of cells lin..lin+3 (any alignment) from the Philox words of counter lin >> 2 and, when the
+// group straddles it, lin >> 2 + 1: word k of counter c belongs to cell 4 c + k (oracle/ipp_oracle.py::philox_correctness).
+__device__ __forceinline__ uint32_t philox_flip_bits4(uint32_t lin, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                                     uint32_t thr, bool straddle_possible) {
+  const Philox4 a = ippm_philox(lin >> 2, c1, c2, c3, k0, k1);
+  uint32_t bits = (a.v[0] < thr ? 1u : 0u) | (a.v[1] < thr ? 2u : 0u) | (a.v[2] < thr ? 4u : 0u) | (a.v[3] < thr ? 8u : 0u);
+  if (straddle_possible) {   // (uniform: the grid is not a multiple of 4 wide)
+    const Philox4 b = ippm_philox((lin >> 2) + 1u, c1, c2, c3, k0, k1);
+    bits |= ((b.v[0] < thr ? 1u : 0u) | (b.v[1] < thr ? 2u : 0u) | (b.v[2] < thr ? 4u : 0u) | (b.v[3] < thr ? 8u : 0u)) << 4;
+    bits = (bits >> (lin & 3u)) & 0xFu;
+  }
+  return bits;
+}
+
 // observation bits of a lane's cell group in a code / flips tile: low nibble of one byte (VEC == 4) or one byte per cell
 template <int VEC>
 __device__ __forceinline__ size_t tile_index(int row, int col, int S) {  // col = y - (yu & ~3)

@@ -38,6 +38,7 @@ class IppmConfig(C.Structure):
         ("comm_range", C.c_double), ("failure_rate", C.c_double),
         ("philox_seed", C.c_uint64), ("gamma", C.c_double), ("lambda_", C.c_double),
         ("logit_noise", C.c_float * MAX_Z),
+        ("logit_prior_f64", C.c_double),
     ]
 
 
@@ -165,6 +166,7 @@ def make_config(d: DerivedConstants) -> IppmConfig:
     c.gamma, c.lambda_ = d.gamma, d.lam
     for k in range(d.space_z):
         c.logit_noise[k] = float(d.logit_noise[k])
+    c.logit_prior_f64 = float(d.logit_prior)
     return c
 
 

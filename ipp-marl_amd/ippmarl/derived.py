@@ -102,17 +102,15 @@ class DerivedConstants:
             with np.errstate(divide="ignore"):
                 self.logit_meas[k] = np.log(y / (1 - y))
             self.flip_threshold[k] = int(math.floor(nz * 4294967296.0))
-        # Two regimes outside every BASELINE configuration hold the returns to a wider bound than the 1e-5 of the rest (DESIGN.md
-        # section 3 / 7, include/ippmarl.h next to `prior`; the parity tests state the same numbers): said once per process.
+        # One regime outside every BASELINE configuration holds the returns to a wider bound than the 1e-5 of the rest (DESIGN.md
+        # section 7, include/ippmarl.h next to `prior`; the parity tests state the same number): said once per process.
         self.noise_free_altitudes = [z for z in self.altitudes if _noise(z) == 0]
         notes = []
-        if self.prior != 0.5:
-            notes.append(f"mapping.prior = {self.prior} != 0.5 takes the explicit whole-grid fusion path: posteriors within 5e-5 "
-                         "(99.99 % of the cells within 1e-5), rewards and reward sums within 5e-5")
         if self.noise_free_altitudes:
             notes.append(f"altitudes {self.noise_free_altitudes} m are outside the sensor model's table (sensor_models.py:13-22: "
                          "noise 0): measurements there set cells to exactly 0 / 1 and the reward terms cancel to a small rest; "
-                         "rewards within 2e-4 instead of 1e-5 with tracked area sums (1e-5 in the env-only form)")
+                         "returns within 2e-4 instead of 1e-5 when area sums are tracked or mapping.prior != 0.5 (1e-5 in the "
+                         "env-only form)")
         for note in notes:
             if note not in _WARNED:
                 _WARNED.add(note)
@@ -147,7 +145,7 @@ class DerivedConstants:
     @property
     def vec(self) -> int:
         # mirror of ippm_ctx_create: 16-byte lane groups need a multiple-of-4 width and at least 4 cells per feature bin
-        return 4 if self.grid_y % 4 == 0 and self.grid_y >= 44 else 1
+        return 4 if self.grid_y >= 44 else 1   # (as ippm_ctx::vec: the grid need not be a multiple of 4 wide)
 
     @property
     def truth_bytes(self) -> int:

@@ -300,7 +300,9 @@ def test_batched_ig_policy_matches_oracle(name="small", over=None, seed=5, first
     env.reset(eps)
     for t in range(4):
         env.build_observations(t, features=False)
-        local = env.posterior_local().cpu().numpy()
+        # the beliefs the planner sees, as float64 probabilities of the stored log-odds (a float32 probability of a saturated cell,
+        # 0.9999, keeps three digits of 1 - p, and a candidate over nothing but saturated cells has a gain made of exactly that)
+        local = 1.0 / (1.0 + np.exp(-env.local.cpu().numpy().astype(np.float64)))
         pos = env.pos.cpu().numpy()
         acts = env.ig_actions(communication=True)
         gains, chosen = env.ig_gains.cpu().numpy(), acts.cpu().numpy()
@@ -308,7 +310,7 @@ def test_batched_ig_policy_matches_oracle(name="small", over=None, seed=5, first
             pls, gls, prior = [], [], []
             for i in range(d.n_agents):
                 m = O.apply_collision_mask(d, pos[e, i], O.action_mask(d, pos[e, i]), prior)
-                ap, g = O.ig_individual(d, pos[e, i], m, local[e, i].astype(np.float64))
+                ap, g = O.ig_individual(d, pos[e, i], m, local[e, i])
                 np.testing.assert_allclose(gains[e, i], g, rtol=RTOL, atol=1e-9)
                 pls.append(ap), gls.append(g), prior.append(pos[e, i])
             util = O.ig_cell_utilities(pls, O.ig_relative(gls))
