@@ -302,7 +302,7 @@ def main():
         cells = rl_counters["sense_cells"] / k3["launches"]
         roofline = roofline_entry("k_sense_update", "K3: sense + Bayes update of the footprint tiles", K3_BYTES_PER_CELL * cells, k3,
                                   {"algorithmic_bytes_per_cell": K3_BYTES_PER_CELL, "cells_per_launch": cells,
-                                   "launches": f"{args.roofline_steps} steps + {rl_resets} resets (start-position sensing) right after "
+                                   "launches": f"the K3 launches of {args.roofline_steps} steps ({rl_resets} resets among them) right after "
                                                "the timed region"})
         # every algorithmic byte of a step of the TIMED region (K3 + fusion; the small plan kernel's ~2.4 MB left out) against
         # the step's wall time: what the whole step, launch gaps and resets included, makes of the HBM peak

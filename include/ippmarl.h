@@ -163,6 +163,15 @@ int ippm_reset_episode(ippm_ctx* ctx, const int64_t* episode, int32_t* pos, uint
                        float* global, int32_t* split_pct, float* comm_range_out, int32_t* ws, double* sums,
                        double* area, int32_t n_envs, void* stream);
 
+/* Reset of the maps in one pass for the batched step (16-byte layout, grid_y >= 44): prior fill of local and global maps
+ * (Mapping.init_priors, mappings.py:126-132) restricted to the bounding box of what the last episode wrote into each map (kept in
+ * `ws` by ippm_plan_step; full != 0: whole maps -- first use, or after maps were written by other entry points), fused with the
+ * start-position sensing of every agent (the stage-0 ippm_sense_update: agent.py:43-49 -> mappings.py:32-78), which needs
+ * `truth` in place.  Call after ippm_reset_episode (with local = global = NULL there) and after the terrain is generated;
+ * writes local, global, code, rect and the boxes in ws.  flips as for ippm_sense_update (NULL: Philox). */
+int ippm_reset_maps(ippm_ctx* ctx, const int64_t* episode, const int32_t* pos, const uint8_t* truth, float* local, float* global,
+                    const uint8_t* flips, uint8_t* code, int32_t* rect, int32_t* ws, int32_t full, int32_t n_envs, void* stream);
+
 /* Elementwise conversions between the stored log-odds and the reference's probabilities (n floats). */
 int ippm_logodds_to_prob(ippm_ctx* ctx, const float* src, float* dst, int64_t n, void* stream);
 int ippm_prob_to_logodds(ippm_ctx* ctx, const float* src, float* dst, int64_t n, void* stream);

@@ -26,7 +26,11 @@ __global__ void k_reset_scalars(const ippm_config* __restrict__ c, const int64_t
   int64_t ep = episode[e];
   // clear this map's workspace (deferred clamp state + plan)
   int32_t* w = ws + (size_t)(e * per + k) * IPPM_WS_WORDS;
+  // the written-cells box of the finished episode moves to the (now idle) first op record, where every workgroup of
+  // ippm_reset_maps finds it unchanged while the first one already writes the new episode's box
+  const int32_t box_x = w[WS_BBOX_X], box_y = w[WS_BBOX_Y];
   for (int i = 0; i < WS_OPS; ++i) w[i] = 0;
+  w[WS_OPS + 0] = box_x; w[WS_OPS + 1] = box_y;
   if (area) {  // area sums of the all-prior map: sigmoid(0) = 0.5 times the bin's weight total gx*gy
     double* a = area + (size_t)(e * per + k) * IPPM_FEAT * IPPM_FEAT;
     const double v = (double)ippm_sigmoid(c->logit_prior) * (double)c->grid_x * (double)c->grid_y;
@@ -425,6 +429,135 @@ k_sense_tiles(const ippm_config* __restrict__ c, const int64_t* __restrict__ epi
     atomicAdd(&counters[(tile & (IPPM_COUNTER_SLOTS - 1)) * 8 + 0], (unsigned long long)h * w);
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// Episode reset of the maps in one launch: prior fill + start-position sensing (Mapping.init_priors, mappings.py:126-132, and the
+// t = 0 Mapping.update_grid_map of agent.py:43-49), restricted to what the last episode wrote.
+//   - Every map carries the bounding box of the cells written since its last reset (ws words WS_BBOX_*, kept by k_plan_step).
+//     At config 2 that box is 54 % of a local map and 85 % of a global map on average: the fills were 200 us of a 580 us reset,
+//     1.6 GB written to store one constant.  full != 0 (first use, or maps written behind the planner's back): whole maps.
+//   - A local map's start footprint gets its first measurement right here (K3's arithmetic on a prior cell: clamp(prior) + the
+//     measurement's log-odds) instead of fill -> read -> modify -> write by a K3 launch of its own.
+// Two kinds of workgroup share the launch and write disjoint cells.  FILL workgroups (blockIdx.x < fill_chunks): 4 rows of one
+// map, one row per wavefront, one 16-byte store per lane (the streaming shape of the copy probe); they skip the 4-cell groups that
+// meet the map's start footprint, and rows outside the box cost an early exit.  SENSE workgroups: a 32-row part of one agent's
+// start footprint in K3's dense lane geometry (a 90-cell footprint row = 3 passes of 8 lanes; a row-per-wavefront layout would
+// run the Philox rounds on 23 of 64 lanes), writing whole groups -- measured cells and the prior cells that share their groups.
+// ------------------------------------------------------------------------------------------------------
+#define IPPM_RESET_ROWS 4
+__global__ void __launch_bounds__(256)
+k_reset_maps(const ippm_config* __restrict__ c, const int64_t* __restrict__ episode, const int32_t* __restrict__ pos,
+             const uint8_t* __restrict__ truth, float* __restrict__ local, float* __restrict__ global, const uint8_t* __restrict__ flips,
+             uint8_t* __restrict__ code, const int32_t* __restrict__ rect, int32_t* __restrict__ ws, int full, int fill_chunks) {
+  const int n = c->n_agents, gx = c->grid_x, gy = c->grid_y, S = c->tile_stride;
+  const int e = blockIdx.z, m = blockIdx.y;
+  const bool is_global = m == n;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int32_t* w = ws + (size_t)(e * (n + 1) + m) * IPPM_WS_WORDS;
+  // everything a workgroup needs comes in ONE round trip: the start footprint was projected by the launch before this one
+  // (343 k workgroups of one 16-byte store per lane: with the position -> lattice index -> centre table chain in front of the
+  // stores the launch ran at the pace of that chain, 214 us)
+  int yu = 0, yd = 0, xl = 0, xr = 0;
+  if (!is_global) {
+    const int4 r = *reinterpret_cast<const int4*>(rect + (size_t)(e * n + m) * 4);
+    yu = r.x; yd = r.y; xl = r.z; xr = r.w;
+    if (xr <= xl || yd <= yu) { yu = yd = xl = xr = 0; }
+  }
+  const float lp = c->logit_prior;
+  float* map = is_global ? global + (size_t)e * gx * gy : local + (size_t)(e * n + m) * gx * gy;
+  const __amdgpu_buffer_rsrc_t rmap = IPPM_K3_RSRC(map, (size_t)gx * gy * 4);
+  const bool mis = (gy & 3) != 0;
+  const int fg0 = yu >> 2, fg1 = (yd + 3) >> 2;   // groups that meet the footprint's columns
+  if ((int)blockIdx.x < fill_chunks) {
+    // ---- FILL
+    int bx0 = 0, bx1 = gx, by0 = 0, by1 = gy;
+    if (!full) {
+      const int bx = w[WS_OPS + 0], by = w[WS_OPS + 1];   // parked there by k_reset_scalars
+      bx0 = bx & 0xFFFF; bx1 = (unsigned)bx >> 16; by0 = by & 0xFFFF; by1 = (unsigned)by >> 16;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {   // the new episode's box: what this launch writes that is not the prior
+      w[WS_BBOX_X] = xl | (xr << 16);
+      w[WS_BBOX_Y] = yu | (yd << 16);
+    }
+    const int x = blockIdx.x * IPPM_RESET_ROWS + wv;
+    if (x >= gx || x < bx0 || x >= bx1 || by1 <= by0) return;
+    const bool fp_row = x >= xl && x < xr;
+    const ippm_k3_u4 t = {__float_as_uint(lp), __float_as_uint(lp), __float_as_uint(lp), __float_as_uint(lp)};
+    for (int g = (by0 >> 2) + lane; g < ((by1 + 3) >> 2); g += 64) {
+      if (fp_row && g >= fg0 && g < fg1) continue;   // a SENSE workgroup writes this group
+      const int y = g * 4, off = (x * gy + y) * 4;
+      if (mis && y + 4 > gy) {   // a row's last group hangs over into the next row: cell by cell
+        __builtin_amdgcn_raw_buffer_store_b32(t.x, rmap, off, 0, 0);
+        if (y + 1 < gy) __builtin_amdgcn_raw_buffer_store_b32(t.x, rmap, off + 4, 0, 0);
+        if (y + 2 < gy) __builtin_amdgcn_raw_buffer_store_b32(t.x, rmap, off + 8, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b128(t, rmap, off, 0, 2);   // non-temporal: written once, read a step later at the earliest
+      }
+    }
+    return;
+  }
+  // ---- SENSE: rows [r0, r1) of the footprint, K3's geometry (k_sense_tiles), on prior cells
+  if (is_global) return;
+  const int part = (int)blockIdx.x - fill_chunks;
+  const int h = xr - xl, wdt = yd - yu;
+  const int r0 = part * 32, r1 = min(h, r0 + 32);
+  if (wdt <= 0 || r0 >= r1) return;
+  const int32_t* p = pos + (size_t)(e * n + m) * 3;
+  const int k = ippm_alt_index(c, p[2]);
+  const float lc = c->logit_clip;
+  const float lm0 = c->logit_meas[k][0] - lp, lm1 = c->logit_meas[k][1] - lp;
+  const uint32_t thr = c->flip_threshold[k];
+  const uint32_t sw = ippm_stream_word((uint32_t)m, 0u, IPPM_DOMAIN_FLIP);
+  const int64_t ep = episode ? episode[e] : 0;
+  const uint32_t k0 = (uint32_t)c->philox_seed, k1 = (uint32_t)(c->philox_seed >> 32);
+  const __amdgpu_buffer_rsrc_t rtruth = IPPM_K3_RSRC(truth + (size_t)e * ippm_truth_bytes(gx, gy), ippm_truth_bytes(gx, gy));
+  const size_t TB = ippm_tile_bytes(S, 4);
+  const __amdgpu_buffer_rsrc_t rcode = IPPM_K3_RSRC(code + (size_t)(e * n + m) * TB, TB);
+  const __amdgpu_buffer_rsrc_t rflip = IPPM_K3_RSRC(flips ? flips + (size_t)(e * n + m) * TB : code, flips ? TB : 0);
+  const int y0 = yu & ~3, groups = fg1 - fg0;
+  int shift = 3;
+  while (shift < 6 && ((groups + (1 << shift) - 1) >> shift) > 3) ++shift;
+  const int lpr = 1 << shift, rpw = 64 >> shift;
+  const int sub = lane >> shift, gl = lane & (lpr - 1);
+  for (int gbase = 0; gbase < groups; gbase += 3 * lpr) {
+    for (int row = r0 + wv * rpw + sub; row < r1; row += 4 * rpw) {
+      const int x = xl + row;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int gidx = gbase + gl + q * lpr;
+        if (gidx >= groups) continue;
+        const int y = y0 + gidx * 4;
+        const int cell = x * gy + y;
+        const uint32_t tw = mis ? (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rtruth, cell >> 3, 0, 0)
+                                : (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rtruth, cell >> 3, 0, 0);
+        const uint32_t tbits = (tw >> (cell & 7)) & 0xFu;
+        uint32_t flipbits;
+        if (flips) flipbits = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rflip, (int)tile_index<4>(row, y - y0, S), 0, 0) & 0xFu;
+        else flipbits = philox_flip_bits4((uint32_t)cell, (uint32_t)ep, sw, (uint32_t)(ep >> 32), k0, k1, thr, mis);
+        uint32_t inm = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) inm |= ((unsigned)(y + j - yu) < (unsigned)wdt) ? (1u << j) : 0u;
+        const uint32_t obs = (tbits ^ flipbits) & inm;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)   // mappings.py:109-124 on a prior cell, exactly as K3 forms it; the group's other cells: prior
+          v[j] = ((inm >> j) & 1u) ? ippm_clampl(lp, lc) + (((obs >> j) & 1u) ? lm1 : lm0) : lp;
+        ippm_k3_u4 t;
+        t.x = __float_as_uint(v[0]); t.y = __float_as_uint(v[1]); t.z = __float_as_uint(v[2]); t.w = __float_as_uint(v[3]);
+        const int off = cell * 4;
+        if (mis && y + 4 > gy) {
+          __builtin_amdgcn_raw_buffer_store_b32(t.x, rmap, off, 0, 0);
+          if (y + 1 < gy) __builtin_amdgcn_raw_buffer_store_b32(t.y, rmap, off + 4, 0, 0);
+          if (y + 2 < gy) __builtin_amdgcn_raw_buffer_store_b32(t.z, rmap, off + 8, 0, 0);
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b128(t, rmap, off, 0, 0);
+        }
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)obs, rcode, (int)tile_index<4>(row, y - y0, S), 0, 0);
+      }
+    }
+  }
+}
+
 // full-grid weighted entropy per map (initialisation of T, evaluation metrics)
 __global__ void __launch_bounds__(256)
 k_weighted_entropy(const ippm_config* __restrict__ c, const float* __restrict__ maps, const uint8_t* __restrict__ truth,
@@ -488,6 +621,29 @@ extern "C" int ippm_reset_episode(ippm_ctx* ctx, const int64_t* episode, int32_t
   }
   if (local) if (int rc = fill_f32(ctx, local, c.logit_prior, cells * n_envs * c.n_agents, S_(stream))) return rc;
   if (global) if (int rc = fill_f32(ctx, global, c.logit_prior, cells * n_envs, S_(stream))) return rc;
+  return 0;
+}
+
+extern "C" int ippm_reset_maps(ippm_ctx* ctx, const int64_t* episode, const int32_t* pos, const uint8_t* truth, float* local,
+                               float* global, const uint8_t* flips, uint8_t* code, int32_t* rect, int32_t* ws, int32_t full,
+                               int32_t n_envs, void* stream) {
+  if (!ctx || !pos || !truth || !local || !global || !code || !rect || !ws) { ippm_set_error("ippm_reset_maps: null argument"); return -1; }
+  if (!flips && !episode) { ippm_set_error("ippm_reset_maps: Philox flips need the episode ids"); return -1; }
+  if (ctx->vec != 4) { ippm_set_error("ippm_reset_maps: needs the 16-byte layout (grid_y >= 44); use ippm_reset_episode + ippm_sense_update"); return -2; }
+  if (n_envs <= 0) return 0;
+  if (n_envs > 65535) { ippm_set_error("ippm_reset_maps: more than 65535 envs per launch"); return -1; }
+  const ippm_config& c = ctx->cfg;
+  // K2 first: the start footprints into `rect` (k_reset_maps then starts from them instead of re-deriving them per workgroup)
+  hipLaunchKernelGGL(k_footprint, dim3(grid1(n_envs * c.n_agents)), dim3(256), 0, S_(stream), ctx->dcfg, pos, rect, (int32_t*)nullptr,
+                     n_envs * c.n_agents);
+  IPPM_LAUNCH_CHECK("footprint");
+  int h_max = 1;
+  for (int k = 0; k < c.space_z; ++k) h_max = std::max(h_max, 2 * c.radius_x[k]);
+  const int fill_chunks = (c.grid_x + IPPM_RESET_ROWS - 1) / IPPM_RESET_ROWS, sense_parts = (h_max + 31) / 32;
+  dim3 grid((unsigned)(fill_chunks + sense_parts), (unsigned)(c.n_agents + 1), (unsigned)n_envs);
+  IPPM_LAUNCH(ctx, IPPM_T_RESET, k_reset_maps, grid, dim3(256), S_(stream), ctx->dcfg, episode, pos, truth, local, global, flips, code, rect,
+              ws, full ? 1 : 0, fill_chunks);
+  IPPM_LAUNCH_CHECK("reset_maps");
   return 0;
 }
 

@@ -16,6 +16,8 @@
 #define WS_FLAG_A 0   // region A may hold values outside [clip_lo, clip_hi]
 #define WS_RECT_A 1   // .. 1..4 = [yu,yd,xl,xr]
 #define WS_FLAG_S 5   // the agent's current footprint rect may hold out-of-range values (set by K3)
+#define WS_BBOX_X 6   // x0 | x1 << 16, WS_BBOX_Y y0 | y1 << 16: bounding box of every cell of the map written since the episode's
+#define WS_BBOX_Y 7   // reset (kept by k_plan_step: plan hulls and the footprints K3 is about to sense); ippm_reset_maps fills only that
 #define WS_PLAN 8
 #define PL_NOPS 0
 #define PL_X0 1

@@ -451,6 +451,17 @@ __device__ void k1_env(const ippm_config* __restrict__ c, int64_t ep, int32_t* s
 //                    starts with its rectangle in hand instead of a pos -> lattice index -> centre table chain
 // comm and the plans read the pre-move positions (LDS copy taken before K1 writes anything).
 // ======================================================================================================
+// written-cells box of a map (ws words WS_BBOX_*): union with rows [x0, x1) x columns [y0, y1)
+__device__ __forceinline__ void box_union(int32_t* wm, int x0, int x1, int y0, int y1) {
+  if (x1 <= x0 || y1 <= y0) return;
+  const int bx = wm[WS_BBOX_X], by = wm[WS_BBOX_Y];
+  int ax0 = bx & 0xFFFF, ax1 = (unsigned)bx >> 16, ay0 = by & 0xFFFF, ay1 = (unsigned)by >> 16;
+  if (ax1 <= ax0 || ay1 <= ay0) { ax0 = x0; ax1 = x1; ay0 = y0; ay1 = y1; }
+  else { ax0 = min(ax0, x0); ax1 = max(ax1, x1); ay0 = min(ay0, y0); ay1 = max(ay1, y1); }
+  wm[WS_BBOX_X] = ax0 | (ax1 << 16);
+  wm[WS_BBOX_Y] = ay0 | (ay1 << 16);
+}
+
 #ifdef IPPM_PLAN_STAMPS   // variant builds: env 0 leaves wall-clock stamps of its phases in word 7 of the counter slots
 #define PLAN_STAMP(k) do { if (blockIdx.x == 0 && lane == 0 && stamps) stamps[((wv * 8 + (k)) & 63) * 8 + 7] = wall_clock64(); \
     if (blockIdx.x == gridDim.x - 1 && wv == 0 && lane == 0 && stamps) stamps[(48 + (k)) * 8 + 7] = wall_clock64(); \
@@ -503,6 +514,12 @@ k_plan_step(const ippm_config* __restrict__ c, const int64_t* __restrict__ episo
     }
     if ((flags & IPPM_STEP_GLOBAL) && lane == n)
       hull_rows = plan_map(c, s_rect, s_pos, 0u, ws, 1, e, n, st, tiled ? s_ops + n * IPPM_MAX_OPS : nullptr, tiled ? s_nops + n : nullptr);
+    // the map's written-cells box takes in this step's plan hull (ippm_reset_maps fills only the box at the next reset)
+    if (plans && lane <= n && hull_rows > 0) {
+      int32_t* wm = ws + (size_t)(e * (n + 1) + lane) * IPPM_WS_WORDS;
+      const int32_t* hdr = wm + WS_PLAN;
+      box_union(wm, hdr[PL_X0], hdr[PL_X1], hdr[PL_Y0], hdr[PL_Y1]);
+    }
     // row-run form of the work list: items of this env's plans into the env's own slice (exclusive scan of the lanes' counts)
     if (work && plans && !tiled) {
       const int items = (hull_rows + wave_rows - 1) / wave_rows;
@@ -558,6 +575,7 @@ k_plan_step(const ippm_config* __restrict__ c, const int64_t* __restrict__ episo
       ippm_footprint_rect(c, s_pos[lane * 3], s_pos[lane * 3 + 1], s_pos[lane * 3 + 2], cl, nullptr);
       int32_t* r = rect_next + (size_t)(e * n + lane) * 4;
       r[0] = cl[0]; r[1] = cl[1]; r[2] = cl[2]; r[3] = cl[3];
+      if (ws) box_union(ws + (size_t)(e * (n + 1) + lane) * IPPM_WS_WORDS, cl[2], cl[3], cl[0], cl[1]);   // what K3 senses next
     }
     PLAN_STAMP(6);
   }

@@ -60,6 +60,7 @@ PROTOTYPES = {
     "ippm_kernel_timing": [P, I32],
     "ippm_read_kernel_times": [P, I32, I32, P, P, P, P, I32, P],
     "ippm_reset_episode": [P, P, P, P, P, P, P, P, P, P, P, I32, P],
+    "ippm_reset_maps": [P, P, P, P, P, P, P, P, P, P, I32, I32, P],
     "ippm_logodds_to_prob": [P, P, P, I64, P],
     "ippm_prob_to_logodds": [P, P, P, I64, P],
     "ippm_footprint": [P, P, P, P, I32, P],

@@ -82,6 +82,7 @@ class VecEnv:
         self.terrain = terrain
         self._field = None
         self._pending_t = None   # step whose fusion (K4 + K5) build_observations has already launched
+        self._boxes_valid = False  # ws holds, per map, the box of everything written since the last reset (kept by the plan kernel)
         self._profile = False    # time the kernels with events bound to their dispatches (bench.py's roofline legs)
         self._ep_host = None     # pinned staging buffer of reset()'s episode ids, and the event of its last copy
         self._ep_copied = None
@@ -165,9 +166,12 @@ class VecEnv:
         self.episode.copy_(self._ep_host, non_blocking=True)
         self._ep_copied = torch.cuda.Event()
         self._ep_copied.record()
+        # Env-only form: the prior fill of the maps and the start-position sensing are ONE pass (ippm_reset_maps, below, once the
+        # terrain is in place) over the box each map was written in; with tracked area sums: full fills here, then a K3 launch.
+        one_pass = not self.track_area and d.vec == 4
         self.ctx.call("ippm_reset_episode", self._p(self.episode), self._p(self.pos),
-                      self._p(self.truth) if truth is None and terrain == "split" else None, self._p(self.local),
-                      self._p(self.glob),
+                      self._p(self.truth) if truth is None and terrain == "split" else None,
+                      None if one_pass else self._p(self.local), None if one_pass else self._p(self.glob),
                       self._p(self.split_pct), self._p(self.comm_range), self._p(self.ws), self._p(self.sums), self._area_arg,
                       self.E, self.stream)
         if truth is not None:
@@ -186,9 +190,21 @@ class VecEnv:
         self.t = 0
         self._pending_t = None
         self._obs_t = None
-        self.sense(stage=0, flips=flips)
+        if one_pass:
+            self.ctx.call("ippm_reset_maps", self._p(self.episode), self._p(self.pos), self._p(self.truth), self._p(self.local),
+                          self._p(self.glob), self._p(flips), self._p(self.code), self._p(self.rect), self._p(self.ws),
+                          0 if self._boxes_valid else 1, self.E, self.stream)
+            self._boxes_valid = True
+        else:
+            self._sense(stage=0, flips=flips)
 
     def sense(self, stage: int, flips: Optional[torch.Tensor] = None, agent: int = -1, close_step: bool = False):
+        """K3 at the current positions, called from outside the batched step (drop-in Agent / Mapping): the maps are then
+        written without the plan kernel's knowledge, so the next reset fills them whole."""
+        self._boxes_valid = False
+        self._sense(stage, flips, agent, close_step)
+
+    def _sense(self, stage: int, flips: Optional[torch.Tensor] = None, agent: int = -1, close_step: bool = False):
         """K3 at the current positions (stage 0 = start sensing, t+1 = sensing of step t).  ``close_step``: this is the K3
         that ends a batched step -- it takes the footprints K1 projected (rect_next) and completes the step's reward."""
         self.ctx.call("ippm_sense_step", self._p(self.episode), self._p(self.pos), self._p(self.truth), self._p(self.local),
@@ -202,6 +218,7 @@ class VecEnv:
 
     def fuse_local(self, agent: int = -1):
         """Stand-alone K4 (drop-in Agent.receive_messages); does not track the area sums."""
+        self._boxes_valid = False
         self.ctx.call("ippm_fuse_local", self._p(self.local), self._p(self.code), self._p(self.rect), self._p(self.pos),
                       self._p(self.comm), self._p(self.ws), agent, self.E, self.stream)
 
@@ -282,7 +299,7 @@ class VecEnv:
             self.ctx.call("ippm_critic_features", self._p(self.area), self._p(self.rect), self._p(self.pos_pre),
                           self._p(self.action), self._p(self.obs), self._p(self.state), self.E, self.stream)
             state = self.state
-        self.sense(stage=t + 1, flips=flips, close_step=True)
+        self._sense(stage=t + 1, flips=flips, close_step=True)
         self.t = t + 1
         return self.reward, t == d.budget, state
 
@@ -329,7 +346,7 @@ class VecEnv:
     def step_graphed(self, t: int):
         """One random-policy env step: graph replay (comm, plans, K1, K4, K5) + K3."""
         self._graphs[t].replay()
-        self.sense(stage=t + 1, close_step=True)
+        self._sense(stage=t + 1, close_step=True)
         self.t = t + 1
         return self.reward, t == self.d.budget
 
