@@ -314,14 +314,15 @@ def main():
     if fuse:
         by = fusion_bytes(rl_counters) / fuse["launches"]
         roofline_kernels.append(roofline_entry(
-            "k_fuse_rows", "K4 local fusion + K5 global fusion and reward terms, one launch", by, fuse,
+            "k_fuse_tiles" if "tiles" in fuse["kernel"] else "k_fuse_rows", "K4 local fusion + K5 global fusion and reward terms, one launch", by, fuse,
             {"algorithmic_bytes": "8 B per cell of the union (R+W once) + 1 B per (cell, message) code read",
              "local_cells_per_launch": rl_counters["fuse_local_cells"] / fuse["launches"],
              "global_cells_per_launch": rl_counters["fuse_global_cells"] / fuse["launches"],
              "message_cells_per_launch": (rl_counters["fuse_local_ops"] + rl_counters["fuse_global_ops"]) / fuse["launches"]}))
     if roofline_kernels is not None:
         for cls, what in (("plan", "comm matrix + fusion plans + work list + K1, one wavefront per env"),
-                          ("reset", "episode reset: scalars and prior fills (per kernel launch)"),
+                          ("reset", "episode reset: device MT19937 scalars (and, with tracked area sums, the prior fills) per kernel launch"),
+                          ("reset_maps", "episode reset: prior fill of the box each map was written in + start-position sensing, one launch"),
                           ("terrain", "random-field synthesis passes (per kernel launch)")):
             if cls in times:
                 roofline_kernels.append({"kernel": times[cls]["kernel"], "what": what, "avg_launch_us": times[cls]["avg_us"],

@@ -145,6 +145,7 @@ int ippm_read_counters(ippm_ctx* ctx, ippm_counters* out, int reset, void* strea
 #define IPPM_T_CRITIC_FEAT 4  /* K6 critic */
 #define IPPM_T_RESET 5        /* reset: scalars, truth split, prior fills */
 #define IPPM_T_TERRAIN 6      /* random-field synthesis passes */
+#define IPPM_T_RESET_MAPS 7   /* ippm_reset_maps: box-limited prior fill + start-position sensing */
 #define IPPM_TIMED_CLASSES 8
 int ippm_kernel_timing(ippm_ctx* ctx, int32_t enable);
 int ippm_read_kernel_times(ippm_ctx* ctx, int32_t cls, int32_t reset, int64_t* launches, double* total_us, double* min_us,

@@ -3,6 +3,8 @@
 // and the target-class F1 counts.  The per-candidate reduction streams a footprint tile of the agent's local map
 // exactly like K3 does (4 grid-aligned cells per lane), accumulates in float64 and is deterministic (no atomics), so
 // candidates with identical cell multisets get bit-identical gains and argmax ties resolve like the reference's.
+#include <cstdlib>
+
 #include "ippm_internal.h"
 
 __device__ __forceinline__ void ig_action_offset(int A, int a, int s, int& dx, int& dy, int& dz) {
@@ -106,6 +108,88 @@ k_ig_candidates(const ippm_config* __restrict__ c, const float* __restrict__ loc
   if (threadIdx.x == 0) gains[cand] = (float)(s[0] / 1000.0);
 }
 
+
+// K9, union walk for the 3 x 3 action sets (9 actions: one layer; 27: three altitude layers): the nine candidates of a layer are
+// the same footprint shifted by one lattice step, so they overlap heavily (at 15 m: 9 footprints of 90 x 90 cells inside a
+// 150 x 150 hull, 3.6 cells of candidate per cell of hull) and a cell's expected gain depends on the layer's altitude only.
+// One workgroup per (env, agent, layer) evaluates every cell of the hull ONCE and adds it to every candidate that holds it:
+// membership is separable (the row offset decides the rows, the column offset the columns), i.e. 3 + 3 range tests per cell.
+// (For the 6-action set -- 5 candidates at 3 altitudes -- the per-candidate kernel stays: measured 1.4x fewer evaluations
+// there, not enough to pay for the bookkeeping.)  Sums in float64, lane-striped then a fixed tree: deterministic.
+__global__ void __launch_bounds__(256)
+k_ig_union(const ippm_config* __restrict__ c, const float* __restrict__ local, const int32_t* __restrict__ pos,
+           const uint8_t* __restrict__ mask, float* __restrict__ gains) {
+  const int n = c->n_agents, A = c->n_actions, layers = A / 9;
+  const int layer = blockIdx.x % layers, i = (blockIdx.x / layers) % n, e = blockIdx.x / (layers * n);
+  const int gx = c->grid_x, gy = c->grid_y, s = c->spacing;
+  const int32_t* p = pos + (size_t)(e * n + i) * 3;
+  const size_t cand0 = (size_t)(e * n + i) * A + layer * 9;
+  const int dz = A == 27 ? (1 - layer) * s : 0;
+  // the three row ranges (offset -1, 0, +1 lattice steps in x) and the three column ranges of the layer's footprints
+  int xl[3], xr[3], yu[3], yd[3];
+#pragma unroll
+  for (int o = 0; o < 3; ++o) {
+    int r[4];
+    ippm_footprint_rect(c, p[0] + (o - 1) * s, p[1], p[2] + dz, r, nullptr);
+    xl[o] = r[2]; xr[o] = r[3];
+    ippm_footprint_rect(c, p[0], p[1] + (o - 1) * s, p[2] + dz, r, nullptr);
+    yu[o] = r[0]; yd[o] = r[1];
+  }
+  // (a masked candidate may lie outside the lattice: its table lookups above read a neighbouring entry, and it is never used)
+  bool ok[9];
+  int X0 = gx, X1 = 0, Y0 = gy, Y1 = 0;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    ok[q] = mask[cand0 + q] != 0;
+    if (ok[q]) { X0 = min(X0, xl[q / 3]); X1 = max(X1, xr[q / 3]); Y0 = min(Y0, yu[q % 3]); Y1 = max(Y1, yd[q % 3]); }
+  }
+  const int k = ippm_alt_index(c, p[2] + dz);
+  const float ln = c->logit_noise[k];
+  const float kp = __expf(ln), km = __expf(-ln), ec = __expf(-c->logit_clip);
+  const float lc = c->logit_clip, wt = c->logit_weight_thr;
+  const float* map = local + (size_t)(e * n + i) * gx * gy;
+  double acc[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) acc[q] = 0.0;
+  const int y0 = Y0 & ~3;
+  const int groups = X1 > X0 && Y1 > Y0 ? (Y1 - y0 + 3) >> 2 : 0, h = X1 - X0;
+  for (int idx = threadIdx.x; idx < h * groups; idx += blockDim.x) {
+    const int row = idx / groups, gi = idx - row * groups;
+    const int x = X0 + row, y = y0 + gi * 4;
+    float v[4];
+    if (y + 4 <= gy) { const float4 t = *reinterpret_cast<const float4*>(map + (size_t)x * gy + y); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    else { for (int q = 0; q < 4; ++q) v[q] = y + q < gy ? map[(size_t)x * gy + y + q] : 0.f; }
+    bool inx[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) inx[o] = x >= xl[o] && x < xr[o];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int yy = y + j;
+      bool iny[3], any = false;
+#pragma unroll
+      for (int o = 0; o < 3; ++o) iny[o] = yy >= yu[o] && yy < yd[o];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) any |= ok[q] && inx[q / 3] && iny[q % 3];
+      if (!any) continue;
+      // IG_baseline.py:236-268 in log-odds: belief clipped once, hypothetical posteriors L +- ln
+      const double g = (double)ig_cell(ippm_clampl(v[j], lc), ln, kp, km, ec, lc, wt);
+#pragma unroll
+      for (int q = 0; q < 9; ++q) acc[q] += ok[q] && inx[q / 3] && iny[q % 3] ? g : 0.0;
+    }
+  }
+  __shared__ double sh[9][256];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) sh[q][threadIdx.x] = acc[q];
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o)
+#pragma unroll
+      for (int q = 0; q < 9; ++q) sh[q][threadIdx.x] += sh[q][threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x < 9) gains[cand0 + threadIdx.x] = ok[threadIdx.x] ? (float)(sh[threadIdx.x][0] / 1000.0) : 0.f;
+}
+
 // K10: get_relative_ig + get_cell_utilities + select_action (IG_baseline.py:270-325), one wavefront per env.
 // The reference walks the agents in order and discounts candidate (i, a1) IN PLACE by every other agent's candidate that lands
 // on the same lattice point: rel[i,a1] = g1 * (1 - rel[j,a2]), last match wins, where rel[j,a2] is already discounted for
@@ -192,7 +276,11 @@ extern "C" int ippm_ig_candidates(ippm_ctx* ctx, const float* local, const int32
   if (!ctx || !local || !pos || !mask || !gains) { ippm_set_error("ippm_ig_candidates: null argument"); return -1; }
   const int total = n_envs * ctx->cfg.n_agents * ctx->cfg.n_actions;
   if (total <= 0) return 0;
-  hipLaunchKernelGGL(k_ig_candidates, dim3(total), dim3(256), 0, S_(stream), ctx->dcfg, local, pos, mask, gains);
+  const int A = ctx->cfg.n_actions;
+  if ((A == 9 || A == 27) && ctx->cfg.grid_y >= 4 && !getenv("IPPM_IG_PER_CANDIDATE"))   // 3 x 3 sets: one walk of the hull per layer
+    hipLaunchKernelGGL(k_ig_union, dim3(n_envs * ctx->cfg.n_agents * (A / 9)), dim3(256), 0, S_(stream), ctx->dcfg, local, pos, mask, gains);
+  else
+    hipLaunchKernelGGL(k_ig_candidates, dim3(total), dim3(256), 0, S_(stream), ctx->dcfg, local, pos, mask, gains);
   IPPM_LAUNCH_CHECK("ig_candidates");
   return 0;
 }

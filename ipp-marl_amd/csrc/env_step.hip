@@ -438,13 +438,15 @@ k_sense_tiles(const ippm_config* __restrict__ c, const int64_t* __restrict__ epi
 //     1.6 GB written to store one constant.  full != 0 (first use, or maps written behind the planner's back): whole maps.
 //   - A local map's start footprint gets its first measurement right here (K3's arithmetic on a prior cell: clamp(prior) + the
 //     measurement's log-odds) instead of fill -> read -> modify -> write by a K3 launch of its own.
-// Two kinds of workgroup share the launch and write disjoint cells.  FILL workgroups (blockIdx.x < fill_chunks): 4 rows of one
-// map, one row per wavefront, one 16-byte store per lane (the streaming shape of the copy probe); they skip the 4-cell groups that
-// meet the map's start footprint, and rows outside the box cost an early exit.  SENSE workgroups: a 32-row part of one agent's
+// Two kinds of workgroup share the launch and write disjoint cells.  FILL workgroups (blockIdx.x < fill_chunks): 32 rows of one
+// map, 8 rows per wavefront, one 16-byte store per lane and row; they skip the 4-cell groups that meet the map's start footprint,
+// and rows outside the box cost an early exit.  SENSE workgroups: a 32-row part of one agent's
 // start footprint in K3's dense lane geometry (a 90-cell footprint row = 3 passes of 8 lanes; a row-per-wavefront layout would
 // run the Philox rounds on 23 of 64 lanes), writing whole groups -- measured cells and the prior cells that share their groups.
 // ------------------------------------------------------------------------------------------------------
-#define IPPM_RESET_ROWS 4
+#ifndef IPPM_RESET_ROWS
+#define IPPM_RESET_ROWS 32   // rows per FILL workgroup = 4 wavefronts x 8 rows.  One row per wavefront ran at the pace of wavefront
+#endif                       // launches (1.4 M of them: 310 us for 0.9 GB); 8 / 16 / 32 rows per workgroup: 201 / 180 / 148 us
 __global__ void __launch_bounds__(256)
 k_reset_maps(const ippm_config* __restrict__ c, const int64_t* __restrict__ episode, const int32_t* __restrict__ pos,
              const uint8_t* __restrict__ truth, float* __restrict__ local, float* __restrict__ global, const uint8_t* __restrict__ flips,
@@ -479,19 +481,30 @@ k_reset_maps(const ippm_config* __restrict__ c, const int64_t* __restrict__ epis
       w[WS_BBOX_X] = xl | (xr << 16);
       w[WS_BBOX_Y] = yu | (yd << 16);
     }
-    const int x = blockIdx.x * IPPM_RESET_ROWS + wv;
-    if (x >= gx || x < bx0 || x >= bx1 || by1 <= by0) return;
-    const bool fp_row = x >= xl && x < xr;
+    if (by1 <= by0) return;
     const ippm_k3_u4 t = {__float_as_uint(lp), __float_as_uint(lp), __float_as_uint(lp), __float_as_uint(lp)};
+    // a wavefront takes IPPM_RESET_ROWS / 4 consecutive rows, a lane one 16-byte store in each of them (all in flight together)
+    constexpr int RPW = IPPM_RESET_ROWS / 4;
+    const int xw = blockIdx.x * IPPM_RESET_ROWS + wv * RPW;
+    if (xw >= bx1 || xw + RPW <= bx0) return;
     for (int g = (by0 >> 2) + lane; g < ((by1 + 3) >> 2); g += 64) {
-      if (fp_row && g >= fg0 && g < fg1) continue;   // a SENSE workgroup writes this group
-      const int y = g * 4, off = (x * gy + y) * 4;
-      if (mis && y + 4 > gy) {   // a row's last group hangs over into the next row: cell by cell
-        __builtin_amdgcn_raw_buffer_store_b32(t.x, rmap, off, 0, 0);
-        if (y + 1 < gy) __builtin_amdgcn_raw_buffer_store_b32(t.x, rmap, off + 4, 0, 0);
-        if (y + 2 < gy) __builtin_amdgcn_raw_buffer_store_b32(t.x, rmap, off + 8, 0, 0);
-      } else {
-        __builtin_amdgcn_raw_buffer_store_b128(t, rmap, off, 0, 2);   // non-temporal: written once, read a step later at the earliest
+      const int y = g * 4;
+      const bool fp_col = g >= fg0 && g < fg1;
+#pragma unroll
+      for (int u = 0; u < RPW; ++u) {
+        const int x = xw + u;
+        // outside the box, or a group a SENSE workgroup writes: the store goes nowhere
+        const bool skip = x < bx0 || x >= bx1 || x >= gx || (fp_col && x >= xl && x < xr);
+        const int off = (x * gy + y) * 4;
+        if (mis && y + 4 > gy) {   // a row's last group hangs over into the next row: cell by cell
+          if (!skip) {
+            __builtin_amdgcn_raw_buffer_store_b32(t.x, rmap, off, 0, 0);
+            if (y + 1 < gy) __builtin_amdgcn_raw_buffer_store_b32(t.x, rmap, off + 4, 0, 0);
+            if (y + 2 < gy) __builtin_amdgcn_raw_buffer_store_b32(t.x, rmap, off + 8, 0, 0);
+          }
+        } else {
+          __builtin_amdgcn_raw_buffer_store_b128(t, rmap, skip ? IPPM_K3_OOB : off, 0, 2);   // non-temporal: read a step later at the earliest
+        }
       }
     }
     return;
@@ -641,7 +654,7 @@ extern "C" int ippm_reset_maps(ippm_ctx* ctx, const int64_t* episode, const int3
   for (int k = 0; k < c.space_z; ++k) h_max = std::max(h_max, 2 * c.radius_x[k]);
   const int fill_chunks = (c.grid_x + IPPM_RESET_ROWS - 1) / IPPM_RESET_ROWS, sense_parts = (h_max + 31) / 32;
   dim3 grid((unsigned)(fill_chunks + sense_parts), (unsigned)(c.n_agents + 1), (unsigned)n_envs);
-  IPPM_LAUNCH(ctx, IPPM_T_RESET, k_reset_maps, grid, dim3(256), S_(stream), ctx->dcfg, episode, pos, truth, local, global, flips, code, rect,
+  IPPM_LAUNCH(ctx, IPPM_T_RESET_MAPS, k_reset_maps, grid, dim3(256), S_(stream), ctx->dcfg, episode, pos, truth, local, global, flips, code, rect,
               ws, full ? 1 : 0, fill_chunks);
   IPPM_LAUNCH_CHECK("reset_maps");
   return 0;

@@ -18,7 +18,7 @@ WS_WORDS = 160
 FEAT, ACTOR_PLANES, CRITIC_PLANES = 11, 7, 12
 STEP_COMM, STEP_GLOBAL, STEP_MOVE, STEP_TILES = 1, 2, 4, 8   # ippm_plan_step flags
 # kernel classes of ippm_read_kernel_times (IPPM_T_*)
-TIMED = {"sense": 0, "fuse": 1, "plan": 2, "actor_features": 3, "critic_features": 4, "reset": 5, "terrain": 6}
+TIMED = {"sense": 0, "fuse": 1, "plan": 2, "actor_features": 3, "critic_features": 4, "reset": 5, "terrain": 6, "reset_maps": 7}
 
 
 class IppmConfig(C.Structure):

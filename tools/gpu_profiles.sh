@@ -13,6 +13,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o p -- $BENCH > /dev/nu
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o p -- $BENCH > /dev/null 2> $OUT/write.err
 python tools/pmc_summary.py $(find $OUT/fetch -name "*.db" | head -1) $(find $OUT/write -name "*.db" | head -1) \
   $(find $OUT/trace -name "*.db" | head -1) 1024 4 256 $OUT/pmc_summary.json > $OUT/pmc_summary.log 2>&1
+python tools/trace_summary.py $(find $OUT/trace -name "*.db" | head -1) > $OUT/trace_summary.txt 2>&1
 tail -40 $OUT/pmc_summary.log
 head -12 $OUT/kernel_stats_bench_steps60.csv
 rm -rf $OUT/fetch $OUT/write $OUT/trace $OUT/stats
