@@ -143,7 +143,10 @@ __global__ void __launch_bounds__(256) k_bias_relu(float4* __restrict__ x, const
   if (i >= n4) return;
   const float4 b = bias[i % (size_t)c4];
   float4 v = x[i];
-  v.x = fmaxf(v.x + b.x, 0.f); v.y = fmaxf(v.y + b.y, 0.f); v.z = fmaxf(v.z + b.z, 0.f); v.w = fmaxf(v.w + b.w, 0.f);
+  // relu that lets NaN through like torch.relu (fmaxf(NaN, 0) = 0 would hide a diverged activation): x > 0 ? x : (x != x ? x : 0)
+  v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+  v.x = v.x > 0.f ? v.x : (v.x != v.x ? v.x : 0.f); v.y = v.y > 0.f ? v.y : (v.y != v.y ? v.y : 0.f);
+  v.z = v.z > 0.f ? v.z : (v.z != v.z ? v.z : 0.f); v.w = v.w > 0.f ? v.w : (v.w != v.w ? v.w : 0.f);
   x[i] = v;
 }
 

@@ -9,6 +9,7 @@ the path.  ``save_actor`` writes a whole-module pickle that names the REFERENCE'
 from __future__ import annotations
 
 import pickle
+import threading
 from typing import Dict
 
 import torch
@@ -21,6 +22,9 @@ _ALIASES = {
     ("critic.network", "CriticNetwork"): CriticNetwork,
     ("marl_framework.critic.network", "CriticNetwork"): CriticNetwork,
 }
+
+
+_SAVE_LOCK = threading.Lock()   # save_actor re-registers the class under another module path for the duration of a save
 
 
 class _Unpickler(pickle.Unpickler):
@@ -53,30 +57,33 @@ def save_actor(actor: ActorNetwork, path: str, reference_class_path: str = "acto
     pickle stores classes by (module, name) and insists that importing that name yields the very class being pickled, so
     for the duration of the save the class is registered under ``reference_class_path`` (the reference's scripts run with
     marl_framework/ as the working directory: ``actor.network``).  Only module state travels in the pickle (parameters,
-    buffers, the ``params`` dict, plain attributes), all of which the reference's class accepts through ``__setstate__``."""
+    buffers, the ``params`` dict, plain attributes), all of which the reference's class accepts through ``__setstate__``; the
+    reference's ``__init__`` does not run on load, so ActorNetwork carries the plain attributes its methods read (``device``, the
+    epsilon schedule, ``log_softmax`` ...) under the reference's names."""
     import sys
     import types
     cls = type(actor)
-    saved_module = cls.__module__
     parts = reference_class_path.split(".")
-    created = []
-    for k in range(1, len(parts) + 1):
-        name = ".".join(parts[:k])
-        if name not in sys.modules:
-            sys.modules[name] = types.ModuleType(name)
-            created.append(name)
-    holder = sys.modules[reference_class_path]
-    had = getattr(holder, cls.__name__, None)
-    try:
-        setattr(holder, cls.__name__, cls)
-        cls.__module__ = reference_class_path
-        torch.save(actor, path)
-    finally:
-        cls.__module__ = saved_module
-        if had is None:
-            delattr(holder, cls.__name__)
-        else:
-            setattr(holder, cls.__name__, had)
-        for name in created:
-            del sys.modules[name]
+    with _SAVE_LOCK:   # (process-global state: cls.__module__ and sys.modules)
+        saved_module = cls.__module__
+        created = []
+        for k in range(1, len(parts) + 1):
+            name = ".".join(parts[:k])
+            if name not in sys.modules:
+                sys.modules[name] = types.ModuleType(name)
+                created.append(name)
+        holder = sys.modules[reference_class_path]
+        had = getattr(holder, cls.__name__, None)
+        try:
+            setattr(holder, cls.__name__, cls)
+            cls.__module__ = reference_class_path
+            torch.save(actor, path)
+        finally:
+            cls.__module__ = saved_module
+            if had is None:
+                delattr(holder, cls.__name__)
+            else:
+                setattr(holder, cls.__name__, had)
+            for name in created:
+                del sys.modules[name]
     torch.save(actor.state_dict(), path + ".state_dict")

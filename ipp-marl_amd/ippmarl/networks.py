@@ -46,6 +46,8 @@ class _ConvDataGradAsGemm(torch.autograd.Function):
     output positions): one hipBLASLt GEMM at the forward's rate plus a memory-bound scatter.  Forward, weight and bias
     gradients stay with the library."""
 
+    COLS_LIMIT = 3 << 30   # bytes of the column matrix of one slice (below the 4 GB at which 32-bit byte offsets wrap)
+
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
@@ -66,12 +68,20 @@ class _ConvDataGradAsGemm(torch.autograd.Function):
             C, K = weight.shape[1], weight.shape[2]
             g = grad_out.permute(0, 2, 3, 1).reshape(B * Ho * Wo, O)                  # [B*L, O] (a view for channels-last)
             if grad_out.is_cuda and C % 4 == 0 and weight.shape[2] == weight.shape[3]:
-                # tap-major, channel-minor columns: the gather kernel of libippmarl reads and writes channels-last rows
-                cols = g.contiguous() @ weight.permute(0, 2, 3, 1).reshape(O, -1)     # [B*L, K*K*C]
+                # tap-major, channel-minor columns: the gather kernel of libippmarl reads and writes channels-last rows.
+                # The column matrix is K*K times the size of grad_out (3.2 GB for a 12 288-sample minibatch of conv2): batches
+                # whose columns would pass COLS_LIMIT bytes go through in slices of the batch
                 from . import _ffi
-                grad_x = torch.empty(B, Ho + K - 1, Wo + K - 1, C, dtype=cols.dtype, device=cols.device)
-                _ffi.check(_ffi.load_library().ippm_col2im_nhwc(_ffi.ptr(cols), _ffi.ptr(grad_x), B, Ho, Wo, K, C,
-                                                                torch.cuda.current_stream(cols.device).cuda_stream), "ippm_col2im_nhwc")
+                lib, stream = _ffi.load_library(), torch.cuda.current_stream(grad_out.device).cuda_stream
+                w2 = weight.permute(0, 2, 3, 1).reshape(O, -1)                        # [O, K*K*C]
+                grad_x = torch.empty(B, Ho + K - 1, Wo + K - 1, C, dtype=grad_out.dtype, device=grad_out.device)
+                g = g.contiguous()
+                per_sample = Ho * Wo * K * K * C * g.element_size()
+                step = max(1, min(B, _ConvDataGradAsGemm.COLS_LIMIT // per_sample))
+                for lo in range(0, B, step):
+                    nb = min(step, B - lo)
+                    cols = g[lo * Ho * Wo:(lo + nb) * Ho * Wo] @ w2                   # [nb*L, K*K*C]
+                    _ffi.check(lib.ippm_col2im_nhwc(_ffi.ptr(cols), grad_x[lo:lo + nb].data_ptr(), nb, Ho, Wo, K, C, stream), "ippm_col2im_nhwc")
                 grad_x = grad_x.permute(0, 3, 1, 2)                                   # logical NCHW, channels-last strides
             else:
                 cols = g @ weight.reshape(O, -1)                                       # [B*L, C*kh*kw]
@@ -134,6 +144,8 @@ class _ConvTrunk(nn.Module):
 
     def _conv_relu(self, conv: nn.Conv2d, x: torch.Tensor, data_grad_as_gemm: bool):
         """activation(conv(x)); on the device the convolution runs bias-free and bias + ReLU are one in-place pass."""
+        # (both paths below, and _ConvDataGradAsGemm's backward, are written for the unpadded stride-1 layers of the reference)
+        assert tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (0, 0) and tuple(conv.dilation) == (1, 1) and conv.groups == 1
         conv2d = _ConvDataGradAsGemm.apply if data_grad_as_gemm else torch.nn.functional.conv2d
         if x.is_cuda and FUSED_BIAS_RELU:
             out = conv2d(x, conv.weight, None)
@@ -175,6 +187,18 @@ class ActorNetwork(_ConvTrunk):
         self.n_actions = params["experiment"]["constraints"]["num_actions"]
         super().__init__(7, self.n_actions)
         self.softmax = nn.Softmax(dim=1)
+        # The plain attributes of the reference's class (actor/network.py:13-39).  A whole-module pickle of this object is
+        # unpickled by the reference WITHOUT running its __init__ (checkpoint.save_actor), so everything its methods read --
+        # get_action_index uses device and the epsilon schedule -- has to travel in our __dict__.
+        m = params["experiment"]["missions"]
+        self.mission_type = m["type"]
+        self.hidden_dim = params["networks"]["actor"]["hidden_dim"]
+        self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.log_softmax = nn.LogSoftmax(dim=1)
+        self.hidden_states = [[]] * self.n_agents
+        self.eps_max, self.eps_min, self.eps_anneal_phase, self.use_eps = m["eps_max"], m["eps_min"], m["eps_anneal_phase"], m["use_eps"]
+        self.network_type = params["networks"]["type"]
+        self.baseline = "no"
 
     def forward(self, input_state: torch.Tensor, eps: float):
         """-> ((1-eps) * softmax + eps / n_actions, hidden) (actor/network.py:70-88)."""

@@ -44,13 +44,27 @@ class GradAllReducer:
         self.calls = 0
         self.flat: Optional[torch.Tensor] = None
         self.spans = {}   # id(module) -> (lo, hi) in elements
+        self.skip = self.unused_fc2
+        self.modules: List[torch.nn.Module] = []
 
     @staticmethod
-    def _trainable(module: torch.nn.Module):
-        return [p for n, p in module.named_parameters() if p.requires_grad and not n.startswith("fc2")]
+    def unused_fc2(name: str) -> bool:
+        """The default ``skip`` of attach(): ``fc2`` of the reference's convnets exists but is never used in forward."""
+        return name.startswith("fc2")
 
-    def attach(self, *modules: torch.nn.Module):
+    def _trainable(self, module: torch.nn.Module):
+        return [p for n, p in module.named_parameters() if p.requires_grad and not self.skip(n)]
+
+    def attach(self, *modules: torch.nn.Module, skip=None):
+        """``skip(name) -> bool``: parameters that never receive a gradient and stay out of the buffer (default: the unused
+        ``fc2``).  A parameter that is skipped here but does get a gradient would silently never be averaged: check_covered()
+        (called by the trainer after its first backward pass) catches that."""
+        self.skip = skip or self.unused_fc2
+        self.modules = list(modules)
         params = [p for m in modules for p in self._trainable(m)]
+        assert params, "attach: nothing to reduce"
+        assert all(p.dtype == params[0].dtype and p.device == params[0].device for p in params), \
+            "attach: all gradients share one flat buffer, so the parameters must share dtype and device"
         total = sum(p.numel() for p in params)
         self.flat = torch.zeros(total, dtype=params[0].dtype, device=params[0].device)
         off = 0
@@ -61,6 +75,17 @@ class GradAllReducer:
                 off += p.numel()
             self.spans[id(m)] = (lo, off)
         return self
+
+    def check_covered(self):
+        """After a backward pass: every gradient of the attached modules lives in the flat buffer (a skipped parameter that
+        received a gradient would diverge across ranks without any error)."""
+        lo = self.flat.data_ptr()
+        hi = lo + self.flat.numel() * self.flat.element_size()
+        for m in self.modules:
+            for n, p in m.named_parameters():
+                if p.grad is not None and not (lo <= p.grad.data_ptr() < hi):
+                    raise RuntimeError(f"GradAllReducer: parameter {n} has a gradient outside the reduced buffer (skipped by "
+                                       "attach(skip=...) although it is used)")
 
     def zero(self, *modules: torch.nn.Module):
         """Clears the gradients of the modules in place (their views into the flat buffer stay)."""

@@ -50,7 +50,8 @@ class COMATrainer:
             broadcast_module(m)
         # gradients of both nets live in one flat buffer (critic, then actor): the data-parallel average is one all-reduce of a
         # view, and the actor's gradients of minibatch b travel together with the critic's of minibatch b+1
-        self.reducer = GradAllReducer().attach(self.critic, self.actor)
+        self.reducer = GradAllReducer().attach(self.critic, self.actor, skip=GradAllReducer.unused_fc2)
+        self._grads_checked = False
         W, T, E, N = waves_per_update, self.T, self.E, self.N
         dev = self.device
         self.buf_obs = torch.empty(W, T, E, N, 11, 11, 7, device=dev)
@@ -234,6 +235,8 @@ class COMATrainer:
             # gradient exchange of actor(b) and critic(b+1) share one all-reduce (B+1 collectives per pass, not 2B).
             idx = [perm[b * bs:(b + 1) * bs] for b in range(self.batch_number)]
             closs = self.critic_learner.backward(states[idx[0]], actions[idx[0]], td[idx[0]])
+            if not self._grads_checked and eager:   # once: no gradient of the attached nets lives outside the reduced buffer
+                self.reducer.check_covered()
             self.reducer(self.critic)
             q_b = self.critic_learner.apply()
             for b in range(self.batch_number):
@@ -242,6 +245,9 @@ class COMATrainer:
                 aloss, _ = self.actor_learner.backward(obs[idx[b]], actions[idx[b]], masks[idx[b]], q_b, eps)
                 if collect:
                     act_rec.append(self.actor_learner.last)
+                if not self._grads_checked and eager:
+                    self.reducer.check_covered()
+                    self._grads_checked = True
                 if b + 1 < self.batch_number:
                     closs = self.critic_learner.backward(states[idx[b + 1]], actions[idx[b + 1]], td[idx[b + 1]])
                     self.reducer(self.critic, self.actor)

@@ -209,6 +209,11 @@ def test_reference_checkpoint_format_loads(tmp_path):
             self.fc2 = torch.nn.Linear(256, 256); self.fc3 = torch.nn.Linear(256, 6)
             self.device = torch.device("cpu"); self.hidden_states = [[]] * 4; self.baseline = "no"
 
+        def reads_what_get_action_index_reads(self, num_episode):   # actor/network.py:41-68: device and the epsilon schedule
+            eps = self.eps_min if num_episode > self.eps_anneal_phase else \
+                self.eps_max - num_episode / self.eps_anneal_phase * (self.eps_max - self.eps_min)
+            return torch.zeros(1).to(self.device), eps, self.use_eps, self.n_actions, self.log_softmax, self.hidden_states
+
     RefActor.__module__, RefActor.__qualname__, RefActor.__name__ = "actor.network", "ActorNetwork", "ActorNetwork"
     mod.ActorNetwork = RefActor
     sys.modules["actor"], sys.modules["actor.network"] = mod_pkg, mod
@@ -241,6 +246,10 @@ def test_reference_checkpoint_format_loads(tmp_path):
     finally:
         del sys.modules["actor"], sys.modules["actor.network"]
     assert type(back) is RefActor and all(torch.equal(a, b) for a, b in zip(actor.parameters(), back.parameters()))
+    # the reference's __init__ did not run on `back`: everything its get_action_index reads came out of our pickle
+    _, eps, use_eps, n_actions, _, hidden = back.reads_what_get_action_index_reads(10)
+    m = params["experiment"]["missions"]
+    assert eps == m["eps_max"] - 10 / m["eps_anneal_phase"] * (m["eps_max"] - m["eps_min"]) and n_actions == 6 and len(hidden) == 4
     sd = torch.load(str(tmp_path / "mine.pth.state_dict"))
     assert set(sd) == set(actor.state_dict())
     assert type(actor).__module__ == "ippmarl.networks" and "actor" not in sys.modules
