@@ -295,7 +295,11 @@ typedef unsigned ippm_k3_u4 __attribute__((ext_vector_type(4)));
 #define IPPM_K3_STORE_AUX 0
 #endif
 
-template <int VEC>
+// MIS: the grid is not a multiple of 4 wide (rows only 4-byte aligned); FLIPS: explicit flip tiles (parity mode) instead of Philox.
+// Both are compile-time so that the production instantiation <4, false, false> carries neither the second Philox call and the
+// cell-by-cell tail stores nor the flips resource (the kernel sits at the SGPR limit: every uniform it holds less is a
+// v_writelane / v_readlane pair less in its instruction stream).
+template <int VEC, bool MIS, bool FLIPS>
 __global__ void __launch_bounds__(256)
 k_sense_tiles(const ippm_config* __restrict__ c, const int64_t* __restrict__ episode, const int32_t* __restrict__ pos,
               const uint8_t* __restrict__ truth, float* __restrict__ local, const uint8_t* __restrict__ flips,
@@ -331,7 +335,7 @@ k_sense_tiles(const ippm_config* __restrict__ c, const int64_t* __restrict__ epi
   const float lc = c->logit_clip;
   const int y0 = yu & ~(VEC - 1), tile_y0 = yu & ~3;
   const int groups = (yd - y0 + VEC - 1) / VEC;
-  const bool mis = VEC == 4 && (gy & 3) != 0;   // rows start at addresses that are only 4-byte aligned
+  constexpr bool mis = MIS;   // rows start at addresses that are only 4-byte aligned
   int shift = 3;
   while (shift < 6 && ((groups + (1 << shift) - 1) >> shift) > CH) ++shift;
   const int lpr = 1 << shift, rpw = 64 >> shift;
@@ -341,7 +345,7 @@ k_sense_tiles(const ippm_config* __restrict__ c, const int64_t* __restrict__ epi
   const __amdgpu_buffer_rsrc_t rmap = IPPM_K3_RSRC(local + (size_t)(e * n + i) * gx * gy, (size_t)gx * gy * 4);
   const __amdgpu_buffer_rsrc_t rtruth = IPPM_K3_RSRC(truth + (size_t)e * ippm_truth_bytes(gx, gy), ippm_truth_bytes(gx, gy));
   const __amdgpu_buffer_rsrc_t rcode = IPPM_K3_RSRC(code + (size_t)(e * n + i) * TB, TB);
-  const __amdgpu_buffer_rsrc_t rflip = IPPM_K3_RSRC(flips ? flips + (size_t)(e * n + i) * TB : code, flips ? TB : 0);
+  const __amdgpu_buffer_rsrc_t rflip = IPPM_K3_RSRC(FLIPS ? flips + (size_t)(e * n + i) * TB : code, FLIPS ? TB : 0);
   const int64_t ep = episode ? episode[e] : 0;
   const uint32_t sw = ippm_stream_word((uint32_t)i, (uint32_t)stage, IPPM_DOMAIN_FLIP);
   const uint32_t k0 = (uint32_t)c->philox_seed, k1 = (uint32_t)(c->philox_seed >> 32);
@@ -370,7 +374,7 @@ k_sense_tiles(const ippm_config* __restrict__ c, const int64_t* __restrict__ epi
         // (grids not a multiple of 4 wide: a group's four truth bits may straddle a byte -- two bytes at any byte address)
         tw[q] = mis ? (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rtruth, on[q] ? (cell >> 3) : IPPM_K3_OOB, 0, 0)
                     : (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rtruth, on[q] ? (cell >> 3) : IPPM_K3_OOB, 0, 0);
-        fw[q] = flips ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rflip, on[q] ? (int)tile_index<VEC>(row, y - tile_y0, S) : IPPM_K3_OOB, 0, 0)
+        fw[q] = FLIPS ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rflip, on[q] ? (int)tile_index<VEC>(row, y - tile_y0, S) : IPPM_K3_OOB, 0, 0)
                       : 0u;
       }
 #pragma unroll
@@ -381,7 +385,7 @@ k_sense_tiles(const ippm_config* __restrict__ c, const int64_t* __restrict__ epi
         const int cell = cellv[q];
         const uint32_t tbits = VEC == 4 ? (tw[q] >> (cell & 7)) & 0xFu : (tw[q] >> (cell & 7)) & 1u;
         uint32_t flipbits;
-        if (flips) {
+        if (FLIPS) {
           flipbits = fw[q] & (VEC == 4 ? 0xFu : 1u);
         } else if (VEC == 4) {
           flipbits = philox_flip_bits4((uint32_t)cell, (uint32_t)ep, sw, (uint32_t)(ep >> 32), k0, k1, thr, mis);
@@ -730,12 +734,17 @@ extern "C" int ippm_sense_step(ippm_ctx* ctx, const int64_t* episode, const int3
     if (n_envs > 65535) { ippm_set_error("ippm_sense_step: more than 65535 envs per launch"); return -1; }
     dim3 grid((unsigned)parts, (unsigned)(agent_sel >= 0 ? 1 : c.n_agents), (unsigned)n_envs);
     int32_t* rect_out = rect_in == rect ? nullptr : rect;
-    if (ctx->vec == 4)
-      IPPM_LAUNCH(ctx, IPPM_T_SENSE, (k_sense_tiles<4>), grid, block, S_(stream), ctx->dcfg, episode, pos, truth, local, flips, code, rect_in,
-                         rect_out, ws, sums, reward, ctx->dcounters, stage, agent_sel, rows_per_part);
-    else
-      IPPM_LAUNCH(ctx, IPPM_T_SENSE, (k_sense_tiles<1>), grid, block, S_(stream), ctx->dcfg, episode, pos, truth, local, flips, code, rect_in,
-                         rect_out, ws, sums, reward, ctx->dcounters, stage, agent_sel, rows_per_part);
+#define IPPM_K3T(V, M, F)                                                                                                   \
+  IPPM_LAUNCH(ctx, IPPM_T_SENSE, (k_sense_tiles<V, M, F>), grid, block, S_(stream), ctx->dcfg, episode, pos, truth, local, flips, code, \
+              rect_in, rect_out, ws, sums, reward, ctx->dcounters, stage, agent_sel, rows_per_part)
+    const bool mis = (c.grid_y & 3) != 0;
+    if (ctx->vec == 4) {
+      if (flips) { if (mis) IPPM_K3T(4, true, true); else IPPM_K3T(4, false, true); }
+      else { if (mis) IPPM_K3T(4, true, false); else IPPM_K3T(4, false, false); }
+    } else {
+      if (flips) IPPM_K3T(1, false, true); else IPPM_K3T(1, false, false);
+    }
+#undef IPPM_K3T
     IPPM_LAUNCH_CHECK("sense_tiles");
     return 0;
   }

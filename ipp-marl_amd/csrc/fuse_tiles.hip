@@ -49,7 +49,7 @@ struct TileAcc {   // per wavefront, over all its items (all of one env)
 };
 
 // One item with at most NA ops (spare slots first) and SLOTS loads in flight per lane.
-template <int NA, int SLOTS>
+template <int NA, int SLOTS, bool MIS>
 __device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e, int slot, int x0, int nr, int g0, int W, unsigned active) {
   const int map_abs = e * (w.n + 1) + slot;
   const bool is_global = slot == w.n;
@@ -185,8 +185,8 @@ __device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e,
       ippm_t_u4 v;
       v.x = __float_as_uint(out[0]); v.y = __float_as_uint(out[1]); v.z = __float_as_uint(out[2]); v.w = __float_as_uint(out[3]);
       // a lane-load past the item's end was never in range; a group no op touches cannot occur inside an interval
-      if ((w.gy & 3) != 0) {
-        // (uniform) rows are not a multiple of 4 wide: the last group of a row hangs over into the next row -- its cells go out
+      if (MIS) {
+        // (compile-time) rows are not a multiple of 4 wide: the last group of a row hangs over into the next row -- its cells go out
         // one by one, another lane owns the rest
         const bool tail = ycol[q] + 4 > w.gy;
         __builtin_amdgcn_raw_buffer_store_b128(v, rmap, tail ? IPPM_T_OOB : off[q], 0, 0);
@@ -232,7 +232,7 @@ __device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e,
 #ifndef IPPM_TILE_WAVES_PER_EU
 #define IPPM_TILE_WAVES_PER_EU 5
 #endif
-template <int NAMAX>
+template <int NAMAX, bool MIS>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(IPPM_TILE_WAVES_PER_EU, 8)))
 k_fuse_tiles(const ippm_config* __restrict__ c, float* __restrict__ local, float* __restrict__ global,
              const uint8_t* __restrict__ code, const int32_t* __restrict__ plan_ro, int32_t* __restrict__ ws,
@@ -266,15 +266,15 @@ k_fuse_tiles(const ippm_config* __restrict__ c, float* __restrict__ local, float
     const int slot = (unsigned)it.w >> 24, x0 = it.y & 0xFFFF, nr = it.y >> 16, g0 = it.z & 0xFFFF, W = it.z >> 16;
     const unsigned active = (unsigned)it.w & 0x00FFFFFFu;
     const int na = __popc(active);
-    if (na == 1) tile_item<1, 4>(w, acc, env, slot, x0, nr, g0, W, active);
-    else if (na == 2) tile_item<2, 4>(w, acc, env, slot, x0, nr, g0, W, active);
-    else if (na == 3) tile_item<3, 4>(w, acc, env, slot, x0, nr, g0, W, active);
-    else if (na == 4) tile_item<4, 4>(w, acc, env, slot, x0, nr, g0, W, active);
-    else if (NAMAX <= 6 || na <= 6) tile_item<(NAMAX < 6 ? NAMAX : 6), 2>(w, acc, env, slot, x0, nr, g0, W, active);
-    else if (na <= 8) tile_item<8, 2>(w, acc, env, slot, x0, nr, g0, W, active);
-    else if (NAMAX <= 10 || na <= 10) tile_item<10, 2>(w, acc, env, slot, x0, nr, g0, W, active);
-    else if (na <= 14) tile_item<14, 1>(w, acc, env, slot, x0, nr, g0, W, active);
-    else tile_item<18, 1>(w, acc, env, slot, x0, nr, g0, W, active);
+    if (na == 1) tile_item<1, 4, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
+    else if (na == 2) tile_item<2, 4, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
+    else if (na == 3) tile_item<3, 4, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
+    else if (na == 4) tile_item<4, 4, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
+    else if (NAMAX <= 6 || na <= 6) tile_item<(NAMAX < 6 ? NAMAX : 6), 2, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
+    else if (na <= 8) tile_item<8, 2, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
+    else if (NAMAX <= 10 || na <= 10) tile_item<10, 2, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
+    else if (na <= 14) tile_item<14, 1, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
+    else tile_item<18, 1, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
     it = nx;
   }
   // the wavefront's reward terms and work counters: one atomic per quantity
@@ -310,12 +310,13 @@ int ippm_launch_fuse_tiles(ippm_ctx* ctx, float* local, float* global, const uin
   // a launch smaller than the chip's wave slots leaves CUs idle: small batches take more wavefronts per env
   while ((long long)per_env * n_envs < 16384 && per_env * 2 <= env_cap && per_env < 256) per_env *= 2;
   dim3 grid((unsigned)n_envs, (unsigned)per_env), block(64);
-  if (max_ops <= 6)
-    IPPM_LAUNCH(ctx, IPPM_T_FUSE, (k_fuse_tiles<6>), grid, block, st, ctx->dcfg, local, global, code, ws, ws, sums, ctx->dcounters, work, n_envs, env_cap);
-  else if (max_ops <= 10)
-    IPPM_LAUNCH(ctx, IPPM_T_FUSE, (k_fuse_tiles<10>), grid, block, st, ctx->dcfg, local, global, code, ws, ws, sums, ctx->dcounters, work, n_envs, env_cap);
-  else
-    IPPM_LAUNCH(ctx, IPPM_T_FUSE, (k_fuse_tiles<18>), grid, block, st, ctx->dcfg, local, global, code, ws, ws, sums, ctx->dcounters, work, n_envs, env_cap);
+#define IPPM_FT(NA, M) \
+  IPPM_LAUNCH(ctx, IPPM_T_FUSE, (k_fuse_tiles<NA, M>), grid, block, st, ctx->dcfg, local, global, code, ws, ws, sums, ctx->dcounters, work, n_envs, env_cap)
+  const bool mis = (c.grid_y & 3) != 0;   // rows only 4-byte aligned: the instantiation with the cell-by-cell row-tail stores
+  if (max_ops <= 6) { if (mis) IPPM_FT(6, true); else IPPM_FT(6, false); }
+  else if (max_ops <= 10) { if (mis) IPPM_FT(10, true); else IPPM_FT(10, false); }
+  else { if (mis) IPPM_FT(18, true); else IPPM_FT(18, false); }
+#undef IPPM_FT
   IPPM_LAUNCH_CHECK("fuse_tiles");
   return 0;
 }

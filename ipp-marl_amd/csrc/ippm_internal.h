@@ -183,7 +183,13 @@ __host__ __device__ __forceinline__ Philox4 ippm_philox(uint32_t c0, uint32_t c1
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
     uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
     uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+#ifdef __HIP_DEVICE_COMPILE__
+    // three-input xor in one instruction (gfx950's v_bitop3_b32, truth table 0x96): the compiler leaves these as two v_xor each,
+    // and the ten rounds of a call are most of K3's instruction stream
+    uint32_t n0 = __builtin_amdgcn_bitop3_b32(hi1, c1, k0, 0x96), n2 = __builtin_amdgcn_bitop3_b32(hi0, c3, k1, 0x96);
+#else
     uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+#endif
     c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
   }
