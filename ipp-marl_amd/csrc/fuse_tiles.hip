@@ -270,8 +270,8 @@ k_fuse_tiles(const ippm_config* __restrict__ c, float* __restrict__ local, float
     else if (na == 2) tile_item<2, 4, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
     else if (na == 3) tile_item<3, 4, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
     else if (na == 4) tile_item<4, 4, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
-    else if (NAMAX <= 6 || na <= 6) tile_item<(NAMAX < 6 ? NAMAX : 6), 2, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
-    else if (na <= 8) tile_item<8, 2, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
+    else if (NAMAX <= 6 || na <= 6) tile_item<(NAMAX < 6 ? NAMAX : 6), IPPM_TILE_SLOTS_MID, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
+    else if (na <= 8) tile_item<8, IPPM_TILE_SLOTS_MID, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
     else if (NAMAX <= 10 || na <= 10) tile_item<10, 2, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
     else if (na <= 14) tile_item<14, 1, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
     else tile_item<18, 1, MIS>(w, acc, env, slot, x0, nr, g0, W, active);

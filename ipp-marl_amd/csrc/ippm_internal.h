@@ -91,7 +91,10 @@ int ippm_launch_fuse_tiles(ippm_ctx* ctx, float* local, float* global, const uin
 #define IPPM_WORK_OVERFLOW 0x20000000  // the env's items did not fit (never, by the bound of ippm_tile_env_cap)
 #define IPPM_WORK_COUNT 0x0FFFFFFF
 // loads in flight per lane of a tile item, by the number of ops that meet it (the code bytes of every op are in flight too)
-__host__ __device__ inline int ippm_tile_slots(int na) { return na <= 4 ? 4 : (na <= 10 ? 2 : 1); }
+#ifndef IPPM_TILE_SLOTS_MID   // loads in flight per lane for items of 5..8 ops (variant builds try 4)
+#define IPPM_TILE_SLOTS_MID 2
+#endif
+__host__ __device__ inline int ippm_tile_slots(int na) { return na <= 4 ? 4 : (na <= 8 ? IPPM_TILE_SLOTS_MID : (na <= 10 ? 2 : 1)); }
 int ippm_launch_plan(ippm_ctx* ctx, const int32_t* rect, const int32_t* pos, const uint8_t* comm, int32_t* ws, int global_maps,
                      int n_envs, int agent_sel, hipStream_t st);
 int ippm_check_hip(hipError_t err, const char* what);
