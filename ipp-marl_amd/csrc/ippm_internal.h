@@ -208,21 +208,29 @@ __host__ __device__ __forceinline__ uint32_t ippm_stream_word(uint32_t agent, ui
 }
 
 // lattice index of a position (agent/state_space.py:53-57)
+// exact floor(n / d) for 0 <= n < 2^20, 0 < d <= 2^14 through one float reciprocal ((n + 1/2) / d is never within 1e-6 of an
+// integer); an integer division by a run-time divisor is a ~35-instruction sequence, and the serial agent loop of K1 holds thirty
+__device__ __forceinline__ int ippm_div_small(int n, float inv_d) { return (int)(((float)n + 0.5f) * inv_d); }
 __device__ __forceinline__ void ippm_pos_to_index(const ippm_config* c, int px, int py, int pz, int& ix, int& iy,
                                                   int& iz) {
-  ix = px / c->spacing;
-  iy = py / c->spacing;
-  iz = pz / c->spacing - 1;
+  const float inv = __builtin_amdgcn_rcpf((float)c->spacing);
+  ix = ippm_div_small(px, inv);
+  iy = ippm_div_small(py, inv);
+  iz = ippm_div_small(pz, inv) - 1;
 }
 __device__ __forceinline__ int ippm_alt_index(const ippm_config* c, int pz) {
-  int k = (pz - c->min_altitude) / c->spacing;
+  const int d = pz - c->min_altitude;
+  int k = d < 0 ? -1 : ippm_div_small(d, __builtin_amdgcn_rcpf((float)c->spacing));
   return k < 0 ? 0 : (k >= c->space_z ? c->space_z - 1 : k);
 }
 
 // Camera.project_field_of_view with host-tabulated centre cells / radii (sensors/cameras.py:62-77)
 __device__ __forceinline__ void ippm_footprint_rect(const ippm_config* c, int px, int py, int pz, int* clipped,
                                                     int* full) {
-  int ix = px / c->spacing, iy = py / c->spacing, k = ippm_alt_index(c, pz);
+  const float inv = __builtin_amdgcn_rcpf((float)c->spacing);
+  // (positions off the lattice only occur for candidates that are masked out: clamped, never used)
+  int ix = min(max(ippm_div_small(max(px, 0), inv), 0), IPPM_MAX_LATTICE - 1), iy = min(max(ippm_div_small(max(py, 0), inv), 0), IPPM_MAX_LATTICE - 1);
+  const int k = ippm_alt_index(c, pz);
   int xl = c->centre_x[ix] - c->radius_x[k], xr = c->centre_x[ix] + c->radius_x[k];
   int yu = c->centre_y[iy] - c->radius_y[k], yd = c->centre_y[iy] + c->radius_y[k];
   if (full) { full[0] = yu; full[1] = yd; full[2] = xl; full[3] = xr; }
