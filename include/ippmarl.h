@@ -91,10 +91,7 @@ typedef struct ippm_config {
   uint32_t flip_threshold[IPPM_MAX_Z];/* observation flipped iff philox word < threshold = floor(noise*2^32) */
   float prior;                        /* mapping.prior; != 0.5 takes the explicit full-grid path of the fusion (every message shifts
                                          every cell; chain in float64 registers, one rounding per fusion: maps and returns at 1e-5
-                                         like the default).  Stated tolerance off the default (the host binding
-                                         warns once): altitudes outside {5, 10, 15} m (noise-free sensor): returns 2e-4 when area
-                                         sums are tracked or prior != 0.5 (float32 lane sums of the row walker), 1e-5 in the
-                                         env-only tile form */
+                                         like the default) */
   float clip_lo, clip_hi;             /* 1e-4, 0.9999 (mappings.py:110-111, state.py:119-120) */
   float logit_prior;                  /* ln(prior/(1-prior)); 0 for the default prior 0.5 */
   float logit_clip;                   /* ln(clip_hi/(1-clip_hi)) = 9.21024...; the clip is symmetric in log-odds */

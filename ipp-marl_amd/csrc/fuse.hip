@@ -63,7 +63,9 @@ struct WaveCtx {   // what a wave needs while it walks its rows
 
 struct WaveAcc {
   bool exceed;
-  float a1, aD, aT;
+  // sum w(a) (H(b) - H(a)) and sum (w(a) - w(b)) H(b) (the increment of T = sum w H is aD - a1): float64 per lane, fed with the
+  // float32 sum of a row's cells -- with noise-free measurements the terms are +-1 and the sums what is left after they cancel
+  double a1, aD;
   unsigned cells, opcells;
 };
 
@@ -263,6 +265,7 @@ __device__ __forceinline__ void walk_slab(const WaveCtx& w, const OpTable& t, Wa
             wsum += wa[q] + wb[q];
           }
           if (__any(wsum != 0.f)) {
+            float r1 = 0.f, rD = 0.f;
 #pragma unroll
             for (int q = 0; q < VEC; ++q) {
               if (SHIFT) {
@@ -272,11 +275,11 @@ __device__ __forceinline__ void walk_slab(const WaveCtx& w, const OpTable& t, Wa
                 sdT += (double)wa[q] * ha - (double)wb[q] * hb;
               } else {
                 const float hb = ippm_entropy_l(bsave[q], w.lc), ha = ippm_entropy_l(mv.v[q], w.lc);
-                acc_out.a1 += wa[q] * (hb - ha);
-                acc_out.aD += (wa[q] - wb[q]) * hb;
-                acc_out.aT += wa[q] * ha - wb[q] * hb;
+                r1 += wa[q] * (hb - ha);
+                rD += (wa[q] - wb[q]) * hb;
               }
             }
+            if (!SHIFT) { acc_out.a1 += (double)r1; acc_out.aD += (double)rD; }
           }
         }
 #endif
@@ -399,7 +402,7 @@ __device__ __forceinline__ void fuse_item(const ippm_config* __restrict__ c, flo
     __syncthreads();
   }
   WaveAcc acc;
-  acc.exceed = false; acc.a1 = acc.aD = acc.aT = 0.f; acc.cells = acc.opcells = 0;
+  acc.exceed = false; acc.a1 = acc.aD = 0.0; acc.cells = acc.opcells = 0;
 
   // slabs that intersect my rows [r0, r1): the table is sorted, the first one is found with one ballot
   int s = __popcll(__ballot(lane < nslabs && st.xb <= r0));
@@ -433,13 +436,13 @@ __device__ __forceinline__ void fuse_item(const ippm_config* __restrict__ c, flo
   // wave reduction of the reward terms and work counters: one atomic per wavefront and quantity
   {
     const float fc = ippm_wave_sum((float)acc.cells), fo = ippm_wave_sum((float)acc.opcells);
-    double a1 = (double)acc.a1, aD = (double)acc.aD, aT = (double)acc.aT;   // the 64 lane sums are added up in float64
+    double a1 = acc.a1, aD = acc.aD;
     if (is_global) {
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { a1 += __shfl_xor(a1, o, 64); aD += __shfl_xor(aD, o, 64); aT += __shfl_xor(aT, o, 64); }
+      for (int o = 32; o > 0; o >>= 1) { a1 += __shfl_xor(a1, o, 64); aD += __shfl_xor(aD, o, 64); }
     }
     if (lane < 3) {
-      const double v = lane == 0 ? a1 : (lane == 1 ? aD : aT);
+      const double v = lane == 0 ? a1 : (lane == 1 ? aD : aD - a1);
       if (is_global && sums && v != 0.0) atomicAdd(&sums[(size_t)e * 8 + SUM_ACC1 + lane], v);
     } else if (lane < 5 && counters) {
       const float v = lane == 3 ? fc : fo;

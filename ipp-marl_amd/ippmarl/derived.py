@@ -7,7 +7,6 @@ the centre-cell and half-width tables are evaluated here with NumPy in the refer
 from __future__ import annotations
 
 import math
-import warnings
 from typing import Dict
 
 import numpy as np
@@ -22,9 +21,6 @@ START_ALTITUDE = 15   # agent/state_space.py:32: state_z = 15
 def _noise(altitude: int) -> float:
     # sensors/models/sensor_models.py:13-22 (coeff_a/coeff_b are never used by the reference)
     return {5: 0.01, 10: 0.265, 15: 0.375}.get(int(altitude), 0)
-
-
-_WARNED = set()   # tolerance notes already issued in this process
 
 
 class DerivedConstants:
@@ -102,19 +98,9 @@ class DerivedConstants:
             with np.errstate(divide="ignore"):
                 self.logit_meas[k] = np.log(y / (1 - y))
             self.flip_threshold[k] = int(math.floor(nz * 4294967296.0))
-        # One regime outside every BASELINE configuration holds the returns to a wider bound than the 1e-5 of the rest (DESIGN.md
-        # section 7, include/ippmarl.h next to `prior`; the parity tests state the same number): said once per process.
+        # altitudes outside the sensor model's table (sensor_models.py:13-22) are noise-free: logit_noise = inf there (the greedy
+        # planner of the reference divides by that noise: IG_baseline raises there, as does the reference)
         self.noise_free_altitudes = [z for z in self.altitudes if _noise(z) == 0]
-        notes = []
-        if self.noise_free_altitudes:
-            notes.append(f"altitudes {self.noise_free_altitudes} m are outside the sensor model's table (sensor_models.py:13-22: "
-                         "noise 0): measurements there set cells to exactly 0 / 1 and the reward terms cancel to a small rest; "
-                         "returns within 2e-4 instead of 1e-5 when area sums are tracked or mapping.prior != 0.5 (1e-5 in the "
-                         "env-only form)")
-        for note in notes:
-            if note not in _WARNED:
-                _WARNED.add(note)
-                warnings.warn("ippmarl: " + note, stacklevel=3)
         # log-odds constants of the device representation (maps are stored as ln(p/(1-p)))
         self.logit_prior = float(np.log(self.prior / (1 - self.prior))) if 0 < self.prior < 1 else 0.0
         self.logit_clip = float(np.log(CLIP_HI / (1 - CLIP_HI)))

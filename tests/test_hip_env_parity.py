@@ -164,28 +164,22 @@ def test_production_randomness_matches_oracle(name, over, n_envs, seed=0x1234567
             else:
                 assert_posteriors(local[e], np.array(rec["fused_local"]), strict=strict, msg=f"fused local t={t} e={e}")
             assert_posteriors(glob[e], rec["global_map"], strict=strict, msg=f"global t={t} e={e}")
-            # returns: 1e-5, also with prior != 0.5 (float64 chain and float64 reward sums on that path) -- except:
-            # (altitudes outside the sensor model's table are noise-free: cells jump between exactly 0 / 1 and the clip, the
-            #  reward terms are of size 1 with both signs and S1 is what is left after they cancel -- float32 wave partials)
-            # (the env-only form -- track_area=False, the one-trip tile fusion -- sums every slot of four cells into float64 lane
-            #  sums and holds 1e-5 there as everywhere else; the row walker of the tracked form keeps float32 lane sums)
-            noise_free = any(z not in (5, 10, 15) for z in env.d.altitudes) and (track_area or env.d.prior != 0.5)
-            rt = RTOL if not noise_free else 2e-4
+            # returns: 1e-5 in every regime.  (Altitudes outside the sensor model's table are noise-free: cells jump between exactly
+            # 0 / 1 and the clip, the reward terms are of size 1 with both signs and S1 is what is left after they cancel -- every
+            # fusion kernel sums a row's / slot's cells in float32 and the lanes in float64; float32 lane sums showed at 2e-4 there.)
+            noise_free = any(z not in (5, 10, 15) for z in env.d.altitudes)
+            rt = RTOL
             # (the rewards are affine in the sums, 22 S1/S2 - 0.5 and 10 S1/cells - 0.17 (utils/reward.py:37-40): the tolerance of
             #  the sums applies to the part in front of the offset, which matters when a reward is close to 0)
             got_r = reward[e].cpu().numpy()
             np.testing.assert_allclose(got_r[0], rec["relative_reward"], rtol=rt, atol=1e-6 + rt * 0.5)
             np.testing.assert_allclose(got_r[1], rec["absolute_reward"], rtol=rt, atol=1e-6 + rt * 0.17)
-            # (S1 = sum of w(a) (H(b) - H(a)) is a difference of two sums of the size of S2 -- with noise-free measurements that
-            #  are clipped back at the next fusion the terms have both signs and nearly cancel: float32 wave partials, 2e-8 of S2.
-            #  With prior != 0.5 every cell of the float32 maps enters both sums at every fusion, each with the 5e-7 absolute
-            #  rounding of its stored log-odds: 1e-6 of S2 there -- measured up to 9e-7 when noise-free measurements make the
-            #  terms large: S1 = 204.31105 vs 204.31102, and the same 1e-4 on an S1 that happens to cancel to -0.126.)
-            #  In the env-only form the lane sums are float64 and what remains is the float32 entropy of the saturated cells
-            #  themselves, the same 3e-8 on each of them: measured 5.4e-8 of S2, on an S1 of 0.83 next to an S2 of 770.)
-            s_scale = 2e-8 if env.d.prior == 0.5 and not noise_free else (5e-7 if env.d.prior == 0.5 else 1e-6)
-            if env.d.prior == 0.5 and not track_area and any(z not in (5, 10, 15) for z in env.d.altitudes):
-                s_scale = 2e-7
+            # (S1 = sum of w(a) (H(b) - H(a)) is a difference of two sums of the size of S2: its absolute error is a fraction of S2.
+            #  Default: 2e-8 of S2.  Noise-free measurements: the terms are +-1 and nearly cancel, what remains is the float32 entropy
+            #  of the saturated cells themselves, the same 3e-8 on each of them -- measured 5.4e-8 of S2 on an S1 of 0.83 next to an S2
+            #  of 770: 2e-7.  prior != 0.5: every cell of the float32 maps enters both sums at every fusion with the 5e-7 absolute
+            #  rounding of its stored log-odds: 1e-6 of S2.)
+            s_scale = 1e-6 if env.d.prior != 0.5 else (2e-7 if noise_free else 2e-8)
             np.testing.assert_allclose(env.sums[e, :2].cpu().numpy(), [rec["s1"], rec["s2"]], rtol=rt, atol=1e-6 + s_scale * abs(rec["s2"]))
             if feats:   # (prior != 0.5: the area sums take a small change of EVERY cell at every fusion: 6e-6 absolute there)
                 fa = 2e-6 if env.d.prior == 0.5 and not noise_free else 6e-6   # (noise-free: float32 increments of size 1/2)
