@@ -638,3 +638,33 @@ def test_empty_mask_sets_fault_flag():
     assert m.sum() == 0
     with pytest.raises(ValueError):
         O.uniform_valid_action(123, m)
+
+
+def test_kernel_timing_reports_dispatch_durations():
+    """ippm_kernel_timing / ippm_read_kernel_times (what bench.py's roofline leg reads): every launch of the timed classes made
+    while timing is on is counted once, under the name the compiler gives the kernel, with a plausible begin-to-end duration;
+    launches made while it is off are not."""
+    from ippmarl.vec_env import POLICY_UNIFORM
+    params = make_params("c2")
+    env = _env(params, 64, track_area=False)
+    env.reset(np.arange(1, 65))
+    env.steps(0, policy=POLICY_UNIFORM, features=False)          # not timed
+    env.profile = True
+    for t in range(1, 6):
+        env.steps(t, policy=POLICY_UNIFORM, features=False)
+    env.profile = False
+    env.steps(6, policy=POLICY_UNIFORM, features=False)          # not timed
+    times = env.event_times_us()
+    assert {"sense", "fuse", "plan"} <= set(times)
+    for cls, kernel in (("sense", "k_sense_tiles<4, false, false>"), ("fuse", "k_fuse_tiles<6, false>"), ("plan", "k_plan_step")):
+        rec = times[cls]
+        assert rec["launches"] == 5 and rec["kernel"] == kernel, (cls, rec)
+        assert 1.0 < rec["min_us"] <= rec["avg_us"] < 2000.0, (cls, rec)
+    assert env.event_times_us() == {}                            # reading resets
+    env.reset(np.arange(100, 164))                               # the reset's kernels have their own classes
+    env.profile = True
+    env.reset(np.arange(200, 264))
+    env.profile = False
+    times = env.event_times_us()
+    assert times["reset_maps"]["launches"] == 1 and times["reset_maps"]["kernel"] == "k_reset_maps"
+    assert times["reset"]["launches"] == 2 and times["reset"]["kernel"] == "k_fill_truth"   # scalars, then the half-plane truth (the last one names the class)
