@@ -256,6 +256,7 @@ int ippm_plan_step(ippm_ctx* ctx, const int64_t* episode, int32_t* pos, const fl
 int ippm_fuse_step(ippm_ctx* ctx, float* local, float* global, const uint8_t* code, int32_t* ws, double* sums, double* area,
                    const int32_t* work, int32_t n_envs, void* stream);
 int ippm_work_words(ippm_ctx* ctx, int32_t n_envs, int64_t* words); /* length of `work` in int32 words for n_envs envs */
+int ippm_tile_form(ippm_ctx* ctx, int32_t* yes); /* 1: this configuration has the tile form (IPPM_STEP_TILES, ippm_fuse_move_step) */
 int ippm_reward_finalize(ippm_ctx* ctx, double* sums, float* reward, int32_t n_envs, void* stream);
 
 /* Full-grid weighted entropy sum(w(p) H(p)) per map (utils/state.py:53-121, "reward" mode); n_maps maps of

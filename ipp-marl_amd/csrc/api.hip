@@ -143,6 +143,12 @@ void ippm_timing_events(ippm_ctx* ctx, int cls, const char* name, hipEvent_t* a,
   ctx->ev_name[cls] = name;
 }
 
+extern "C" int ippm_tile_form(ippm_ctx* ctx, int32_t* yes) {
+  if (!ctx || !yes) { ippm_set_error("ippm_tile_form: null argument"); return -1; }
+  *yes = ctx->tiles;
+  return 0;
+}
+
 extern "C" int ippm_kernel_timing(ippm_ctx* ctx, int32_t enable) {
   if (!ctx) { ippm_set_error("ippm_kernel_timing: null context"); return -1; }
   ctx->timing = enable ? 1 : 0;

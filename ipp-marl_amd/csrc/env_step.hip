@@ -28,9 +28,17 @@ __global__ void k_reset_scalars(const ippm_config* __restrict__ c, const int64_t
   int32_t* w = ws + (size_t)(e * per + k) * IPPM_WS_WORDS;
   // the written-cells box of the finished episode moves to the (now idle) first op record, where every workgroup of
   // ippm_reset_maps finds it unchanged while the first one already writes the new episode's box
-  const int32_t box_x = w[WS_BBOX_X], box_y = w[WS_BBOX_Y];
+  const int32_t box_x = w[WS_BBOX_X], box_y = w[WS_BBOX_Y], sbox_x = w[WS_SBOX_X], sbox_y = w[WS_SBOX_Y];
   for (int i = 0; i < WS_OPS; ++i) w[i] = 0;
-  w[WS_OPS + 0] = box_x; w[WS_OPS + 1] = box_y;
+  {   // the union of the fused-cells box and the sensed-cells box (either may be empty: x1 <= x0)
+    int ax0 = box_x & 0xFFFF, ax1 = (unsigned)box_x >> 16, ay0 = box_y & 0xFFFF, ay1 = (unsigned)box_y >> 16;
+    const int bx0 = sbox_x & 0xFFFF, bx1 = (unsigned)sbox_x >> 16, by0 = sbox_y & 0xFFFF, by1 = (unsigned)sbox_y >> 16;
+    if (bx1 > bx0 && by1 > by0) {
+      if (ax1 <= ax0 || ay1 <= ay0) { ax0 = bx0; ax1 = bx1; ay0 = by0; ay1 = by1; }
+      else { ax0 = min(ax0, bx0); ax1 = max(ax1, bx1); ay0 = min(ay0, by0); ay1 = max(ay1, by1); }
+    }
+    w[WS_OPS + 0] = ax0 | (ax1 << 16); w[WS_OPS + 1] = ay0 | (ay1 << 16);
+  }
   if (area) {  // area sums of the all-prior map: sigmoid(0) = 0.5 times the bin's weight total gx*gy
     double* a = area + (size_t)(e * per + k) * IPPM_FEAT * IPPM_FEAT;
     const double v = (double)ippm_sigmoid(c->logit_prior) * (double)c->grid_x * (double)c->grid_y;

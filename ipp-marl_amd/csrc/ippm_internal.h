@@ -17,7 +17,9 @@
 #define WS_RECT_A 1   // .. 1..4 = [yu,yd,xl,xr]
 #define WS_FLAG_S 5   // the agent's current footprint rect may hold out-of-range values (set by K3)
 #define WS_BBOX_X 6   // x0 | x1 << 16, WS_BBOX_Y y0 | y1 << 16: bounding box of every cell of the map written since the episode's
-#define WS_BBOX_Y 7   // reset (kept by k_plan_step: plan hulls and the footprints K3 is about to sense); ippm_reset_maps fills only that
+#define WS_BBOX_Y 7   // reset by fusions (the plans' hulls, kept by the planning wavefront of k_plan_step); ippm_reset_maps fills only
+#define WS_SBOX_X 14  // the union of this box and the next: the same for the footprints K3 sensed (kept by the K1 wavefront, which runs
+#define WS_SBOX_Y 15  // beside the planning wavefront: two boxes, two writers, no read-modify-write race)
 #define WS_PLAN 8
 #define PL_NOPS 0
 #define PL_X0 1

@@ -6,7 +6,7 @@
 // mask work of K1, the agent loop of K1 stays serial (agent i is masked against the already-moved j < i).
 #include <algorithm>
 
-#include "ippm_internal.h"
+#include "ippm_k1.h"
 
 // ======================================================================================================
 // comm matrix
@@ -164,9 +164,10 @@ __global__ void k_plan(const ippm_config* __restrict__ c, const int32_t* __restr
 // ======================================================================================================
 __device__ __forceinline__ int tb_lane_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
-// items of rows [xa, xb) x groups [g0, g1) with the ops of `mask`: counted, and written to dst when emit
-__device__ __forceinline__ int tile_items_of_interval(bool emit, int4* dst, int room, int env, int slot, int xa, int xb, int g0, int g1,
-                                                      unsigned mask) {
+// items of rows [xa, xb) x groups [g0, g1) with the ops of `mask`: their slots in the env's list are reserved with one LDS atomic
+// (the env's running item count), then written
+__device__ __forceinline__ void tile_items_of_interval(int4* items, int env_cap, int32_t* s_items, int env, int slot, int xa, int xb, int g0,
+                                                       int g1, unsigned mask) {
   const int W = g1 - g0, rows = xb - xa;
   const int sl = ippm_tile_slots(__popc(mask));          // 4, 2 or 1
   const int cap = 64 * sl;
@@ -176,44 +177,21 @@ __device__ __forceinline__ int tile_items_of_interval(bool emit, int4* dst, int 
   // boundary after the +0.5)
   const int rpi = max(1, (int)(((float)cap + 0.5f) * __builtin_amdgcn_rcpf((float)Wc)));
   const int nrb = (int)(((float)(rows + rpi - 1) + 0.5f) * __builtin_amdgcn_rcpf((float)rpi));
-  if (emit) {
-    int k = 0;
-    for (int rb = 0; rb < nrb; ++rb) {
-      const int x0 = xa + rb * rpi, nr = min(rpi, xb - x0);
-      for (int ch = 0; ch < nch; ++ch, ++k) {
-        const int g = g0 + ch * Wc, w = min(Wc, g1 - g);
-        if (k < room) dst[k] = make_int4(env, x0 | (nr << 16), g | (w << 16), (int)(mask | ((unsigned)slot << 24)));
-      }
+  int k = atomicAdd(s_items, nch * nrb);
+  for (int rb = 0; rb < nrb; ++rb) {
+    const int x0 = xa + rb * rpi, nr = min(rpi, xb - x0);
+    for (int ch = 0; ch < nch; ++ch, ++k) {
+      const int g = g0 + ch * Wc, w = min(Wc, g1 - g);
+      if (k < env_cap) items[k] = make_int4(env, x0 | (nr << 16), g | (w << 16), (int)(mask | ((unsigned)slot << 24)));
     }
   }
-  return nch * nrb;
-}
-
-// my slab's items: walk the plan's ops in ascending first column, merging their group ranges into intervals
-__device__ __forceinline__ int tile_walk_slab(bool emit, int4* dst, int room, int env, int slot, bool slab_on, int xa, int xb, int nops,
-                                              int order, int r_yu, int r_yd, int r_xl, int r_xr) {
-  int cnt = 0, g0 = 0, g1 = -1;
-  unsigned mask = 0;
-  for (int r = 0; r < nops; ++r) {
-    const int o = tb_lane_i(order, r);  // op with the r-th smallest first column
-    const int yu = tb_lane_i(r_yu, o), yd = tb_lane_i(r_yd, o), xl = tb_lane_i(r_xl, o), xr = tb_lane_i(r_xr, o);
-    const bool in = slab_on && xl <= xa && xa < xr;
-    const int lo = yu >> 2, hi = (yd + 3) >> 2;
-    if (in) {
-      if (mask != 0 && lo > g1) {  // a gap of at least one group: the interval so far is complete
-        cnt += tile_items_of_interval(emit, dst + cnt, room - cnt, env, slot, xa, xb, g0, g1, mask);
-        mask = 0;
-      }
-      if (mask == 0) { g0 = lo; g1 = hi; }
-      else g1 = max(g1, hi);
-      mask |= 1u << o;
-    }
-  }
-  if (mask != 0) cnt += tile_items_of_interval(emit, dst + cnt, room - cnt, env, slot, xa, xb, g0, g1, mask);
-  return cnt;
 }
 
 // All items of one map's plan (nops > 0, uniform) into the env's list.  s_ops: the plan's rectangles in LDS.
+// Lane l ranks edge l among the plan's 2 nops row edges; lane s then owns slab s and walks the plan's ops in ascending first
+// column (a second rank sort), merging their group ranges into intervals; every finished interval goes out at once (ONE pass: a
+// counting pass + prefix sum + second walk made the builder the plan kernel's critical path).  The order of an env's items in its
+// list is whatever the atomics make it; no result depends on it.
 __device__ __forceinline__ void tile_build_map(const int4* s_ops, int nops, int env, int slot, int4* items, int env_cap, int32_t* s_items,
                                                int lane) {
   const int n_edges = 2 * nops;
@@ -242,85 +220,29 @@ __device__ __forceinline__ void tile_build_map(const int4* s_ops, int nops, int 
   int xb = __builtin_amdgcn_ds_bpermute(min(lane + 1, 63) << 2, sorted);
   const bool slab_on = lane + 1 < n_edges && xb > xa;
   if (!slab_on) xb = xa;
-  const int cnt = tile_walk_slab(false, nullptr, 0, env, slot, slab_on, xa, xb, nops, order, r_yu, r_yd, r_xl, r_xr);
-  int before = 0, total = 0;
-  for (int j = 0; j + 1 < n_edges; ++j) {
-    const int v = tb_lane_i(cnt, j);
-    before += j < lane ? v : 0;
-    total += v;
+  int g0 = 0, g1 = -1;
+  unsigned mask = 0;
+  for (int r = 0; r < nops; ++r) {
+    const int o = tb_lane_i(order, r);  // op with the r-th smallest first column
+    const int yu = tb_lane_i(r_yu, o), yd = tb_lane_i(r_yd, o), xl = tb_lane_i(r_xl, o), xr = tb_lane_i(r_xr, o);
+    const bool in = slab_on && xl <= xa && xa < xr;
+    const int lo = yu >> 2, hi = (yd + 3) >> 2;
+    if (in) {
+      if (mask != 0 && lo > g1) {  // a gap of at least one group: the interval so far is complete
+        tile_items_of_interval(items, env_cap, s_items, env, slot, xa, xb, g0, g1, mask);
+        mask = 0;
+      }
+      if (mask == 0) { g0 = lo; g1 = hi; }
+      else g1 = max(g1, hi);
+      mask |= 1u << o;
+    }
   }
-  if (total == 0) return;
-  int base = 0;
-  if (lane == 0) base = atomicAdd(s_items, total);   // where this map's items start in the env's list
-  base = __builtin_amdgcn_readfirstlane(base);
-  tile_walk_slab(true, items + base + before, env_cap - base - before, env, slot, slab_on, xa, xb, nops, order, r_yu, r_yd, r_xl, r_xr);
+  if (mask != 0) tile_items_of_interval(items, env_cap, s_items, env, slot, xa, xb, g0, g1, mask);
 }
 
 // ======================================================================================================
 // K1: action mask + collision mask + action choice + move
 // ======================================================================================================
-__device__ __forceinline__ void action_offset(int A, int a, int s, int& dx, int& dy, int& dz) {
-  dx = dy = dz = 0;
-  if (A == 4) {
-    if (a == 0) dx = -s; else if (a == 1) dy = -s; else if (a == 2) dy = s; else dx = s;
-  } else if (A == 6) {
-    if (a == 0) dz = s; else if (a == 1) dx = -s; else if (a == 2) dy = -s; else if (a == 3) dy = s;
-    else if (a == 4) dx = s; else dz = -s;
-  } else if (A == 9) {
-    dx = (a / 3 - 1) * s; dy = (a % 3 - 1) * s;
-  } else {  // 27: layer 0 = +z (action_space.py:249-303)
-    int layer = a / 9, c9 = a % 9;
-    dz = (1 - layer) * s; dx = (c9 / 3 - 1) * s; dy = (c9 % 3 - 1) * s;
-  }
-}
-
-// AgentActionSpace.get_action_mask for one action (action_space.py:25-196)
-__device__ __forceinline__ bool action_in_bounds(const ippm_config* c, int a, int px, int py, int pz) {
-  const int A = c->n_actions, s = c->spacing;
-  const int max_alt = c->min_altitude + (c->space_z - 1) * s;
-  int dx, dy, dz;
-  action_offset(A, a, s, dx, dy, dz);
-  const int nx = px + dx, ny = py + dy, nz = pz + dz;
-  bool ok = nx >= 0 && nx <= c->x_dim_m && ny >= 0 && ny <= c->y_dim_m;
-  if (A == 6 || A == 27) ok = ok && nz >= c->min_altitude && nz <= max_alt;
-  if ((A == 9 || A == 27) && dx == 0 && dy == 0 && dz == 0) ok = false;
-  return ok;
-}
-__device__ __forceinline__ uint32_t boundary_mask(const ippm_config* c, int px, int py, int pz) {
-  uint32_t m = 0;
-  for (int a = 0; a < c->n_actions; ++a) m |= action_in_bounds(c, a, px, py, pz) ? (1u << a) : 0u;
-  return m;
-}
-
-// actions zeroed when an already-moved agent sits at lattice offset (dx,dy,dz) (action_space.py:309-589)
-__device__ __forceinline__ uint32_t collision_bits(int A, int dx, int dy, int dz) {
-  if (A == 4) {
-    if (dx == -1 && dy == 0) return 1u; if (dx == 0 && dy == -1) return 2u;
-    if (dx == 0 && dy == 1) return 4u; if (dx == 1 && dy == 0) return 8u;
-    return 0;
-  }
-  if (A == 6) {
-    if (dx == 0 && dy == 0) return (1u << 0) | (1u << 5);
-    if (dx == -1 && dy == 0) return 1u << 1; if (dx == 0 && dy == -1) return 1u << 2;
-    if (dx == 0 && dy == 1) return 1u << 3; if (dx == 1 && dy == 0) return 1u << 4;
-    return 0;
-  }
-  if (dx < -1 || dx > 1 || dy < -1 || dy > 1) return 0;
-  int c9 = (dx + 1) * 3 + (dy + 1);
-  if (A == 9) return (dx == 0 && dy == 0) ? 0u : (1u << c9);
-  if (dz < -1 || dz > 1 || (dx == 0 && dy == 0 && dz == 0)) return 0;
-  if (dx == 0 && dy == 0) return (1u << 4) | (1u << 22);
-  return (1u << c9) | (1u << (c9 + 9)) | (1u << (c9 + 18));
-}
-
-// the order-dependent zeroing rules of apply_collision_mask for one moved agent
-__device__ __forceinline__ uint32_t collide(int A, uint32_t m, uint32_t z) {
-  if (!z) return m;
-  if (A == 6) return __popc(m) > 1 ? (m & ~z) : m;
-  if (A == 9) { m &= ~z; return m == 0 ? z : m; }
-  return m & ~z;
-}
-
 // stand-alone mask query of the drop-in AgentActionSpace (get_action_mask / apply_collision_mask)
 __global__ void k_action_mask(const ippm_config* __restrict__ c, const int32_t* __restrict__ pos,
                               const int32_t* __restrict__ others, const int32_t* __restrict__ n_others, int max_others,
@@ -353,96 +275,6 @@ __global__ void k_action_mask(const ippm_config* __restrict__ c, const int32_t* 
   for (int q = 0; q < A; ++q) mask_out[(size_t)b * A + q] = (m >> q) & 1u;
 }
 
-// LDS hand-over between the lanes of ONE wavefront (K1 runs on wavefront 0 of the plan kernel's workgroup while the others build
-// tile items, so a workgroup barrier is not available here): DS operations of a wavefront execute in program order, the fence
-// only keeps the compiler from moving them.
-__device__ __forceinline__ void wave_sync_lds() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
-
-// K1 for one env by one wavefront (lanes 0..63 of wavefront 0).  s_pos: the env's positions in LDS, updated in place.
-// get_action_mask -> apply_collision_mask -> action choice -> action_to_position (action_space.py:25-589,
-// actor/network.py:90-96, coma_wrapper.py:97-104)
-__device__ void k1_env(const ippm_config* __restrict__ c, int64_t ep, int32_t* s_pos, const float* __restrict__ probs_e,
-                       const int32_t* __restrict__ action_in_e, int policy, int t, uint8_t* __restrict__ mask_e,
-                       int32_t* __restrict__ action_e, int32_t* __restrict__ fault_e) {
-  const int n = c->n_agents, A = c->n_actions, s = c->spacing;
-  const int lane = threadIdx.x & 63;
-  const uint32_t k0 = (uint32_t)c->philox_seed, k1 = (uint32_t)(c->philox_seed >> 32);
-  int flt = 0;
-  // Off the serial chain, up front: every agent's boundary mask (its position does not change before its own move; lanes =
-  // actions, one ballot each, kept in lane i) and its Philox word (lane i draws for agent i).
-  __shared__ float s_pr[IPPM_MAX_AGENTS * IPPM_MAX_ACTIONS];  // the policy's probabilities: fetched once, not per agent in the chain
-  if (policy >= 2)
-    for (int q = lane; q < n * A; q += 64) s_pr[q] = probs_e[q];
-  uint32_t bmask_mine = 0, word_mine = 0;
-  for (int i = 0; i < n; ++i) {
-    const uint32_t b = (uint32_t)__ballot(lane < A && action_in_bounds(c, lane, s_pos[i * 3], s_pos[i * 3 + 1], s_pos[i * 3 + 2]));
-    bmask_mine = lane == i ? b : bmask_mine;
-  }
-  if ((policy == 1 || policy == 2) && lane < n)
-    word_mine = ippm_philox(0u, (uint32_t)ep, ippm_stream_word((uint32_t)lane, (uint32_t)t, IPPM_DOMAIN_ACTION), (uint32_t)(ep >> 32), k0, k1).v[0];
-  wave_sync_lds();
-  for (int i = 0; i < n; ++i) {
-    const int px = s_pos[i * 3], py = s_pos[i * 3 + 1], pz = s_pos[i * 3 + 2];
-    const uint32_t bmask = (uint32_t)__builtin_amdgcn_readlane((int)bmask_mine, i);
-    const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)word_mine, i);
-    uint32_t m = bmask;
-    int ix, iy, iz;
-    ippm_pos_to_index(c, px, py, pz, ix, iy, iz);
-    for (int j = 0; j < i; ++j) {  // s_pos[j] already holds agent j's post-move position
-      int jx, jy, jz;
-      ippm_pos_to_index(c, s_pos[j * 3], s_pos[j * 3 + 1], s_pos[j * 3 + 2], jx, jy, jz);
-      m = collide(A, m, collision_bits(A, jx - ix, jy - iy, jz - iz));
-    }
-    int a = -1;
-    if (m == 0) {
-      flt |= 1 << i;  // the reference's torch.multinomial raises on an all-zero distribution
-    } else if (policy == 0) {
-      a = action_in_e[i];
-    } else if (policy == 1) {
-      const int kth = (int)__umulhi(word, (uint32_t)__popc(m));
-      // the kth valid action: the lane whose bit is set and has kth set bits below it
-      const bool mine = lane < A && ((m >> lane) & 1u) && __popc(m & ((1u << (lane & 31)) - 1u)) == kth;
-      a = __ffsll((unsigned long long)__ballot(mine)) - 1;
-    } else {
-      const float* pr = s_pr + i * A;
-      if (policy == 3) {  // eval: argmax of probs*mask (first maximum)
-        float best = -1.f;
-        for (int q = 0; q < A; ++q) {
-          float v = ((m >> q) & 1u) ? pr[q] : 0.f;
-          if (v > best) { best = v; a = q; }
-        }
-      } else {  // train: inverse CDF over probs*mask, sequential float32 sums without FMA contraction
-        float total = 0.f;
-        for (int q = 0; q < A; ++q) total = __fadd_rn(total, ((m >> q) & 1u) ? pr[q] : 0.f);
-        const float u = (float)(word >> 8) * (1.0f / 16777216.0f);
-        const float target = __fmul_rn(u, total);
-        float acc = 0.f;
-        int lastv = -1;
-        for (int q = 0; q < A && a < 0; ++q) {
-          float v = ((m >> q) & 1u) ? pr[q] : 0.f;
-          if (v > 0.f) { lastv = q; acc = __fadd_rn(acc, v); if (acc > target) a = q; }
-        }
-        if (a < 0) a = lastv;
-        if (a < 0) flt |= 1 << i;
-      }
-    }
-    if (a < 0 || a >= A) a = bmask ? __ffs(bmask) - 1 : 0;  // keep the state sane: first boundary-valid action
-    int dx, dy, dz;
-    action_offset(A, a, s, dx, dy, dz);
-    wave_sync_lds();  // every lane has read agent i's old position
-    if (lane == 0) {
-      s_pos[i * 3] = px + dx; s_pos[i * 3 + 1] = py + dy; s_pos[i * 3 + 2] = pz + dz;
-      action_e[i] = a;
-    }
-    if (lane < A) mask_e[(size_t)i * A + lane] = (m >> lane) & 1u;
-    wave_sync_lds();
-  }
-  if (fault_e && lane == 0) *fault_e = flt;
-}
-
 // ======================================================================================================
 // k_plan_step: everything small of an env step in one launch, one wavefront per env
 //   IPPM_STEP_COMM   comm matrix + local-fusion plans (lanes = agents)
@@ -451,17 +283,6 @@ __device__ void k1_env(const ippm_config* __restrict__ c, int64_t ep, int32_t* s
 //                    starts with its rectangle in hand instead of a pos -> lattice index -> centre table chain
 // comm and the plans read the pre-move positions (LDS copy taken before K1 writes anything).
 // ======================================================================================================
-// written-cells box of a map (ws words WS_BBOX_*): union with rows [x0, x1) x columns [y0, y1)
-__device__ __forceinline__ void box_union(int32_t* wm, int x0, int x1, int y0, int y1) {
-  if (x1 <= x0 || y1 <= y0) return;
-  const int bx = wm[WS_BBOX_X], by = wm[WS_BBOX_Y];
-  int ax0 = bx & 0xFFFF, ax1 = (unsigned)bx >> 16, ay0 = by & 0xFFFF, ay1 = (unsigned)by >> 16;
-  if (ax1 <= ax0 || ay1 <= ay0) { ax0 = x0; ax1 = x1; ay0 = y0; ay1 = y1; }
-  else { ax0 = min(ax0, x0); ax1 = max(ax1, x1); ay0 = min(ay0, y0); ay1 = max(ay1, y1); }
-  wm[WS_BBOX_X] = ax0 | (ax1 << 16);
-  wm[WS_BBOX_Y] = ay0 | (ay1 << 16);
-}
-
 #ifdef IPPM_PLAN_STAMPS   // variant builds: env 0 leaves wall-clock stamps of its phases in word 7 of the counter slots
 #define PLAN_STAMP(k) do { if (blockIdx.x == 0 && lane == 0 && stamps) stamps[((wv * 8 + (k)) & 63) * 8 + 7] = wall_clock64(); \
     if (blockIdx.x == gridDim.x - 1 && wv == 0 && lane == 0 && stamps) stamps[(48 + (k)) * 8 + 7] = wall_clock64(); \
@@ -479,33 +300,43 @@ k_plan_step(const ippm_config* __restrict__ c, const int64_t* __restrict__ episo
             const int32_t* __restrict__ action_in, int policy, uint8_t* __restrict__ mask, int32_t* __restrict__ action,
             int32_t* __restrict__ fault, int32_t* __restrict__ rect_next, int agent_sel, int32_t* __restrict__ work,
             int wave_rows, int env_cap, unsigned long long* __restrict__ stamps) {
-  // Wavefront 0 does what the kernel always did (comm, plans, K1).  With a tile-form work list the workgroup carries builder
-  // wavefronts as well: once the plans are in LDS they cut them into one-trip items (a map each, round-robin) while wavefront 0
-  // goes on with K1.  One wavefront per SIMD runs ~2.5 ns per instruction; the items of five plans took 19 us in line.
+  // Wavefront 0 plans (comm matrix, fusion plans, written-cells boxes).  With a tile-form work list the workgroup carries more
+  // wavefronts: builders, which cut the plans into one-trip items (a map each, round-robin) as soon as the plans are in LDS --
+  // wavefront 0 joins them once it has planned -- and, when the launch also moves the agents, wavefront 1 for K1, which needs
+  // nothing but the positions and runs beside the planning (in line K1 was 7 of the 13 us of wavefront 0's chain; one wavefront
+  // per SIMD executes ~2.5 ns per instruction, so anything serial here is expensive and anything that can go to a neighbour
+  // wavefront is almost free -- up to 4 wavefronts per env: a round of the launch holds 16 per CU).
+  // Hand-overs: ONE workgroup barrier, after the loads; the builders then wait for `s_ready` (an LDS flag the planning wavefront
+  // releases), K1 waits for nobody.  K1's LDS traffic stays inside its wavefront (wave_sync_lds).
   const int e = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int n = c->n_agents, A = c->n_actions;
-  __shared__ int32_t s_pos[IPPM_MAX_AGENTS * 3];
+  __shared__ int32_t s_pos[IPPM_MAX_AGENTS * 3];    // pre-move positions: what comm and the plans see
+  __shared__ int32_t s_pos1[IPPM_MAX_AGENTS * 3];   // K1's working copy (moved in place)
   __shared__ int32_t s_rect[IPPM_MAX_AGENTS * 4];
   __shared__ int4 s_ops[(IPPM_MAX_AGENTS + 1) * IPPM_MAX_OPS];   // the op rectangles of every plan, for the tile builders
   __shared__ int32_t s_nops[IPPM_MAX_AGENTS + 1];
-  __shared__ int32_t s_items, s_done;                            // items handed out so far; builders that have finished
+  __shared__ int32_t s_items, s_done, s_ready;   // items handed out so far; builders that have finished; plans are in LDS
   const bool plans = (flags & (IPPM_STEP_COMM | IPPM_STEP_GLOBAL)) != 0;
   const bool tiled = (flags & IPPM_STEP_TILES) != 0 && work && plans;
-  const int builders = (int)(blockDim.x >> 6) - 1;
+  const bool move = (flags & IPPM_STEP_MOVE) != 0;
+  const int waves = (int)(blockDim.x >> 6);
+  const int k1_wave = move ? (tiled && waves >= 3 ? 1 : 0) : -1;   // K1 beside the planning only when builders exist besides it
   int32_t* pg = pos + (size_t)e * n * 3;
   int32_t st[6] = {0, 0, 0, 0, 0, 0};
   PLAN_STAMP(0);
   if (wv == 0) {
-    // everything this wavefront will read is requested now, in one round trip: positions, published footprints, the
+    // everything the workgroup will read is requested now, in one round trip: positions, published footprints, the
     // deferred-clamp state of my map (lane i: local map i, lane n: the global map)
     if (lane <= n) s_nops[lane] = 0;
-    if (lane == 0) { s_items = 0; s_done = 0; }
-    if (lane < n * 3) s_pos[lane] = pg[lane];
+    if (lane == 0) { s_items = 0; s_done = 0; s_ready = 0; }
+    if (lane < n * 3) { const int32_t v = pg[lane]; s_pos[lane] = v; s_pos1[lane] = v; }
     if (plans && lane < n * 4) s_rect[lane] = rect[(size_t)e * n * 4 + lane];
     if (plans && lane <= n)
       for (int q = 0; q < 6; ++q) st[q] = ws[(size_t)(e * (n + 1) + lane) * IPPM_WS_WORDS + q];
-    wave_sync_lds();
-    PLAN_STAMP(1);
+  }
+  if (waves > 1) __syncthreads(); else wave_sync_lds();
+  PLAN_STAMP(1);
+  if (wv == 0 && plans) {
     int hull_rows = 0;
     if ((flags & IPPM_STEP_COMM) && lane < n) {
       const uint32_t recv = comm_row(c, episode, s_pos, comm_range, draws, comm, t, e, lane);
@@ -514,14 +345,14 @@ k_plan_step(const ippm_config* __restrict__ c, const int64_t* __restrict__ episo
     }
     if ((flags & IPPM_STEP_GLOBAL) && lane == n)
       hull_rows = plan_map(c, s_rect, s_pos, 0u, ws, 1, e, n, st, tiled ? s_ops + n * IPPM_MAX_OPS : nullptr, tiled ? s_nops + n : nullptr);
-    // the map's written-cells box takes in this step's plan hull (ippm_reset_maps fills only the box at the next reset)
-    if (plans && lane <= n && hull_rows > 0) {
+    // the map's fused-cells box takes in this step's plan hull (ippm_reset_maps fills only the boxes at the next reset)
+    if (lane <= n && hull_rows > 0) {
       int32_t* wm = ws + (size_t)(e * (n + 1) + lane) * IPPM_WS_WORDS;
       const int32_t* hdr = wm + WS_PLAN;
       box_union(wm, hdr[PL_X0], hdr[PL_X1], hdr[PL_Y0], hdr[PL_Y1]);
     }
     // row-run form of the work list: items of this env's plans into the env's own slice (exclusive scan of the lanes' counts)
-    if (work && plans && !tiled) {
+    if (work && !tiled) {
       const int items = (hull_rows + wave_rows - 1) / wave_rows;
       // the global map's runs go first (they carry the reward arithmetic: longest items first balances the env's wavefronts)
       const int g_items = __builtin_amdgcn_readlane(items, n);
@@ -536,49 +367,48 @@ k_plan_step(const ippm_config* __restrict__ c, const int64_t* __restrict__ episo
       if (lane <= n)
         for (int k = 0; k < items; ++k) dst[k] = ((e * (n + 1) + lane) << 8) | k;
     }
+    if (tiled && lane == 0) __hip_atomic_store(&s_ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // the plans are in LDS
   }
   PLAN_STAMP(2);
-  if (tiled) {
-    __syncthreads();   // the plans are in LDS (the only workgroup barrier: K1 below syncs within its wavefront)
-    if (wv > 0 || builders == 0) {
-      // Tile items: builder b takes maps b, b + builders, ...; a map's items go wherever the env's running count says (an LDS
-      // atomic per map), so no builder waits for another; the last one to finish writes the env's count.
-      int4* items = reinterpret_cast<int4*>(work + ((gridDim.x + 3) & ~3)) + (size_t)e * env_cap;
-      const int nb = max(builders, 1), b = builders ? wv - 1 : 0;
-      PLAN_STAMP(3);
-      for (int mm = b; mm <= n; mm += nb) {
-        const int m = mm == 0 ? n : mm - 1;   // the global map's items come early: they carry the reward arithmetic
-        const int nops = __builtin_amdgcn_readfirstlane(s_nops[m]);
-        if (nops > 0) tile_build_map(s_ops + m * IPPM_MAX_OPS, nops, e, m, items, env_cap, &s_items, lane);
-      }
-      PLAN_STAMP(4);
-      int last = 0;
-      if (lane == 0) last = atomicAdd(&s_done, 1) == nb - 1 ? 1 : 0;
-      last = __builtin_amdgcn_readfirstlane(last);
-      if (last && lane == 0) {
-        // (the capacity bound of ippm_tile_env_cap covers every plan; a list that would not fit is cut and reported)
-        const int total = atomicAdd(&s_items, 0);
-        work[e] = min(total, env_cap) | IPPM_WORK_TILED | (total > env_cap ? IPPM_WORK_OVERFLOW : 0);
-      }
+  if (tiled && wv != k1_wave) {
+    // Tile items: builder b takes maps b, b + nb, ...; an interval's items go wherever the env's running count says (an LDS
+    // atomic), so no builder waits for another; the last one to finish writes the env's count.
+    const int nb = waves - (k1_wave > 0 ? 1 : 0), b = (k1_wave > 0 && wv > k1_wave) ? wv - 1 : wv;
+    if (wv != 0)
+      while (__hip_atomic_load(&s_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+    int4* items = reinterpret_cast<int4*>(work + ((gridDim.x + 3) & ~3)) + (size_t)e * env_cap;
+    PLAN_STAMP(3);
+    for (int mm = b; mm <= n; mm += nb) {
+      const int m = mm == 0 ? n : mm - 1;   // the global map's items come early: they carry the reward arithmetic
+      const int nops = __builtin_amdgcn_readfirstlane(s_nops[m]);
+      if (nops > 0) tile_build_map(s_ops + m * IPPM_MAX_OPS, nops, e, m, items, env_cap, &s_items, lane);
+    }
+    PLAN_STAMP(4);
+    int last = 0;
+    if (lane == 0) last = atomicAdd(&s_done, 1) == nb - 1 ? 1 : 0;
+    last = __builtin_amdgcn_readfirstlane(last);
+    if (last && lane == 0) {
+      // (the capacity bound of ippm_tile_env_cap covers every plan; a list that would not fit is cut and reported)
+      const int total = atomicAdd(&s_items, 0);
+      work[e] = min(total, env_cap) | IPPM_WORK_TILED | (total > env_cap ? IPPM_WORK_OVERFLOW : 0);
     }
   }
-  if (wv != 0) return;
-  if (flags & IPPM_STEP_MOVE) {
-    wave_sync_lds();
-    PLAN_STAMP(5);
-    k1_env(c, episode ? episode[e] : 0, s_pos, probs ? probs + (size_t)e * n * A : nullptr,
-           action_in ? action_in + (size_t)e * n : nullptr, policy, t, mask + (size_t)e * n * A, action + (size_t)e * n,
-           fault ? fault + e : nullptr);
-    if (lane < n * 3) pg[lane] = s_pos[lane];
-    if (rect_next && lane < n) {
-      int cl[4];
-      ippm_footprint_rect(c, s_pos[lane * 3], s_pos[lane * 3 + 1], s_pos[lane * 3 + 2], cl, nullptr);
-      int32_t* r = rect_next + (size_t)(e * n + lane) * 4;
-      r[0] = cl[0]; r[1] = cl[1]; r[2] = cl[2]; r[3] = cl[3];
-      if (ws) box_union(ws + (size_t)(e * (n + 1) + lane) * IPPM_WS_WORDS, cl[2], cl[3], cl[0], cl[1]);   // what K3 senses next
-    }
-    PLAN_STAMP(6);
+  if (wv != k1_wave) return;
+  // ---- K1 on its own positions; the footprints of the NEW positions for K3, and into the map's sensed-cells box
+  wave_sync_lds();
+  PLAN_STAMP(5);
+  k1_env(c, episode ? episode[e] : 0, s_pos1, probs ? probs + (size_t)e * n * A : nullptr,
+         action_in ? action_in + (size_t)e * n : nullptr, policy, t, mask + (size_t)e * n * A, action + (size_t)e * n,
+         fault ? fault + e : nullptr);
+  if (lane < n * 3) pg[lane] = s_pos1[lane];
+  if (rect_next && lane < n) {
+    int cl[4];
+    ippm_footprint_rect(c, s_pos1[lane * 3], s_pos1[lane * 3 + 1], s_pos1[lane * 3 + 2], cl, nullptr);
+    int32_t* r = rect_next + (size_t)(e * n + lane) * 4;
+    r[0] = cl[0]; r[1] = cl[1]; r[2] = cl[2]; r[3] = cl[3];
+    if (ws) box_union(ws + (size_t)(e * (n + 1) + lane) * IPPM_WS_WORDS, cl[2], cl[3], cl[0], cl[1], WS_SBOX_X, WS_SBOX_Y);   // what K3 senses next
   }
+  PLAN_STAMP(6);
 }
 
 // ======================================================================================================

@@ -71,6 +71,7 @@ PROTOTYPES = {
     "ippm_fuse_step": [P, P, P, P, P, P, P, P, I32, P],
     "ippm_reward_finalize": [P, P, P, I32, P],
     "ippm_work_words": [P, I32, P],
+    "ippm_tile_form": [P, P],
     "ippm_area_sums": [P, P, P, I32, I32, I32, P],
     "ippm_area_resize": [P, P, I32, I32, P, P, I32, P],
     "ippm_entropy_maps": [P, P, P, P, P, P, P, I64, P],

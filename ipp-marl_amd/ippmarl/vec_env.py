@@ -65,6 +65,9 @@ class VecEnv:
         words = np.zeros(1, dtype=np.int64)
         self.ctx.call("ippm_work_words", E, words.ctypes.data)
         self.work = z(int(words[0]), dtype=torch.int32)
+        yes = np.zeros(1, dtype=np.int32)
+        self.ctx.call("ippm_tile_form", yes.ctypes.data)
+        self._tile_form = bool(yes[0])   # the fusion without area sums runs in one-trip tile items (16-byte layout, prior 0.5)
         # 11x11 area sums of every map (slot N = global): the input of the K6 feature builders.  track_area=True: K3 / K4 /
         # K5 keep them up to date as they write maps (the batched training path); False: rebuilt by a streaming pass right
         # before the features are needed (env-only stepping never needs them; the single-env drop-in engine, whose maps

@@ -522,9 +522,10 @@ def test_fused_comm_and_plan_equals_separate_calls():
         a.build_observations(t, features=False)          # fused entry point
         b.comm_matrix(t)
         b.fuse_local()
-        # (workspace words 6, 7 = the written-cells box, which only the batched step's plan kernel keeps)
+        # (workspace words 6, 7 and 14, 15 = the written-cells boxes, which only the batched step's plan kernel keeps)
         assert torch.equal(a.comm, b.comm) and torch.equal(a.local, b.local), t
-        assert torch.equal(a.ws[:, :-1, :6], b.ws[:, :-1, :6]) and torch.equal(a.ws[:, :-1, 8:], b.ws[:, :-1, 8:]), t
+        for lo, hi in ((0, 6), (8, 14), (16, None)):
+            assert torch.equal(a.ws[:, :-1, lo:hi], b.ws[:, :-1, lo:hi]), (t, lo)
         a.steps(t, policy=POLICY_UNIFORM, features=False)
         # b: the stand-alone K5 entry point (plan + fusion + finalize), then K1 and K3 through the step's own kernels
         b.ctx.call("ippm_fuse_global_reward", b._p(b.glob), b._p(b.code), b._p(b.rect), b._p(b.pos), b._p(b.ws), b._p(b.sums),
