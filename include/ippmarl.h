@@ -67,6 +67,7 @@ extern "C" {
 #define IPPM_STEP_GLOBAL 2 /* global-fusion plan */
 #define IPPM_STEP_MOVE 4   /* K1 mask/act/move (+ footprints of the new positions) */
 #define IPPM_STEP_TILES 8  /* write the work list as one-trip tile items (for ippm_fuse_step WITHOUT area sums) */
+#define IPPM_SENSE_REC_WORDS 8  /* words per agent of ippm_plan_step's rect_next / ippm_sense_step's rect_in */
 
 /* Derived constants, computed on the host in float64 with the reference's expression order
  * (ippmarl/derived.py) and handed over as plain integers/floats. */
@@ -193,8 +194,9 @@ int ippm_sense_update(ippm_ctx* ctx, const int64_t* episode, const int32_t* pos,
                       float* local, const uint8_t* flips, uint8_t* code, int32_t* rect, int32_t* ws,
                       int32_t stage, int32_t agent_sel, int32_t n_envs, void* stream);
 /* K3 as the closing kernel of a batched env step (COMAWrapper.steps' `agent.step` calls, coma_wrapper.py:106-134):
- * rect_in (optional) = the footprints ippm_plan_step projected for the new positions (saves the dependent
- * pos -> lattice index -> centre-table loads); area (optional) = tracked area sums, updated for local[e,i];
+ * rect_in (optional) = the sense records ippm_plan_step wrote for the new positions, int32 [E,N,IPPM_SENSE_REC_WORDS] (the
+ * footprint and the measurement constants of its altitude: saves the dependent pos -> lattice index -> centre-table and
+ * pos -> altitude -> sensor-table loads in front of the map accesses); area (optional) = tracked area sums, updated for local[e,i];
  * sums + reward (optional, together) = complete the reward of the step's global fusion in the same launch
  * (what ippm_reward_finalize does; the fusion of ippm_fuse_step leaves it open). */
 int ippm_sense_step(ippm_ctx* ctx, const int64_t* episode, const int32_t* pos, const uint8_t* truth, float* local,
@@ -234,7 +236,9 @@ int ippm_fuse_global_reward(ippm_ctx* ctx, float* global, const uint8_t* code, c
  *   IPPM_STEP_COMM    CommunicationLog.get_messages for every agent + the local-fusion plans (as ippm_comm_fuse_local)
  *   IPPM_STEP_GLOBAL  the global-fusion plan (as ippm_fuse_global_reward's first stage)
  *   IPPM_STEP_MOVE    K1 = ippm_mask_act_move on the same positions (comm and the plans see the pre-move ones); also writes
- *                     rect_next int32 [E,N,4] (optional) = the clipped footprints of the NEW positions for ippm_sense_step.
+ *                     rect_next int32 [E,N,IPPM_SENSE_REC_WORDS] (optional) = the sense records of the NEW positions for
+ *                     ippm_sense_step: {yu, yd, xl, xr (clipped footprint), float bits of the two measurement log-odds minus
+ *                     logit(prior) at the new altitude, its flip threshold, 0}.
  *                     Only policies that do not depend on this step's observations (0 explicit, 1 uniform) can share a call
  *                     with COMM/GLOBAL; a learned policy calls MOVE separately after the actor.
  *   work (optional, int32 [ippm_work_words()]): with COMM | GLOBAL the kernel also lists the non-empty work items of the
@@ -256,7 +260,7 @@ int ippm_plan_step(ippm_ctx* ctx, const int64_t* episode, int32_t* pos, const fl
 int ippm_fuse_step(ippm_ctx* ctx, float* local, float* global, const uint8_t* code, int32_t* ws, double* sums, double* area,
                    const int32_t* work, int32_t n_envs, void* stream);
 int ippm_work_words(ippm_ctx* ctx, int32_t n_envs, int64_t* words); /* length of `work` in int32 words for n_envs envs */
-int ippm_tile_form(ippm_ctx* ctx, int32_t* yes); /* 1: this configuration has the tile form (IPPM_STEP_TILES, ippm_fuse_move_step) */
+int ippm_tile_form(ippm_ctx* ctx, int32_t* yes); /* 1: this configuration has the tile form (IPPM_STEP_TILES) */
 int ippm_reward_finalize(ippm_ctx* ctx, double* sums, float* reward, int32_t n_envs, void* stream);
 
 /* Full-grid weighted entropy sum(w(p) H(p)) per map (utils/state.py:53-121, "reward" mode); n_maps maps of

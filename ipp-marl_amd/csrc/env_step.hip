@@ -181,7 +181,7 @@ k_sense_update(const ippm_config* __restrict__ c, const int64_t* __restrict__ ep
   const int32_t* p = pos + (size_t)(e * n + i) * 3;
   int r[4];
   if (rect_in) {  // projected by the kernel that moved the agents (k_plan_step): no pos -> index -> table chain here
-    const int32_t* ri = rect_in + (size_t)(e * n + i) * 4;
+    const int32_t* ri = rect_in + (size_t)(e * n + i) * IPPM_SENSE_REC_WORDS;   // the footprint words of K1's sense record
     r[0] = ri[0]; r[1] = ri[1]; r[2] = ri[2]; r[3] = ri[3];
   } else {
     ippm_footprint_rect(c, p[0], p[1], p[2], r, nullptr);
@@ -303,44 +303,69 @@ typedef unsigned ippm_k3_u4 __attribute__((ext_vector_type(4)));
 #define IPPM_K3_STORE_AUX 0
 #endif
 
-// MIS: the grid is not a multiple of 4 wide (rows only 4-byte aligned); FLIPS: explicit flip tiles (parity mode) instead of Philox.
-// Both are compile-time so that the production instantiation <4, false, false> carries neither the second Philox call and the
+// MIS: the grid is not a multiple of 4 wide (rows only 4-byte aligned); FLIPS: explicit flip tiles (parity mode) instead of Philox;
+// REC: rect_in holds K1's sense records (the closing kernel of a batched step) -- without it the footprint and the sensor constants
+// come from pos and the config tables.  All
+// are compile-time so that the production instantiation <4, false, false> carries neither the second Philox call and the
 // cell-by-cell tail stores nor the flips resource (the kernel sits at the SGPR limit: every uniform it holds less is a
 // v_writelane / v_readlane pair less in its instruction stream).
-template <int VEC, bool MIS, bool FLIPS>
+template <int VEC, bool MIS, bool FLIPS, bool REC>
 __global__ void __launch_bounds__(256)
-k_sense_tiles(const ippm_config* __restrict__ c, const int64_t* __restrict__ episode, const int32_t* __restrict__ pos,
-              const uint8_t* __restrict__ truth, float* __restrict__ local, const uint8_t* __restrict__ flips,
-              uint8_t* __restrict__ code, const int32_t* __restrict__ rect_in, int32_t* __restrict__ rect_out,
-              int32_t* __restrict__ ws, double* __restrict__ sums, float* __restrict__ reward,
-              unsigned long long* __restrict__ counters, int stage, int agent_sel, int rows_per_part) {
+k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int stage, int rows_per_part, int gy, int gx,
+              float* __restrict__ local, const uint8_t* __restrict__ truth, const int64_t* __restrict__ episode,
+              uint8_t* __restrict__ code, int S_arg, float lc_arg, uint32_t k0_arg, uint32_t k1_arg,
+              const ippm_config* __restrict__ c, const int32_t* __restrict__ pos,
+              const uint8_t* __restrict__ flips, int32_t* __restrict__ rect_out, int32_t* __restrict__ ws,
+              double* __restrict__ sums, float* __restrict__ reward, unsigned long long* __restrict__ counters) {
+  // Argument order = latency order.  A workgroup lives for one trip, so what stands in front of its map loads is paid by every
+  // wavefront: with the config fields behind the config pointer behind the kernel-argument load, the footprint came in three
+  // dependent scalar round trips.  The first 14 argument words arrive in SGPRs with the wavefront (kernel-argument preload,
+  // csrc/Makefile): the address of the agent's sense record (K1: footprint + the measurement constants of its altitude) needs
+  // nothing else, and every config scalar the kernel uses is passed by value -- one scalar round trip, then the map loads.
   constexpr int CH = 3;
   // grid = (row parts, agents, envs): no index arithmetic to undo
-  const int n = c->n_agents;
   const int part = blockIdx.x, e = blockIdx.z, i = agent_sel >= 0 ? agent_sel : (int)blockIdx.y;
-  const int tile = e * (int)gridDim.y + (int)blockIdx.y;
-  // the reward of the step whose global fusion ran in the launch before this one: any one thread per env can complete it
-  if (sums && part == 0 && blockIdx.y == 0 && threadIdx.x == 0) ippm_reward_finalize_env(c, sums, reward, e);
-  const int gx = c->grid_x, gy = c->grid_y, S = c->tile_stride;
-  const int32_t* p = pos + (size_t)(e * n + i) * 3;
+  const int tile = e * n + (int)blockIdx.y;
   int r[4];
-  if (rect_in) {
-    const int32_t* ri = rect_in + (size_t)(e * n + i) * 4;
-    r[0] = ri[0]; r[1] = ri[1]; r[2] = ri[2]; r[3] = ri[3];
+  float lm0, lm1;
+  uint32_t thr;
+  int64_t ep = episode ? episode[e] : 0;
+  int S = S_arg;
+  float lc = lc_arg;
+  uint32_t k0 = k0_arg, k1 = k1_arg;
+  if (REC) {   // K1's sense record: the footprint and the measurement constants of its altitude in one 32-byte scalar load
+    const int4* ri = reinterpret_cast<const int4*>(rect_in + (size_t)(e * n + i) * IPPM_SENSE_REC_WORDS);
+    const int4 a = ri[0], b = ri[1];
+    r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w;
+    lm0 = __int_as_float(b.x); lm1 = __int_as_float(b.y); thr = (uint32_t)b.z;
   } else {
-    ippm_footprint_rect(c, p[0], p[1], p[2], r, nullptr);
+    const int32_t* p0 = pos + (size_t)(e * n + i) * 3;
+    ippm_footprint_rect(c, p0[0], p0[1], p0[2], r, nullptr);
+    const int k = ippm_alt_index(c, p0[2]);
+    const float lp = c->logit_prior;
+    lm0 = c->logit_meas[k][0] - lp; lm1 = c->logit_meas[k][1] - lp;
+    thr = c->flip_threshold[k];
+  }
+  // every scalar the kernel will use is on its way; left alone the compiler sinks the later ones to their first use, behind a
+  // second (third) scalar wait in front of the map loads
+  {
+    int b0 = __builtin_amdgcn_readfirstlane(__float_as_int(lm0)), b1 = __builtin_amdgcn_readfirstlane(__float_as_int(lm1));
+    int b2 = __builtin_amdgcn_readfirstlane(__float_as_int(lc)), e0 = (int)(uint32_t)ep, e1 = (int)(uint32_t)(ep >> 32);
+    asm volatile("" : "+s"(r[0]), "+s"(r[1]), "+s"(r[2]), "+s"(r[3]), "+s"(thr), "+s"(b0), "+s"(b1), "+s"(b2), "+s"(e0), "+s"(e1), "+s"(S),
+                 "+s"(k0), "+s"(k1), "+s"(code), "+s"(ws), "+s"(counters), "+s"(sums), "+s"(rect_out));
+    lm0 = __int_as_float(b0); lm1 = __int_as_float(b1); lc = __int_as_float(b2);
+    ep = (int64_t)(((uint64_t)(uint32_t)e1 << 32) | (uint32_t)e0);
   }
   const int yu = r[0], yd = r[1], xl = r[2], xr = r[3];
   if (rect_out && part == 0 && threadIdx.x < 4) rect_out[(size_t)(e * n + i) * 4 + threadIdx.x] = r[threadIdx.x];
   const int h = xr - xl, w = yd - yu;
   const int r0 = part * rows_per_part, r1 = min(h, r0 + rows_per_part);
-  if (w <= 0 || r0 >= r1) return;
-  // altitude index = (z - z_min) / spacing through one reciprocal (exact: (n + 1/2) / d is never within 1e-6 of an integer)
-  const int k = min(max((int)(((float)(p[2] - c->min_altitude) + 0.5f) * __builtin_amdgcn_rcpf((float)c->spacing)), 0), c->space_z - 1);
-  const float lp = c->logit_prior;
-  const float lm0 = c->logit_meas[k][0] - lp, lm1 = c->logit_meas[k][1] - lp;
-  const uint32_t thr = c->flip_threshold[k];
-  const float lc = c->logit_clip;
+  // the reward of the step whose global fusion ran in the launch before this one: any one thread per env completes it (last:
+  // nothing of this launch waits for it)
+  if (w <= 0 || r0 >= r1) {
+    if (sums && part == 0 && blockIdx.y == 0 && threadIdx.x == 0) ippm_reward_finalize_env(c, sums, reward, e);
+    return;
+  }
   const int y0 = yu & ~(VEC - 1), tile_y0 = yu & ~3;
   const int groups = (yd - y0 + VEC - 1) / VEC;
   constexpr bool mis = MIS;   // rows start at addresses that are only 4-byte aligned
@@ -354,9 +379,7 @@ k_sense_tiles(const ippm_config* __restrict__ c, const int64_t* __restrict__ epi
   const __amdgpu_buffer_rsrc_t rtruth = IPPM_K3_RSRC(truth + (size_t)e * ippm_truth_bytes(gx, gy), ippm_truth_bytes(gx, gy));
   const __amdgpu_buffer_rsrc_t rcode = IPPM_K3_RSRC(code + (size_t)(e * n + i) * TB, TB);
   const __amdgpu_buffer_rsrc_t rflip = IPPM_K3_RSRC(FLIPS ? flips + (size_t)(e * n + i) * TB : code, FLIPS ? TB : 0);
-  const int64_t ep = episode ? episode[e] : 0;
   const uint32_t sw = ippm_stream_word((uint32_t)i, (uint32_t)stage, IPPM_DOMAIN_FLIP);
-  const uint32_t k0 = (uint32_t)c->philox_seed, k1 = (uint32_t)(c->philox_seed >> 32);
   float amax = 0.f;
   for (int gbase = 0; gbase < groups; gbase += CH * lpr) {     // one trip unless the footprint is wider than 3 x 64 groups
     for (int row = r0 + wv * rpw + sub; row < r1; row += 4 * rpw) {  // one trip for rows_per_part = 4 * rpw
@@ -389,7 +412,10 @@ k_sense_tiles(const ippm_config* __restrict__ c, const int64_t* __restrict__ epi
       for (int q = 0; q < CH; ++q) {
         if (gbase + q * lpr >= groups) continue;   // wave-uniform: narrow footprints use one or two of the three passes
         const int gidx = gbase + gl + q * lpr;
-        const int y = y0 + gidx * VEC;
+        int y = y0 + gidx * VEC;
+        // (the column masks below do not depend on the row: left alone they are hoisted in front of the loads, ~60 instructions
+        // between the wavefront's start and its first memory request)
+        asm volatile("" : "+v"(y));
         const int cell = cellv[q];
         const uint32_t tbits = VEC == 4 ? (tw[q] >> (cell & 7)) & 0xFu : (tw[q] >> (cell & 7)) & 1u;
         uint32_t flipbits;
@@ -439,6 +465,7 @@ k_sense_tiles(const ippm_config* __restrict__ c, const int64_t* __restrict__ epi
   if (ws && __any(amax > lc) && lane == 0) ws[(size_t)(e * (n + 1) + i) * IPPM_WS_WORDS + WS_FLAG_S] = 1;
   if (counters && part == 0 && threadIdx.x == 0)
     atomicAdd(&counters[(tile & (IPPM_COUNTER_SLOTS - 1)) * 8 + 0], (unsigned long long)h * w);
+  if (sums && part == 0 && blockIdx.y == 0 && threadIdx.x == 0) ippm_reward_finalize_env(c, sums, reward, e);
 }
 
 
@@ -742,9 +769,11 @@ extern "C" int ippm_sense_step(ippm_ctx* ctx, const int64_t* episode, const int3
     if (n_envs > 65535) { ippm_set_error("ippm_sense_step: more than 65535 envs per launch"); return -1; }
     dim3 grid((unsigned)parts, (unsigned)(agent_sel >= 0 ? 1 : c.n_agents), (unsigned)n_envs);
     int32_t* rect_out = rect_in == rect ? nullptr : rect;
-#define IPPM_K3T(V, M, F)                                                                                                   \
-  IPPM_LAUNCH(ctx, IPPM_T_SENSE, (k_sense_tiles<V, M, F>), grid, block, S_(stream), ctx->dcfg, episode, pos, truth, local, flips, code, \
-              rect_in, rect_out, ws, sums, reward, ctx->dcounters, stage, agent_sel, rows_per_part)
+#define IPPM_K3T_(V, M, F, R)                                                                                               \
+  IPPM_LAUNCH(ctx, IPPM_T_SENSE, (k_sense_tiles<V, M, F, R>), grid, block, S_(stream), rect_in, c.n_agents, agent_sel, stage, rows_per_part, \
+              c.grid_y, c.grid_x, local, truth, episode, code, c.tile_stride, c.logit_clip, (uint32_t)c.philox_seed,                 \
+              (uint32_t)(c.philox_seed >> 32), ctx->dcfg, pos, flips, rect_out, ws, sums, reward, ctx->dcounters)
+#define IPPM_K3T(V, M, F) do { if (rect_in) IPPM_K3T_(V, M, F, true); else IPPM_K3T_(V, M, F, false); } while (0)
     const bool mis = (c.grid_y & 3) != 0;
     if (ctx->vec == 4) {
       if (flips) { if (mis) IPPM_K3T(4, true, true); else IPPM_K3T(4, false, true); }
@@ -752,6 +781,7 @@ extern "C" int ippm_sense_step(ippm_ctx* ctx, const int64_t* episode, const int3
     } else {
       if (flips) IPPM_K3T(1, false, true); else IPPM_K3T(1, false, false);
     }
+#undef IPPM_K3T_
 #undef IPPM_K3T
     IPPM_LAUNCH_CHECK("sense_tiles");
     return 0;

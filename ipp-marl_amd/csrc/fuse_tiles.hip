@@ -234,15 +234,20 @@ __device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e,
 #endif
 template <int NAMAX, bool MIS>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(IPPM_TILE_WAVES_PER_EU, 8)))
-k_fuse_tiles(const ippm_config* __restrict__ c, float* __restrict__ local, float* __restrict__ global,
-             const uint8_t* __restrict__ code, const int32_t* __restrict__ plan_ro, int32_t* __restrict__ ws,
-             double* __restrict__ sums, unsigned long long* __restrict__ counters, const int32_t* __restrict__ work,
-             int n_envs, int env_cap) {
+k_fuse_tiles(const int32_t* __restrict__ work, int n_envs, int env_cap, int n, int gx, int gy, int row_bytes, int TB, float lc, float wt,
+             const int32_t* __restrict__ plan_ro, float* __restrict__ local, float* __restrict__ global,
+             const uint8_t* __restrict__ code, int32_t* __restrict__ ws, double* __restrict__ sums,
+             unsigned long long* __restrict__ counters) {
+  // (argument order = latency order, as in k_sense_tiles: the work list's address and sizes arrive in SGPRs with the wavefront,
+  // every config scalar by value -- the count and the first item are one scalar round trip away, the first item's cells two)
   const int env = blockIdx.x, first = blockIdx.y, step = gridDim.y;   // consecutive workgroups = consecutive envs
   const int4* __restrict__ items = reinterpret_cast<const int4*>(work + ((n_envs + 3) & ~3)) + (size_t)env * env_cap;
   // count and first item are requested together (the item's address does not depend on the count)
-  const int tag = work[env];
+  int tag = work[env];
   int4 it = items[min(first, env_cap - 1)];
+  // (pinned: the compiler would sink the item and the pointer arguments behind the test of the tag, a second scalar round trip)
+  asm volatile("" : "+s"(tag), "+s"(it.x), "+s"(it.y), "+s"(it.z), "+s"(it.w), "+s"(local), "+s"(global), "+s"(code), "+s"(ws), "+s"(sums),
+               "+s"(counters));
   const int lane = threadIdx.x;
   if (!(tag & IPPM_WORK_TILED) || (tag & IPPM_WORK_OVERFLOW)) {  // a list of the other form, or one that did not fit: say so
     if (first == 0 && lane == 0 && counters) atomicAdd(&counters[(env & (IPPM_COUNTER_SLOTS - 1)) * 8 + 6], 1ull);
@@ -252,11 +257,11 @@ k_fuse_tiles(const ippm_config* __restrict__ c, float* __restrict__ local, float
   if (first >= count) return;
   TileCtx w;
   w.local = local; w.global = global; w.code = code; w.plan = plan_ro; w.ws = ws;
-  w.n = c->n_agents; w.gx = c->grid_x; w.gy = c->grid_y;
-  w.row_bytes = c->tile_stride >> 2;
-  w.TB = (int)ippm_tile_bytes(c->tile_stride, 4);
+  w.n = n; w.gx = gx; w.gy = gy;
+  w.row_bytes = row_bytes;
+  w.TB = TB;
   w.n_envs = n_envs;
-  w.lc = c->logit_clip; w.wt = c->logit_weight_thr;
+  w.lc = lc; w.wt = wt;
   w.lane = lane;
   TileAcc acc;
   acc.a1 = acc.aD = 0.0;
@@ -311,7 +316,8 @@ int ippm_launch_fuse_tiles(ippm_ctx* ctx, float* local, float* global, const uin
   while ((long long)per_env * n_envs < 16384 && per_env * 2 <= env_cap && per_env < 256) per_env *= 2;
   dim3 grid((unsigned)n_envs, (unsigned)per_env), block(64);
 #define IPPM_FT(NA, M) \
-  IPPM_LAUNCH(ctx, IPPM_T_FUSE, (k_fuse_tiles<NA, M>), grid, block, st, ctx->dcfg, local, global, code, ws, ws, sums, ctx->dcounters, work, n_envs, env_cap)
+  IPPM_LAUNCH(ctx, IPPM_T_FUSE, (k_fuse_tiles<NA, M>), grid, block, st, work, n_envs, env_cap, c.n_agents, c.grid_x, c.grid_y, c.tile_stride >> 2, \
+              (int)ippm_tile_bytes(c.tile_stride, 4), c.logit_clip, c.logit_weight_thr, ws, local, global, code, ws, sums, ctx->dcounters)
   const bool mis = (c.grid_y & 3) != 0;   // rows only 4-byte aligned: the instantiation with the cell-by-cell row-tail stores
   if (max_ops <= 6) { if (mis) IPPM_FT(6, true); else IPPM_FT(6, false); }
   else if (max_ops <= 10) { if (mis) IPPM_FT(10, true); else IPPM_FT(10, false); }

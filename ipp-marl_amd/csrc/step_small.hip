@@ -294,12 +294,15 @@ __global__ void k_action_mask(const ippm_config* __restrict__ c, const int32_t* 
 #define IPPM_PLAN_BUILDERS_DEFAULT 3   // measured at 1024 envs x 4 UAVs: 1 / 2 / 3 / 5 builders -> 32.6 / 25.8 / 21.1 / 26.5 us (16 wavefronts
                                        // per CU is what one round of the launch holds; a sixth wavefront per env makes it two rounds)
 __global__ void __launch_bounds__(64 * (1 + IPPM_PLAN_BUILDERS))
-k_plan_step(const ippm_config* __restrict__ c, const int64_t* __restrict__ episode, int32_t* __restrict__ pos,
+k_plan_step(int32_t* __restrict__ pos, const int32_t* __restrict__ rect, int32_t* __restrict__ ws, int n, int flags, int t, int policy,
+            const ippm_config* __restrict__ c, const int64_t* __restrict__ episode,
             const float* __restrict__ comm_range, const double* __restrict__ draws, uint8_t* __restrict__ comm,
-            const int32_t* __restrict__ rect, int32_t* __restrict__ ws, int t, int flags, const float* __restrict__ probs,
-            const int32_t* __restrict__ action_in, int policy, uint8_t* __restrict__ mask, int32_t* __restrict__ action,
+            const float* __restrict__ probs,
+            const int32_t* __restrict__ action_in, uint8_t* __restrict__ mask, int32_t* __restrict__ action,
             int32_t* __restrict__ fault, int32_t* __restrict__ rect_next, int agent_sel, int32_t* __restrict__ work,
             int wave_rows, int env_cap, unsigned long long* __restrict__ stamps) {
+  // (argument order = latency order: what the first loads need -- positions, footprints, the maps' clamp state, the team size --
+  // arrives in SGPRs with the wavefront, so the loads go out before anything else has been read)
   // Wavefront 0 plans (comm matrix, fusion plans, written-cells boxes).  With a tile-form work list the workgroup carries more
   // wavefronts: builders, which cut the plans into one-trip items (a map each, round-robin) as soon as the plans are in LDS --
   // wavefront 0 joins them once it has planned -- and, when the launch also moves the agents, wavefront 1 for K1, which needs
@@ -309,7 +312,7 @@ k_plan_step(const ippm_config* __restrict__ c, const int64_t* __restrict__ episo
   // Hand-overs: ONE workgroup barrier, after the loads; the builders then wait for `s_ready` (an LDS flag the planning wavefront
   // releases), K1 waits for nobody.  K1's LDS traffic stays inside its wavefront (wave_sync_lds).
   const int e = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int n = c->n_agents, A = c->n_actions;
+  const int A = c->n_actions;
   __shared__ int32_t s_pos[IPPM_MAX_AGENTS * 3];    // pre-move positions: what comm and the plans see
   __shared__ int32_t s_pos1[IPPM_MAX_AGENTS * 3];   // K1's working copy (moved in place)
   __shared__ int32_t s_rect[IPPM_MAX_AGENTS * 4];
@@ -327,12 +330,20 @@ k_plan_step(const ippm_config* __restrict__ c, const int64_t* __restrict__ episo
   if (wv == 0) {
     // everything the workgroup will read is requested now, in one round trip: positions, published footprints, the
     // deferred-clamp state of my map (lane i: local map i, lane n: the global map)
+    // (unconditional loads from clamped addresses: behind lane predicates each load was waited for before the next went out)
+    const int32_t vpos = pg[min(lane, n * 3 - 1)];
+    int32_t vrect = 0;
+    if (plans) {
+      vrect = rect[(size_t)e * n * 4 + min(lane, n * 4 - 1)];
+      const int4* wsm = reinterpret_cast<const int4*>(ws + (size_t)(e * (n + 1) + min(lane, n)) * IPPM_WS_WORDS);
+      const int4 a = wsm[0];
+      const int2 b = *reinterpret_cast<const int2*>(wsm + 1);
+      st[0] = a.x; st[1] = a.y; st[2] = a.z; st[3] = a.w; st[4] = b.x; st[5] = b.y;
+    }
     if (lane <= n) s_nops[lane] = 0;
     if (lane == 0) { s_items = 0; s_done = 0; s_ready = 0; }
-    if (lane < n * 3) { const int32_t v = pg[lane]; s_pos[lane] = v; s_pos1[lane] = v; }
-    if (plans && lane < n * 4) s_rect[lane] = rect[(size_t)e * n * 4 + lane];
-    if (plans && lane <= n)
-      for (int q = 0; q < 6; ++q) st[q] = ws[(size_t)(e * (n + 1) + lane) * IPPM_WS_WORDS + q];
+    if (lane < n * 3) { s_pos[lane] = vpos; s_pos1[lane] = vpos; }
+    if (plans && lane < n * 4) s_rect[lane] = vrect;
   }
   if (waves > 1) __syncthreads(); else wave_sync_lds();
   PLAN_STAMP(1);
@@ -402,10 +413,14 @@ k_plan_step(const ippm_config* __restrict__ c, const int64_t* __restrict__ episo
          fault ? fault + e : nullptr);
   if (lane < n * 3) pg[lane] = s_pos1[lane];
   if (rect_next && lane < n) {
+    // the agent's sense record: K3 starts from these 32 bytes alone (footprint + the measurement constants of the new altitude)
     int cl[4];
     ippm_footprint_rect(c, s_pos1[lane * 3], s_pos1[lane * 3 + 1], s_pos1[lane * 3 + 2], cl, nullptr);
-    int32_t* r = rect_next + (size_t)(e * n + lane) * 4;
-    r[0] = cl[0]; r[1] = cl[1]; r[2] = cl[2]; r[3] = cl[3];
+    const int k = ippm_alt_index(c, s_pos1[lane * 3 + 2]);
+    const float lp = c->logit_prior;
+    int4* r = reinterpret_cast<int4*>(rect_next + (size_t)(e * n + lane) * IPPM_SENSE_REC_WORDS);
+    r[0] = make_int4(cl[0], cl[1], cl[2], cl[3]);
+    r[1] = make_int4(__float_as_int(c->logit_meas[k][0] - lp), __float_as_int(c->logit_meas[k][1] - lp), (int)c->flip_threshold[k], 0);
     if (ws) box_union(ws + (size_t)(e * (n + 1) + lane) * IPPM_WS_WORDS, cl[2], cl[3], cl[0], cl[1], WS_SBOX_X, WS_SBOX_Y);   // what K3 senses next
   }
   PLAN_STAMP(6);
@@ -491,8 +506,8 @@ extern "C" int ippm_plan_step(ippm_ctx* ctx, const int64_t* episode, int32_t* po
   }
   const bool tile_list = plans && work && (flags & IPPM_STEP_TILES);
   const int plan_waves = tile_list ? 1 + std::min(ctx->cfg.n_agents + 1, ctx->knob_plan_builders > 0 ? std::min(ctx->knob_plan_builders, IPPM_PLAN_BUILDERS) : IPPM_PLAN_BUILDERS_DEFAULT) : 1;
-  IPPM_LAUNCH(ctx, IPPM_T_PLAN, k_plan_step, dim3(n_envs), dim3(64 * plan_waves), S_(stream), ctx->dcfg, episode, pos, comm_range, draws, comm, rect, ws,
-                     t, flags, probs, action_in, policy, mask, action, fault, rect_next, -1, plans ? work : nullptr,
+  IPPM_LAUNCH(ctx, IPPM_T_PLAN, k_plan_step, dim3(n_envs), dim3(64 * plan_waves), S_(stream), pos, rect, ws, ctx->cfg.n_agents, flags, t, policy,
+                     ctx->dcfg, episode, comm_range, draws, comm, probs, action_in, mask, action, fault, rect_next, -1, plans ? work : nullptr,
                      ippm_fuse_wave_rows(ctx, n_envs), (flags & IPPM_STEP_TILES) ? ippm_tile_env_cap(ctx) : ippm_work_env_cap(ctx, n_envs),
                      ctx->dcounters);
   IPPM_LAUNCH_CHECK("plan_step");

@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("IPPMARL_LIB", os.path.join(_HERE, "..", "lib", "libip
 WS_WORDS = 160
 FEAT, ACTOR_PLANES, CRITIC_PLANES = 11, 7, 12
 STEP_COMM, STEP_GLOBAL, STEP_MOVE, STEP_TILES = 1, 2, 4, 8   # ippm_plan_step flags
+SENSE_REC_WORDS = 8   # words per agent of ippm_plan_step's rect_next / ippm_sense_step's rect_in (IPPM_SENSE_REC_WORDS)
 # kernel classes of ippm_read_kernel_times (IPPM_T_*)
 TIMED = {"sense": 0, "fuse": 1, "plan": 2, "actor_features": 3, "critic_features": 4, "reset": 5, "terrain": 6, "reset_maps": 7}
 

@@ -45,7 +45,7 @@ class VecEnv:
         self.pos = z(E, N, 3, dtype=torch.int32)
         self.pos_pre = z(E, N, 3, dtype=torch.int32)
         self.rect = z(E, N, 4, dtype=torch.int32)
-        self.rect_next = z(E, N, 4, dtype=torch.int32)                # footprints of the post-move positions (K1 -> K3)
+        self.rect_next = z(E, N, _ffi.SENSE_REC_WORDS, dtype=torch.int32)   # sense records of the post-move positions (K1 -> K3)
         self.truth = z(E, d.truth_bytes, dtype=torch.uint8)           # bit-packed ground truth (1 bit per cell)
         # beliefs are stored as float32 log-odds (0 = prior 0.5); posterior_local()/posterior_global() export p
         self.local = z(E, N, d.grid_x, d.grid_y, dtype=torch.float32)
