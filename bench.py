@@ -138,6 +138,8 @@ def main():
                     "ordinary launch.  Off by default: three launches per step do not need it")
     ap.add_argument("--rendezvous-only", action="store_true", help="start the ranks, all-reduce the rank ids over --dist-backend, "
                     "print {\"ranks\": N, ...} and stop before any GPU work (the CPU test of the self-launch)")
+    ap.add_argument("--placement-draws", type=int, default=8, help="allocations of the env's hot planes tried before the run "
+                    "(VecEnv.tune_placement; 1 = take what the allocator hands out)")
     ap.add_argument("--calib", action="store_true", help="PMC calibration: 3 device-to-device copies of the local maps (known "
                     "bytes read and written by a 16 B/lane streaming kernel) before the timed loop")
     args = ap.parse_args()
@@ -182,6 +184,9 @@ def main():
     params = bench_params(args)
     # env-only stepping never builds network inputs: the area sums are not tracked here (the trainer below tracks them)
     env = VecEnv(params, args.envs, device=device, philox_seed=3, terrain=args.terrain, track_area=False)
+    # where the allocator puts the maps is worth 10 % of the fusion kernel (VecEnv.tune_placement): a few candidate sets, one
+    # episode each, before anything is timed
+    placement = env.tune_placement(args.placement_draws)
     E, N, T = env.E, env.d.n_agents, env.d.budget + 1
     wave = [0]
 
@@ -446,6 +451,7 @@ def main():
             "cells": counters,
             "roofline": roofline,
             "roofline_kernels": roofline_kernels,
+            "placement": placement,
             "coma_training": coma,
         }
     if dist:   # every collective is done: the other ranks may leave while rank 0 times the CPU baseline on the host cores

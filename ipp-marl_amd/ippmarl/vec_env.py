@@ -46,11 +46,13 @@ class VecEnv:
         self.pos_pre = z(E, N, 3, dtype=torch.int32)
         self.rect = z(E, N, 4, dtype=torch.int32)
         self.rect_next = z(E, N, _ffi.SENSE_REC_WORDS, dtype=torch.int32)   # sense records of the post-move positions (K1 -> K3)
-        self.truth = z(E, d.truth_bytes, dtype=torch.uint8)           # bit-packed ground truth (1 bit per cell)
-        # beliefs are stored as float32 log-odds (0 = prior 0.5); posterior_local()/posterior_global() export p
-        self.local = z(E, N, d.grid_x, d.grid_y, dtype=torch.float32)
-        self.glob = z(E, d.grid_x, d.grid_y, dtype=torch.float32)
-        self.code = z(E, N, d.tile_bytes, dtype=torch.uint8)          # packed measurement codes (a nibble per 4-cell group)
+        # The step's hot planes live in ONE allocation (see tune_placement):
+        #   truth  bit-packed ground truth (1 bit per cell)
+        #   local, glob  beliefs as float32 log-odds (0 = prior 0.5); posterior_local()/posterior_global() export p
+        #   code   packed measurement codes (a nibble per 4-cell group)
+        self._hot_shapes = (("local", (E, N, d.grid_x, d.grid_y), torch.float32), ("glob", (E, d.grid_x, d.grid_y), torch.float32),
+                            ("code", (E, N, d.tile_bytes), torch.uint8), ("truth", (E, d.truth_bytes), torch.uint8))
+        self._place_hot()
         self.comm = z(E, N, N, dtype=torch.uint8)
         self.comm_range = z(E, dtype=torch.float32)
         self.mask = z(E, N, A, dtype=torch.uint8)
@@ -91,6 +93,18 @@ class VecEnv:
         self._ep_copied = None
 
     # ------------------------------------------------------------------------------------------------
+    def _place_hot(self, slack_mb: int = 0):
+        """(Re)allocates the hot planes as views of one zeroed device allocation, each plane on a 2 MB boundary."""
+        MB2 = 2 << 20
+        sizes = [int(np.prod(shape)) * torch.empty((), dtype=dt).element_size() for _, shape, dt in self._hot_shapes]
+        offs, total = [], 0
+        for n in sizes:
+            offs.append(total)
+            total += (n + MB2 - 1) // MB2 * MB2
+        self._arena = torch.zeros(total + (slack_mb << 20), dtype=torch.uint8, device=self.device)
+        for (name, shape, dt), off, n in zip(self._hot_shapes, offs, sizes):
+            setattr(self, name, self._arena[off:off + n].view(dt).view(shape))
+
     @property
     def profile(self) -> bool:
         return self._profile
@@ -354,6 +368,65 @@ class VecEnv:
         return self.reward, t == self.d.budget
 
     # ------------------------------------------------------------------------------------------------
+    def tune_placement(self, draws: int = 4) -> Optional[dict]:
+        """Draws the allocation of the env's hot planes (maps, code and truth planes: one device allocation) up to ``draws``
+        times and keeps the one on which the step's two map kernels run fastest.
+
+        Measured (tools/placement_probe*.py; config 2, MI355X, ROCm 7.2): a device allocation is either a good or a bad place
+        for these planes, for as long as it lives.  With all of them on good allocations the fusion kernel takes 76.5 us and
+        K3 35.8; each large plane on a bad one costs the fusion about 8 us (both maps: 90 us) and K3 about 1.5 -- same sizes,
+        same relative virtual addresses, same streaming-copy rate (6.7 TB/s either way), any offset inside an allocation behaves
+        like the allocation; only replacing the allocation changes it, and about every second fresh allocation is a bad one
+        (the two "kinds of box", 81 vs 86 us, of the round's earlier bench lines were this lottery, drawn once per buffer and
+        process).  The accesses that suffer are the scattered ones (90-cell row segments, code bytes), which points at the
+        translation reach of physically fragmented allocations rather than at DRAM; nothing in user space shows it directly.
+        The remedy that needs no knowledge of the cause: one allocation for everything hot (one draw decides, instead of four
+        independent ones), timed with one episode per candidate by the kernels' own dispatch-bound events; the best is kept,
+        the others are released.  Costs ~3 ms per draw at construction; the env must be reset afterwards.  Returns the trace
+        of the search (None for batches too small to matter)."""
+        d = self.d
+        if draws < 2 or self.E * d.grid_x * d.grid_y < (1 << 24):
+            return None
+        T = d.budget + 1
+        ids = list(range(1, self.E + 1))
+
+        def episode():
+            self._boxes_valid = False
+            self.reset(ids)
+            for t in range(T):
+                if self.track_area:
+                    self.build_observations(t, features=False)
+                self.steps(t, policy=POLICY_UNIFORM, features=False)
+
+        def score():
+            episode()                      # first touch of the candidate
+            was = self.profile
+            self.event_times_us()
+            self.profile = True
+            episode()
+            self.profile = was
+            tm = self.event_times_us()
+            return sum(tm[k]["avg_us"] * tm[k]["launches"] for k in ("sense", "fuse") if k in tm) / T
+
+        scores, arenas = [score()], [self._arena]
+        for k in range(1, draws):
+            self._place_hot(slack_mb=66 * k)       # (the earlier candidates stay allocated: every draw is a new block)
+            arenas.append(self._arena)
+            scores.append(score())
+        best = min(range(draws), key=scores.__getitem__)
+        self._arena = arenas[best]
+        MB2, off = 2 << 20, 0
+        for name, shape, dt in self._hot_shapes:
+            n = int(np.prod(shape)) * torch.empty((), dtype=dt).element_size()
+            setattr(self, name, self._arena[off:off + n].view(dt).view(shape))
+            off += (n + MB2 - 1) // MB2 * MB2
+        del arenas
+        torch.cuda.empty_cache()           # the rejected allocations go back to the driver
+        self._boxes_valid = False
+        self._pending_t = None
+        self._obs_t = None
+        return {"draws": draws, "kept": best, "map_kernels_us_per_step": [round(v, 1) for v in scores]}
+
     def event_times_us(self, clear: bool = True) -> Dict[str, Dict[str, float]]:
         """{kernel class: {"launches", "avg_us", "min_us", "kernel"}} of the launches made while ``profile`` was set
         (synchronises the stream)."""

@@ -641,6 +641,30 @@ def test_empty_mask_sets_fault_flag():
         O.uniform_valid_action(123, m)
 
 
+def test_placement_search_changes_addresses_not_results():
+    """VecEnv.tune_placement: the hot planes move to the allocation the map kernels ran fastest on; an episode afterwards is bit
+    for bit the episode of an env that never searched."""
+    from ippmarl.vec_env import POLICY_UNIFORM
+    params = make_params("c2")
+    E = 256                                                       # the smallest batch the search bothers with
+    a, b = _env(params, E, track_area=False), _env(params, E, track_area=False)
+    before = {n: getattr(b, n).data_ptr() for n in ("local", "glob", "code", "truth")}
+    res = b.tune_placement(3)
+    assert res is not None and res["draws"] == 3 and len(res["map_kernels_us_per_step"]) == 3
+    assert res["map_kernels_us_per_step"][res["kept"]] == min(res["map_kernels_us_per_step"])
+    if res["kept"] != 0:
+        assert all(getattr(b, n).data_ptr() != before[n] for n in before)
+    assert _env(params, 8, track_area=False).tune_placement(3) is None   # small batches: nothing to search for
+    ids = np.arange(11, 11 + E)
+    for env in (a, b):
+        env.reset(ids)
+        for t in range(env.d.budget + 1):
+            env.steps(t, policy=POLICY_UNIFORM, features=False)
+    torch.cuda.synchronize()
+    for n in ("local", "glob", "pos", "truth", "reward", "action"):   # (code tiles keep bytes of earlier footprints outside the current one)
+        assert torch.equal(getattr(a, n), getattr(b, n)), n
+
+
 def test_kernel_timing_reports_dispatch_durations():
     """ippm_kernel_timing / ippm_read_kernel_times (what bench.py's roofline leg reads): every launch of the timed classes made
     while timing is on is counted once, under the name the compiler gives the kernel, with a plausible begin-to-end duration;
