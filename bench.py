@@ -138,7 +138,7 @@ def main():
                     "ordinary launch.  Off by default: three launches per step do not need it")
     ap.add_argument("--rendezvous-only", action="store_true", help="start the ranks, all-reduce the rank ids over --dist-backend, "
                     "print {\"ranks\": N, ...} and stop before any GPU work (the CPU test of the self-launch)")
-    ap.add_argument("--placement-draws", type=int, default=8, help="allocations of the env's hot planes tried before the run "
+    ap.add_argument("--placement-draws", type=int, default=24, help="allocations of the env's hot planes tried before the run "
                     "(VecEnv.tune_placement; 1 = take what the allocator hands out)")
     ap.add_argument("--calib", action="store_true", help="PMC calibration: 3 device-to-device copies of the local maps (known "
                     "bytes read and written by a 16 B/lane streaming kernel) before the timed loop")
@@ -340,7 +340,8 @@ def main():
         from ippmarl.trainer import COMATrainer
         env = None  # release the env-only state before the trainer allocates its own
         torch.cuda.empty_cache()
-        tr = COMATrainer(params, args.envs, device=device, philox_seed=3, rank=rank, world=world, terrain=args.terrain)
+        tr = COMATrainer(params, args.envs, device=device, philox_seed=3, rank=rank, world=world, terrain=args.terrain,
+                         placement_draws=args.placement_draws)
         tr.rollout("train")
         tr.update()  # warm-up round (MIOpen kernel selection, allocator)
         torch.cuda.synchronize()

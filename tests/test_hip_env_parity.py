@@ -650,7 +650,7 @@ def test_placement_search_changes_addresses_not_results():
     a, b = _env(params, E, track_area=False), _env(params, E, track_area=False)
     before = {n: getattr(b, n).data_ptr() for n in ("local", "glob", "code", "truth")}
     res = b.tune_placement(3)
-    assert res is not None and res["draws"] == 3 and len(res["map_kernels_us_per_step"]) == 3
+    assert res is not None and 1 <= res["draws"] <= 3 and len(res["map_kernels_us_per_step"]) == res["draws"]
     assert res["map_kernels_us_per_step"][res["kept"]] == min(res["map_kernels_us_per_step"])
     if res["kept"] != 0:
         assert all(getattr(b, n).data_ptr() != before[n] for n in before)
