@@ -5,7 +5,9 @@
 TAG=${1:-prof}
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-BENCH="python bench.py --steps 60 --warmup 15 --no-cpu-baseline --train-rounds 0 --calib"
+# (--placement-draws 1: no search, so that every launch rocprofv3 sees belongs to the bench loop; the class of allocation the
+# process drew shows in the fusion time, 80-81 us on a good one, 85-87 on a bad one)
+BENCH="python bench.py --steps 60 --warmup 15 --no-cpu-baseline --train-rounds 0 --calib --placement-draws 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o p -- $BENCH > $OUT/bench_under_rocprofv3.json 2> $OUT/stats.err
 find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_bench_steps60.csv \;
 rocprofv3 --kernel-trace -d $OUT/trace -o p -- $BENCH > /dev/null 2> $OUT/trace.err
