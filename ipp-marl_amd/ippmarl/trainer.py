@@ -158,6 +158,7 @@ class COMATrainer:
         for k, v in saved.items():   # capture does not execute; keep the env's state untouched in any case
             getattr(env, k).copy_(v)
         self._step_graphs, self._update_graph = graphs, g
+        env._graphs = graphs            # (the env's buffers are baked into the recording: VecEnv.tune_placement refuses from here on)
 
     # ------------------------------------------------------------------------------------------------
     def td_targets(self):

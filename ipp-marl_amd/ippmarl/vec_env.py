@@ -393,6 +393,8 @@ class VecEnv:
         d = self.d
         if draws < 2 or self.E * d.grid_x * d.grid_y < (1 << 24):
             return None
+        if getattr(self, "_graphs", None):
+            raise _ffi.IppmError("tune_placement moves the maps: call it before capture_step_graphs (captured launches keep the old addresses)")
         T = d.budget + 1
         ids = list(range(1, self.E + 1))
 
