@@ -132,6 +132,74 @@ __device__ __forceinline__ int plan_map(const ippm_config* __restrict__ c, const
   return nops > 0 ? x1 - x0 : 0;
 }
 
+// plan_map for k_plan_step: the op record of a measurement (type, source, log-odds of its altitude, footprint) is the same for
+// every map that receives it, so lane j has prepared it once (s_rec: two int4 per agent, s_rect4: the footprints) and a map's lane
+// copies 32 bytes per received agent instead of re-deriving altitude index and table values op by op (the planning wavefront's
+// serial loop was 4 of the kernel's 12 us).  Same results as plan_map, field by field.
+__device__ __forceinline__ int plan_map_fast(const ippm_config* __restrict__ c, const int4* s_rect4, const int4* s_rec, uint32_t recv,
+                                              int32_t* __restrict__ ws, int global_maps, int e, int i, const int32_t* st,
+                                              int4* s_ops, int32_t* s_nops) {
+  const int n = c->n_agents;
+  int32_t* w = ws + (size_t)(e * (n + 1) + i) * IPPM_WS_WORDS;
+  const uint32_t all = n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
+  const uint32_t takes = global_maps ? all : (recv & ~(1u << i) & all);
+  int32_t* hdr = w + WS_PLAN;
+  if (takes == 0) {  // nothing received: the map is untouched; carry possible out-of-range regions forward
+    if (!global_maps && st[WS_FLAG_S]) {
+      const int4 ri = s_rect4[i];
+      if (st[WS_FLAG_A]) {
+        w[WS_RECT_A + 0] = min(st[WS_RECT_A + 0], ri.x); w[WS_RECT_A + 1] = max(st[WS_RECT_A + 1], ri.y);
+        w[WS_RECT_A + 2] = min(st[WS_RECT_A + 2], ri.z); w[WS_RECT_A + 3] = max(st[WS_RECT_A + 3], ri.w);
+      } else {
+        w[WS_RECT_A + 0] = ri.x; w[WS_RECT_A + 1] = ri.y; w[WS_RECT_A + 2] = ri.z; w[WS_RECT_A + 3] = ri.w;
+      }
+      w[WS_FLAG_A] = 1;
+      w[WS_FLAG_S] = 0;
+    }
+    hdr[PL_NOPS] = 0;
+    *s_nops = 0;
+    return 0;
+  }
+  const int last_src = 31 - __clz(takes);
+  int nops = 0, x0 = 1 << 30, x1 = -1, y0 = 1 << 30, y1 = -1;
+  int4* ops = reinterpret_cast<int4*>(w + WS_OPS);
+  auto clamp_op = [&](int4 r) {   // an op that only clips (type 0)
+    if (r.w <= r.z || r.y <= r.x) return;
+    s_ops[nops] = r;
+    ops[nops * 2] = make_int4(0, -1, 0, r.x);
+    ops[nops * 2 + 1] = make_int4(r.y, r.z, r.w, 0);
+    x0 = min(x0, r.z); x1 = max(x1, r.w); y0 = min(y0, r.x); y1 = max(y1, r.y);
+    ++nops;
+  };
+  if (st[WS_FLAG_A]) clamp_op(make_int4(st[WS_RECT_A], st[WS_RECT_A + 1], st[WS_RECT_A + 2], st[WS_RECT_A + 3]));
+  if (!global_maps && st[WS_FLAG_S]) clamp_op(s_rect4[i]);
+  int last_op = -1;
+  for (uint32_t rem = takes; rem != 0; rem &= rem - 1u) {
+    const int j = __ffs(rem) - 1;
+    const int4 r = s_rect4[j];
+    const bool some = r.w > r.z && r.y > r.x;
+    if (some) {
+      s_ops[nops] = r;
+      ops[nops * 2] = s_rec[j * 2];
+      ops[nops * 2 + 1] = s_rec[j * 2 + 1];
+      x0 = min(x0, r.z); x1 = max(x1, r.w); y0 = min(y0, r.x); y1 = max(y1, r.y);
+      ++nops;
+    }
+    if (j == last_src) {
+      last_op = some ? nops - 1 : -1;  // an empty last footprint leaves no unclamped outputs
+      w[WS_RECT_A + 0] = r.x; w[WS_RECT_A + 1] = r.y; w[WS_RECT_A + 2] = r.z; w[WS_RECT_A + 3] = r.w;
+    }
+  }
+  w[WS_FLAG_A] = 0;  // set again by the fusion kernel if the last op leaves out-of-range values
+  w[WS_FLAG_S] = 0;
+  hdr[PL_NOPS] = nops;
+  *s_nops = nops;
+  if (c->logit_prior != 0.f && nops > 0) { x0 = 0; x1 = c->grid_x; y0 = 0; y1 = c->grid_y; }
+  hdr[PL_X0] = x0; hdr[PL_X1] = x1; hdr[PL_Y0] = y0; hdr[PL_Y1] = y1;
+  hdr[PL_LAST] = last_op;
+  return nops > 0 ? x1 - x0 : 0;
+}
+
 __global__ void k_plan(const ippm_config* __restrict__ c, const int32_t* __restrict__ rect,
                        const int32_t* __restrict__ pos, const uint8_t* __restrict__ comm, int32_t* __restrict__ ws,
                        int global_maps, int n_envs, int agent_sel) {
@@ -315,7 +383,9 @@ k_plan_step(int32_t* __restrict__ pos, const int32_t* __restrict__ rect, int32_t
   const int A = c->n_actions;
   __shared__ int32_t s_pos[IPPM_MAX_AGENTS * 3];    // pre-move positions: what comm and the plans see
   __shared__ int32_t s_pos1[IPPM_MAX_AGENTS * 3];   // K1's working copy (moved in place)
-  __shared__ int32_t s_rect[IPPM_MAX_AGENTS * 4];
+  __shared__ int4 s_rect4[IPPM_MAX_AGENTS];
+  __shared__ int4 s_rec[IPPM_MAX_AGENTS * 2];        // per agent: the op record of its measurement (plan_map_fast)
+  int32_t* s_rect = reinterpret_cast<int32_t*>(s_rect4);
   __shared__ int4 s_ops[(IPPM_MAX_AGENTS + 1) * IPPM_MAX_OPS];   // the op rectangles of every plan, for the tile builders
   __shared__ int32_t s_nops[IPPM_MAX_AGENTS + 1];
   __shared__ int32_t s_items, s_done, s_ready;   // items handed out so far; builders that have finished; plans are in LDS
@@ -349,13 +419,27 @@ k_plan_step(int32_t* __restrict__ pos, const int32_t* __restrict__ rect, int32_t
   PLAN_STAMP(1);
   if (wv == 0 && plans) {
     int hull_rows = 0;
-    if ((flags & IPPM_STEP_COMM) && lane < n) {
-      const uint32_t recv = comm_row(c, episode, s_pos, comm_range, draws, comm, t, e, lane);
-      if (agent_sel < 0 || agent_sel == lane)
-        hull_rows = plan_map(c, s_rect, s_pos, recv, ws, 0, e, lane, st, tiled ? s_ops + lane * IPPM_MAX_OPS : nullptr, tiled ? s_nops + lane : nullptr);
+    if (tiled && lane < n) {   // lane j: the op record of agent j's measurement, once for all the maps that will take it
+      const int k = ippm_alt_index(c, s_pos[lane * 3 + 2]);
+      const int4 r = s_rect4[lane];
+      s_rec[lane * 2] = make_int4(1, lane, __float_as_int(c->logit_meas[k][0]), r.x);
+      s_rec[lane * 2 + 1] = make_int4(r.y, r.z, r.w, __float_as_int(c->logit_meas[k][1]));
     }
-    if ((flags & IPPM_STEP_GLOBAL) && lane == n)
-      hull_rows = plan_map(c, s_rect, s_pos, 0u, ws, 1, e, n, st, tiled ? s_ops + n * IPPM_MAX_OPS : nullptr, tiled ? s_nops + n : nullptr);
+    uint32_t recv = 0;
+    if ((flags & IPPM_STEP_COMM) && lane < n) recv = comm_row(c, episode, s_pos, comm_range, draws, comm, t, e, lane);
+    PLAN_STAMP(7);
+    if (tiled) {
+      wave_sync_lds();
+      if ((flags & IPPM_STEP_COMM) && lane < n && (agent_sel < 0 || agent_sel == lane))
+        hull_rows = plan_map_fast(c, s_rect4, s_rec, recv, ws, 0, e, lane, st, s_ops + lane * IPPM_MAX_OPS, s_nops + lane);
+      if ((flags & IPPM_STEP_GLOBAL) && lane == n)
+        hull_rows = plan_map_fast(c, s_rect4, s_rec, 0u, ws, 1, e, n, st, s_ops + n * IPPM_MAX_OPS, s_nops + n);
+    } else {
+      if ((flags & IPPM_STEP_COMM) && lane < n && (agent_sel < 0 || agent_sel == lane))
+        hull_rows = plan_map(c, s_rect, s_pos, recv, ws, 0, e, lane, st);
+      if ((flags & IPPM_STEP_GLOBAL) && lane == n)
+        hull_rows = plan_map(c, s_rect, s_pos, 0u, ws, 1, e, n, st);
+    }
     // the map's fused-cells box takes in this step's plan hull (ippm_reset_maps fills only the boxes at the next reset)
     if (lane <= n && hull_rows > 0) {
       int32_t* wm = ws + (size_t)(e * (n + 1) + lane) * IPPM_WS_WORDS;

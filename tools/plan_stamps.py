@@ -19,7 +19,7 @@ class A:
 
 env = VecEnv(bench_params(A), 1024, philox_seed=3, terrain="split", track_area=False)
 env.reset(list(range(1, 1025)))
-names = ["start", "loaded", "plans done", "builder start", "builder done", "K1 start", "K1 done"]
+names = ["start", "loaded", "plans done", "builder start", "builder done", "K1 start", "K1 done", "comm done"]
 for t in range(8):
     env.steps(t, policy=POLICY_UNIFORM, features=False)
     raw = np.zeros(512, dtype=np.uint64)
@@ -28,6 +28,6 @@ for t in range(8):
     t0 = st[0]
     line = []
     for wv in (0, 1, 6, 7):   # 6 / 7: wavefront 0 of the last / the middle env
-        ks = {0: (0, 1, 2, 5, 6), 6: (0, 1, 2, 5, 6), 7: (0, 1, 2, 5, 6)}.get(wv, (0, 2, 3, 4))
+        ks = {0: (0, 1, 7, 2, 3, 4), 6: (0, 1, 7, 2, 4), 7: (0, 1, 7, 2, 4)}.get(wv, (0, 5, 6))
         line.append(f"w{wv}: " + " ".join(f"{names[k]}={(st[wv * 8 + k] - t0) / 100.0:.1f}us" for k in ks if st[wv * 8 + k]))
     print(f"t={t}  " + " | ".join(line))
