@@ -11,36 +11,43 @@
 // ======================================================================================================
 // comm matrix
 // ======================================================================================================
-// row i of the comm matrix of env e: bit j set <=> agent i hears agent j (communication_log.py:39-58); also stored as bytes.
-// pos_e = the env's [N,3] positions (global memory or LDS)
+// does agent i hear agent j in env e at step t? (communication_log.py:39-58)  pos_e = the env's [N,3] positions (global memory or
+// LDS); u = the pair's uniform draw: explicit (parity mode), Philox, or moot when links never fail
+__device__ __forceinline__ bool comm_pair(const ippm_config* __restrict__ c, int64_t ep, const int32_t* pos_e, double range,
+                                          const double* __restrict__ draws, int t, int e, int i, int j) {
+  const int n = c->n_agents;
+  const int32_t* pi = pos_e + i * 3;
+  const int32_t* pj = pos_e + j * 3;
+  long long dx = pi[0] - pj[0], dy = pi[1] - pj[1], dz = pi[2] - pj[2];
+  long long d2 = dx * dx + dy * dy + dz * dz;
+  double u = 1.0;
+  if (c->failure_rate > 0.0) {  // u >= 0 always passes otherwise: the draw (one per ordered pair in the reference) is moot
+    if (draws) u = draws[(size_t)(e * n + i) * n + j];
+    else {
+      const uint32_t k0 = (uint32_t)c->philox_seed, k1 = (uint32_t)(c->philox_seed >> 32);
+      Philox4 ph = ippm_philox((uint32_t)j, (uint32_t)ep, ippm_stream_word((uint32_t)i, (uint32_t)t, IPPM_DOMAIN_COMM),
+                               (uint32_t)(ep >> 32), k0, k1);
+      u = (double)ph.v[0] * (1.0 / 4294967296.0);
+    }
+  }
+  bool ok = d2 == 0;
+  if (d2 > 0) {
+    double dist = sqrt((double)d2);
+    if (dist <= range && u >= c->failure_rate) ok = true;
+  }
+  return ok;
+}
+
+// row i of the comm matrix of env e: bit j set <=> agent i hears agent j; also stored as bytes
 __device__ __forceinline__ uint32_t comm_row(const ippm_config* __restrict__ c, const int64_t* __restrict__ episode,
                                              const int32_t* pos_e, const float* __restrict__ comm_range,
                                              const double* __restrict__ draws, uint8_t* __restrict__ comm, int t, int e, int i) {
   const int n = c->n_agents;
-  const int32_t* pi = pos_e + i * 3;
   const double range = comm_range ? (double)comm_range[e] : c->comm_range;
   const int64_t ep = episode ? episode[e] : 0;
-  const uint32_t k0 = (uint32_t)c->philox_seed, k1 = (uint32_t)(c->philox_seed >> 32);
-  const bool lossy = c->failure_rate > 0.0;  // u >= 0 always passes otherwise: the draw (one per ordered pair in the reference) is moot
   uint32_t row = 0;
   for (int j = 0; j < n; ++j) {
-    const int32_t* pj = pos_e + j * 3;
-    long long dx = pi[0] - pj[0], dy = pi[1] - pj[1], dz = pi[2] - pj[2];
-    long long d2 = dx * dx + dy * dy + dz * dz;
-    double u = 1.0;
-    if (lossy) {
-      if (draws) u = draws[(size_t)(e * n + i) * n + j];
-      else {
-        Philox4 ph = ippm_philox((uint32_t)j, (uint32_t)ep, ippm_stream_word((uint32_t)i, (uint32_t)t, IPPM_DOMAIN_COMM),
-                                 (uint32_t)(ep >> 32), k0, k1);
-        u = (double)ph.v[0] * (1.0 / 4294967296.0);
-      }
-    }
-    bool ok = d2 == 0;
-    if (d2 > 0) {
-      double dist = sqrt((double)d2);
-      if (dist <= range && u >= c->failure_rate) ok = true;
-    }
+    const bool ok = comm_pair(c, ep, pos_e, range, draws, t, e, i, j);
     comm[(size_t)(e * n + i) * n + j] = ok ? 1 : 0;
     row |= ok ? (1u << j) : 0u;
   }
@@ -388,6 +395,7 @@ k_plan_step(int32_t* __restrict__ pos, const int32_t* __restrict__ rect, int32_t
   int32_t* s_rect = reinterpret_cast<int32_t*>(s_rect4);
   __shared__ int4 s_ops[(IPPM_MAX_AGENTS + 1) * IPPM_MAX_OPS];   // the op rectangles of every plan, for the tile builders
   __shared__ int32_t s_nops[IPPM_MAX_AGENTS + 1];
+  __shared__ uint32_t s_recv[IPPM_MAX_AGENTS];     // row i of the comm matrix as a bit mask
   __shared__ int32_t s_items, s_done, s_ready;   // items handed out so far; builders that have finished; plans are in LDS
   const bool plans = (flags & (IPPM_STEP_COMM | IPPM_STEP_GLOBAL)) != 0;
   const bool tiled = (flags & IPPM_STEP_TILES) != 0 && work && plans;
@@ -411,6 +419,7 @@ k_plan_step(int32_t* __restrict__ pos, const int32_t* __restrict__ rect, int32_t
       st[0] = a.x; st[1] = a.y; st[2] = a.z; st[3] = a.w; st[4] = b.x; st[5] = b.y;
     }
     if (lane <= n) s_nops[lane] = 0;
+    if (lane < n) s_recv[lane] = 0;
     if (lane == 0) { s_items = 0; s_done = 0; s_ready = 0; }
     if (lane < n * 3) { s_pos[lane] = vpos; s_pos1[lane] = vpos; }
     if (plans && lane < n * 4) s_rect[lane] = vrect;
@@ -426,7 +435,24 @@ k_plan_step(int32_t* __restrict__ pos, const int32_t* __restrict__ rect, int32_t
       s_rec[lane * 2 + 1] = make_int4(r.y, r.z, r.w, __float_as_int(c->logit_meas[k][1]));
     }
     uint32_t recv = 0;
-    if ((flags & IPPM_STEP_COMM) && lane < n) recv = comm_row(c, episode, s_pos, comm_range, draws, comm, t, e, lane);
+    if (flags & IPPM_STEP_COMM) {
+      // the comm matrix with lanes = ordered pairs (a lane per row walked its n pairs one after the other: a float64 square root
+      // and a Philox call each); the rows' receive masks are gathered in LDS
+      const double range = comm_range ? (double)comm_range[e] : c->comm_range;
+      const int64_t ep = episode ? episode[e] : 0;
+      const float inv_n = __builtin_amdgcn_rcpf((float)n);
+      for (int p0 = 0; p0 < n * n; p0 += 64) {
+        const int p = p0 + lane;
+        if (p < n * n) {
+          const int i = (int)(((float)p + 0.5f) * inv_n), j = p - i * n;
+          const bool ok = comm_pair(c, ep, s_pos, range, draws, t, e, i, j);
+          comm[(size_t)e * n * n + p] = ok ? 1 : 0;
+          if (ok) atomicOr(&s_recv[i], 1u << j);
+        }
+      }
+      wave_sync_lds();
+      if (lane < n) recv = s_recv[lane];
+    }
     PLAN_STAMP(7);
     if (tiled) {
       wave_sync_lds();
