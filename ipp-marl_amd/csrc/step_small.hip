@@ -499,7 +499,13 @@ k_plan_step(int32_t* __restrict__ pos, const int32_t* __restrict__ rect, int32_t
       while (__hip_atomic_load(&s_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
     int4* items = reinterpret_cast<int4*>(work + ((gridDim.x + 3) & ~3)) + (size_t)e * env_cap;
     PLAN_STAMP(3);
-    for (int mm = b; mm <= n; mm += nb) {
+    // Builder 0 is the planning wavefront: it starts last, and it takes the global map, whose plan holds every footprint (about
+    // as many items as two or three local plans).  The local maps go to the other builders in turn, every third round of them
+    // to builder 0 (4 UAVs, 3 builders: global | locals 0, 2 | locals 1, 3 instead of global + local 2 on the late one: -1 us).
+    for (int mm = 0; mm <= n; ++mm) {
+      const int k = mm - 1;
+      const int owner = (mm == 0 || nb == 1) ? 0 : (((k / (nb - 1)) % 3 == 2) ? 0 : 1 + k % (nb - 1));
+      if (owner != b) continue;
       const int m = mm == 0 ? n : mm - 1;   // the global map's items come early: they carry the reward arithmetic
       const int nops = __builtin_amdgcn_readfirstlane(s_nops[m]);
       if (nops > 0) tile_build_map(s_ops + m * IPPM_MAX_OPS, nops, e, m, items, env_cap, &s_items, lane);
