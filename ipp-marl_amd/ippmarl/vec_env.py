@@ -416,6 +416,7 @@ class VecEnv:
             tm = self.event_times_us()
             return sum(tm[k]["avg_us"] * tm[k]["launches"] for k in ("sense", "fuse") if k in tm) / T
 
+        score()                            # (the process's first episodes run 2-4 % slow whatever the allocation: not a sample)
         scores, arenas = [score()], [self._arena]
         for k in range(1, draws):
             # the two kinds are 7-8 % apart and each is sharp to 1 %: a candidate well below the worst seen is a good one
