@@ -18,6 +18,8 @@ lib = C.CDLL(os.path.join(ROOT, "tools", "probe", "libvmm_arena.so"))
 lib.vmm_arena_create.restype = C.c_void_p
 lib.vmm_arena_create.argtypes = [C.c_size_t, C.c_size_t, C.c_int, C.c_uint, C.c_size_t, C.POINTER(C.c_void_p)]
 lib.vmm_arena_destroy.argtypes = [C.c_void_p]
+lib.vmm_arena_create_spread.restype = C.c_void_p
+lib.vmm_arena_create_spread.argtypes = [C.c_size_t, C.c_size_t, C.c_int, C.c_uint, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
 
 
 class Raw:
@@ -51,16 +53,15 @@ def main():
     keep = []
     MB = 1 << 20
     for rep in range(3):
-        for chunk, order, align in ((256 * MB, 0, 2 * MB), (256 * MB, 0, 256 * MB), (1024 * MB, 0, 2 * MB), (1024 * MB, 0, 1024 * MB),
-                                    (2048 * MB, 0, 2048 * MB), (64 * MB, 0, 64 * MB), (32 * MB, 0, 32 * MB), (2 * MB, 0, 2 * MB)):
+        for chunk, order, spread in ((2 * MB, 0, 1), (2 * MB, 2, 4), (2 * MB, 0, 4), (2 * MB, 2, 16), (8 * MB, 2, 4), (32 * MB, 2, 4), (2 * MB, 2, 1)):
             ptr = C.c_void_p()
-            h = lib.vmm_arena_create(nbytes, chunk, order, 17 + rep, align, C.byref(ptr))
+            h = lib.vmm_arena_create_spread(nbytes, chunk, order, 17 + rep, 2 * MB, spread, C.byref(ptr))
             if not h:
-                print("create failed", chunk, order)
+                print("create failed", chunk, order, spread)
                 continue
             arena = torch.as_tensor(Raw(ptr.value, nbytes), device="cuda")
             env._use_arena(arena)
-            print(f"rep {rep} chunk {chunk / MB:8.2f} MB va-align {align / MB:7.1f} MB at {ptr.value:#x}", score(), flush=True)
+            print(f"rep {rep} chunk {chunk / MB:6.1f} MB order {('created', 'reversed', 'shuffled')[order]:9s} spread {spread:2d}", score(), flush=True)
             keep.append(h)
     env._place_hot()
     print("torch allocation", score())
