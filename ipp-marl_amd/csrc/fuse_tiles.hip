@@ -229,11 +229,12 @@ __device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e,
 
 // Workgroup = one wavefront; gridDim.x is a multiple of the env count: wavefront b serves env b % E and takes every
 // (gridDim.x / E)-th item of the env's list.
+// (wavefronts per SIMD: 5 in general; the production instantiation <6, false> fits in 80 VGPRs without scratch and takes 6: +1 %)
 #ifndef IPPM_TILE_WAVES_PER_EU
 #define IPPM_TILE_WAVES_PER_EU 5
 #endif
 template <int NAMAX, bool MIS>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(IPPM_TILE_WAVES_PER_EU, 8)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NAMAX <= 6 && !MIS ? 6 : IPPM_TILE_WAVES_PER_EU, 8)))
 k_fuse_tiles(const int32_t* __restrict__ work, int n_envs, int env_cap, int n, int gx, int gy, int row_bytes, int TB, float lc, float wt,
              const int32_t* __restrict__ plan_ro, float* __restrict__ local, float* __restrict__ global,
              const uint8_t* __restrict__ code, int32_t* __restrict__ ws, double* __restrict__ sums,
