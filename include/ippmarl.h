@@ -53,7 +53,7 @@
 extern "C" {
 #endif
 
-#define IPPM_VERSION 300
+#define IPPM_VERSION 301
 #define IPPM_MAX_AGENTS 16
 #define IPPM_MAX_LATTICE 64 /* lattice points per horizontal axis */
 #define IPPM_MAX_Z 8        /* altitude levels */
