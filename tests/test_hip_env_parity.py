@@ -641,6 +641,32 @@ def test_empty_mask_sets_fault_flag():
         O.uniform_valid_action(123, m)
 
 
+def test_sense_records_hold_footprint_and_sensor_constants():
+    """K1's sense records (rect_next, what K3 starts from): the footprint K3 then publishes, and the measurement log-odds (minus
+    logit(prior), float32 arithmetic) and flip threshold of the agent's NEW altitude, bit for bit from the host tables."""
+    from ippmarl import _ffi
+    from ippmarl.vec_env import POLICY_UNIFORM
+    for name, over in (("c2", {}), ("small", {"mapping__prior": 0.45})):
+        params = make_params(name, **over)
+        env = _env(params, 16, track_area=(name == "small"))
+        d = env.d
+        env.reset(np.arange(5, 21))
+        for t in range(4):
+            if env.track_area:
+                env.build_observations(t)
+            env.steps(t, policy=POLICY_UNIFORM, features=False)
+            torch.cuda.synchronize()
+            rec = env.rect_next.cpu().numpy()
+            assert rec.shape[-1] == _ffi.SENSE_REC_WORDS
+            np.testing.assert_array_equal(rec[..., :4], env.rect.cpu().numpy())
+            k = (env.pos.cpu().numpy()[..., 2] - d.min_altitude) // d.spacing
+            lp = np.float32(d.logit_prior)
+            want_lm = (d.logit_meas[k] - lp).astype(np.float32)                     # [E, N, 2]
+            np.testing.assert_array_equal(rec[..., 4:6].view(np.float32), want_lm)
+            np.testing.assert_array_equal(rec[..., 6].astype(np.int64) & 0xFFFFFFFF, d.flip_threshold[k].astype(np.int64))
+            assert not rec[..., 7].any()
+
+
 def test_placement_search_changes_addresses_not_results():
     """VecEnv.tune_placement: the hot planes move to the allocation the map kernels ran fastest on; an episode afterwards is bit
     for bit the episode of an env that never searched."""
