@@ -422,7 +422,7 @@ class VecEnv:
             # the two kinds are 7-8 % apart and each is sharp to 1 %: a candidate well below the worst seen is a good one
             if min(scores) < 0.96 * max(scores) and not os.environ.get("IPPM_PLACEMENT_NO_EARLY"):
                 break
-            self._place_hot(slack_mb=66 * k)       # (the earlier candidates stay allocated: every draw is a new block)
+            self._place_hot(slack_mb=66 * (k % 16))   # (the earlier candidates stay allocated: every draw is a new block)
             arenas.append(self._arena)
             scores.append(score())
         best = min(range(len(scores)), key=scores.__getitem__)
