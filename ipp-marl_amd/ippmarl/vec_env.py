@@ -29,6 +29,17 @@ from .derived import DerivedConstants
 POLICY_EXPLICIT, POLICY_UNIFORM, POLICY_SAMPLE, POLICY_ARGMAX = 0, 1, 2, 3
 
 
+def hot_layout(shapes, align: int = 2 << 20):
+    """Byte spans [(offset, bytes)] of the planes ``shapes`` = ((name, shape, torch dtype), ...) inside one allocation, every plane
+    on an ``align`` boundary, and the allocation's size."""
+    spans, total = [], 0
+    for _, shape, dt in shapes:
+        n = int(np.prod(shape)) * torch.empty((), dtype=dt).element_size()
+        spans.append((total, n))
+        total += (n + align - 1) // align * align
+    return spans, total
+
+
 class VecEnv:
     def __init__(self, params: Dict, n_envs: int, device: str = "cuda:0", philox_seed: int = 3, terrain: str = "split",
                  track_area: bool = True):
@@ -97,18 +108,16 @@ class VecEnv:
     # ------------------------------------------------------------------------------------------------
     def _place_hot(self, slack_mb: int = 0):
         """(Re)allocates the hot planes as views of one zeroed device allocation, each plane on a 2 MB boundary."""
-        MB2 = 2 << 20
-        sizes = [int(np.prod(shape)) * torch.empty((), dtype=dt).element_size() for _, shape, dt in self._hot_shapes]
-        total = sum((n + MB2 - 1) // MB2 * MB2 for n in sizes)
+        _, total = hot_layout(self._hot_shapes)
         self._use_arena(torch.zeros(total + (slack_mb << 20), dtype=torch.uint8, device=self.device))
 
     def _use_arena(self, arena: torch.Tensor):
-        MB2, off = 2 << 20, 0
+        spans, total = hot_layout(self._hot_shapes)
+        if arena.numel() < total or arena.dtype != torch.uint8:
+            raise ValueError(f"an arena for this env holds at least {total} bytes (uint8)")
         self._arena = arena
-        for name, shape, dt in self._hot_shapes:
-            n = int(np.prod(shape)) * torch.empty((), dtype=dt).element_size()
+        for (name, shape, dt), (off, n) in zip(self._hot_shapes, spans):
             setattr(self, name, arena[off:off + n].view(dt).view(shape))
-            off += (n + MB2 - 1) // MB2 * MB2
         self._boxes_valid = False          # the maps of another allocation: the next reset fills them whole
 
     @property

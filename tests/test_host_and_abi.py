@@ -179,3 +179,18 @@ def test_params_schema_loads_and_matches_reference_defaults():
     assert p["experiment"]["uav"]["communication_range"] == 25 and p["mapping"]["prior"] == 0.5
     from ippmarl.derived import DerivedConstants
     assert DerivedConstants(grid256_params()).grid_x == 256
+
+
+def test_hot_plane_layout_is_aligned_and_disjoint():
+    """VecEnv keeps its large planes in one allocation: 2 MB-aligned, non-overlapping spans, config 2's sizes."""
+    import torch
+    from ippmarl.vec_env import hot_layout
+    shapes = (("local", (1024, 4, 256, 256), torch.float32), ("glob", (1024, 256, 256), torch.float32),
+              ("code", (1024, 4, 96 * 96 // 4), torch.uint8), ("truth", (1024, 8192), torch.uint8), ("odd", (3, 5, 7), torch.float32))
+    spans, total = hot_layout(shapes)
+    assert [n for _, n in spans] == [1 << 30, 1 << 28, 1024 * 4 * 2304, 1 << 23, 420]
+    end = 0
+    for off, n in spans:
+        assert off % (2 << 20) == 0 and off >= end
+        end = off + n
+    assert total % (2 << 20) == 0 and total >= end and total - end < (2 << 20)
