@@ -25,6 +25,7 @@ class MissionMetrics:
 
     f1_bracket: List[Tuple[float, float]]
     f1_cancelled: List[float]
+    f1_counts_log: List[Tuple[Tuple[int, int, int], Tuple[int, int, int]]]   # per evaluation: (tp, fp, fn) at log-odds > +1e-5 / > -1e-5
 
     def _f1_counts(self, map_tensor: torch.Tensor, threshold: float = 0.0):
         env = self.mapping.engine.env
@@ -51,6 +52,11 @@ class MissionMetrics:
         if getattr(self, "f1_cancelled", None) is None:
             self.f1_cancelled = []
         self.f1_bracket.append((f1_of(tp_s, fp_l, fn_s), f1_of(tp_l, fp_s, fn_l)))
+        # the same two counts over the map as it is (never-observed cells included): integers that do not depend on rounding --
+        # every cell but the exactly-cancelled ones is at least one measurement's log-odds away from 0
+        if getattr(self, "f1_counts_log", None) is None:
+            self.f1_counts_log = []
+        self.f1_counts_log.append((self._f1_counts(m, 1e-5), self._f1_counts(m, -1e-5)))
         # cells within 1e-5 of p = 0.5 in log-odds (their class is rounding noise), as a share of the target cells
         self.f1_cancelled.append(((tp_l - tp_s) + (fp_l - fp_s)) / max(target, 1))
         return float(ent[0]) / target, f1_of(*self._f1_counts(m, 0.0))

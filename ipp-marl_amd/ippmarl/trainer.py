@@ -291,12 +291,21 @@ class COMATrainer:
         glob = env.glob if glob is None else glob
         ent = torch.zeros(self.E, dtype=torch.float64, device=self.device)
         env.ctx.call("ippm_weighted_entropy", env._p(glob), env._p(env.truth), 1, _ffi.ptr(ent), self.E, env.stream)
-        counts = torch.zeros(self.E, 3, dtype=torch.int64, device=self.device)
-        env.ctx.call("ippm_f1_counts", env._p(glob), env._p(env.truth), 1, 0.0, _ffi.ptr(counts), self.E, env.stream)
+        counts = self.f1_counts(glob, 0.0)
         tp, fp, fn = counts[:, 0].double(), counts[:, 1].double(), counts[:, 2].double()
         target = (tp + fn).clamp_min(1)
         f1 = torch.where(2 * tp + fp + fn > 0, 2 * tp / (2 * tp + fp + fn).clamp_min(1), torch.zeros_like(tp))
         return ent / target, f1
+
+    def f1_counts(self, glob: Optional[torch.Tensor] = None, logodds_threshold: float = 0.0) -> torch.Tensor:
+        """int64 [E,3] = (tp, fp, fn) of the target class for maps thresholded at log-odds > ``logodds_threshold`` (0 <=> the
+        reference's p > 0.5, utils/utils.py:64-76).  Thresholds +-1e-5 leave out / take in the exactly-cancelled cells, whose class
+        is rounding noise in the reference: the counts under those two are exact integers."""
+        env = self.env
+        glob = env.glob if glob is None else glob
+        counts = torch.zeros(self.E, 3, dtype=torch.int64, device=self.device)
+        env.ctx.call("ippm_f1_counts", env._p(glob), env._p(env.truth), 1, float(logodds_threshold), _ffi.ptr(counts), self.E, env.stream)
+        return counts
 
     def global_map_with_pending(self) -> torch.Tensor:
         """The global maps with the measurements of the CURRENT positions fused in, as log-odds [E,gx,gy], without touching
@@ -310,16 +319,23 @@ class COMATrainer:
                      _ffi.ptr(sums), _ffi.ptr(reward), self.E, env.stream)
         return glob
 
-    def evaluate(self, waves: int = 1) -> Dict[str, object]:
+    def evaluate(self, waves: int = 1, counts_log: Optional[list] = None) -> Dict[str, object]:
         """Greedy (argmax) deployment of the current actor, the reference's coma_test loop for E envs at once: mean return and
         the per-step curves of target entropy and F1.  Index 0 = the prior map, index t+1 = the map holding every
-        measurement up to and including the sensing of step t (coma_test.py:84-97,150-196)."""
+        measurement up to and including the sensing of step t (coma_test.py:84-97,150-196).  ``counts_log`` (a list) receives, per
+        scored map, the pair of int64 [E,3] count tensors of f1_counts at log-odds thresholds +1e-5 and -1e-5."""
         returns, ent_curves, f1_curves = [], [], []
+
+        def log_counts(glob=None):
+            if counts_log is not None:
+                counts_log.append((self.f1_counts(glob, 1e-5).cpu(), self.f1_counts(glob, -1e-5).cpu()))
+
         for _ in range(waves):
             env = self.env
             eps_ids = episode_ids(self.first_episode, self.wave, self.E, self.rank, self.world)
             env.reset(eps_ids)
             e0, f0 = self.map_metrics()   # reset senses at the start cells, the global map is still the prior
+            log_counts()
             ents, f1s = [e0.mean().item()], [f0.mean().item()]
             ret = torch.zeros(self.E, device=self.device)
             for t in range(self.T):
@@ -328,7 +344,9 @@ class COMATrainer:
                     probs, _ = self.actor(obs.view(self.E * self.N, 11, 11, 7), self.eps)
                 reward, _, _ = env.steps(t, policy=POLICY_ARGMAX, probs=probs.view(self.E, self.N, self.A))
                 ret += reward[:, 0]
-                e, f = self.map_metrics(self.global_map_with_pending())
+                pending = self.global_map_with_pending()
+                e, f = self.map_metrics(pending)
+                log_counts(pending)
                 ents.append(e.mean().item())
                 f1s.append(f.mean().item())
             self.wave += 1

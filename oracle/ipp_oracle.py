@@ -896,8 +896,40 @@ def target_entropy(d: Derived, gmap: np.ndarray, truth: np.ndarray) -> float:
     return float(np.sum(masked) / counts[-1])
 
 
+# Cells whose observations cancel exactly sit at p = 0.5 +- rounding noise (|log-odds| < 1e-7), and which side of the threshold
+# they fall on is decided by the last bit of whoever computed them.  Every other cell is DECIDABLE: at least one measurement's
+# log-odds (>= 0.5) away from 0.  The counts under the two thresholds +-1e-5 in log-odds separate the two kinds, and are integers
+# that any correct implementation must reproduce exactly (the device's ippm_f1_counts takes the same threshold).
+F1_DECIDABLE_LOGODDS = 1e-5
+_F1_COUNTS_LOG = None
+
+
+def f1_counts(gmap: np.ndarray, truth: np.ndarray, logodds_thr: float = 0.0):
+    """(tp, fp, fn) of class 1 for the map thresholded at log-odds > logodds_thr (0 <=> p > 0.5: utils/utils.py:64-76)."""
+    p = np.asarray(gmap, dtype=np.float64)
+    with np.errstate(divide="ignore"):
+        pred = (np.log(p) - np.log1p(-p)) > logodds_thr
+    t = np.asarray(truth) == 1
+    return int(np.sum(pred & t)), int(np.sum(pred & ~t)), int(np.sum(~pred & t))
+
+
+class record_f1_counts:
+    """``with record_f1_counts() as log:`` -- every f1_target() evaluated inside appends ((tp, fp, fn) at +1e-5, (tp, fp, fn) at -1e-5)."""
+
+    def __enter__(self):
+        global _F1_COUNTS_LOG
+        self._saved, _F1_COUNTS_LOG = _F1_COUNTS_LOG, []
+        return _F1_COUNTS_LOG
+
+    def __exit__(self, *exc):
+        global _F1_COUNTS_LOG
+        _F1_COUNTS_LOG = self._saved
+
+
 def f1_target(gmap: np.ndarray, truth: np.ndarray) -> float:
     """F1 of class 1 of the map thresholded at 0.5 (utils/utils.py:64-76, sklearn f1_score(average=None)[1])."""
+    if _F1_COUNTS_LOG is not None:
+        _F1_COUNTS_LOG.append((f1_counts(gmap, truth, F1_DECIDABLE_LOGODDS), f1_counts(gmap, truth, -F1_DECIDABLE_LOGODDS)))
     pred = gmap > 0.5
     t = truth == 1
     tp, fp, fn = np.sum(pred & t), np.sum(pred & ~t), np.sum(~pred & t)

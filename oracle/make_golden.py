@@ -363,7 +363,7 @@ class Recorder:
         np.random.random_sample = self._rs
 
 
-def run_reference_episode(p, episode, tag, mode="train"):
+def run_reference_episode(p, episode, tag, mode="train", snapshots=True):
     torch.manual_seed(1234 + episode)
     np.random.seed(4321 + episode)
     wrapper = COMAWrapper(p, None)
@@ -413,9 +413,11 @@ def run_reference_episode(p, episode, tag, mode="train"):
         corr_packed=np.concatenate(packed), corr_lens=lens,
         comm_draws=np.array(rec.comm), sampled_actions=np.array(rec.actions, dtype=np.int32),
         final_local=np.array([np.asarray(a.local_map, dtype=np.float32) for a in agents]),
-        final_global=gmaps[-1], global_t0=gmaps[0], global_t7=gmaps[7],
+        final_global=gmaps[-1],
         eps=np.array(ret[7]),
     )
+    if snapshots:   # (left out at 493 x 493 to keep the fixture small)
+        arrays.update(global_t0=gmaps[0], global_t7=gmaps[7])
     save(tag, **arrays)
 
 
@@ -426,6 +428,12 @@ def gen_episodes():
                           "episode_small27_e6")
     run_reference_episode(make_params("small", experiment__missions__n_agents=5, experiment__uav__communication_range=15), 3,
                           "episode_small5_e3", mode="eval")
+
+
+def gen_episode_default_grid():
+    """One episode at the reference's own default grid (493 x 493: the only BASELINE-relevant grid whose 11 feature bins are
+    not whole cells wide), 2 UAVs as BASELINE config 1: pins the assembled actor / critic planes there."""
+    run_reference_episode(make_params("c1"), 2, "episode_default_e2", snapshots=False)
 
 
 # ------------------------------------------------------------------ 12: TD(lambda)
@@ -579,7 +587,7 @@ def gen_missions():
 
 
 GENERATORS = [gen_derived_and_footprints, gen_start_states, gen_truth, gen_terrain, gen_masks, gen_comm, gen_bayes_measurement,
-              gen_entropy_reward, gen_episodes, gen_td_lambda, gen_coma_step, gen_ig_baseline, gen_missions]
+              gen_entropy_reward, gen_episodes, gen_episode_default_grid, gen_td_lambda, gen_coma_step, gen_ig_baseline, gen_missions]
 
 if __name__ == "__main__":
     check_schema()

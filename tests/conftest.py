@@ -52,8 +52,11 @@ def unpack_correctness(fx):
 # of the same size in p.  No other arithmetic reproduces that noise.  Found by replaying every recorded episode through the
 # oracle in exact-float64 mode (tests/test_oracle_golden.py::test_exact_mode_differs_only_by_reference_quantisation): one map
 # cell, (6, 81) of episode_small5_e3, at 2.45e-5 -- in the global map and in the two local maps that received it; every other
-# cell of every recording is within 1e-5.
+# cell of every recording is within 1e-5.  The 493 x 493 recording (episode_default_e2, added in round 4) has two such cells, at
+# 1.03e-5 .. 1.27e-5.
 REFERENCE_QUANTISATION_CELLS = {
+    ("episode_default_e2", "final_local"): [(1, 487, 373), (1, 490, 367)],
+    ("episode_default_e2", "final_global"): [(487, 373)],
     ("episode_small5_e3", "final_local"): [(1, 6, 81), (3, 6, 81)],
     ("episode_small5_e3", "final_global"): [(6, 81)],
 }

@@ -201,7 +201,20 @@ def test_ig_baseline_replays_reference_run(golden, tag, monkeypatch):
     # bracketed: every such cell in the wrong class <= reference <= every such cell in the right class.
     assert f1s[0] == fx["f1"][0] == 0.0
     _check_f1_brackets(ig, fx)
+    from test_oracle_golden import oracle_ig_run
+    _check_f1_counts(ig, oracle_ig_run(fx, tag)[1])
     np.testing.assert_allclose([rel, ab], [fx["relative_return"], fx["absolute_return"]], rtol=1e-9)
+
+
+def _check_f1_counts(obj, oracle_counts):
+    """tp / fp / fn of every evaluation, AS INTEGERS, under the two thresholds that leave the exactly-cancelled cells out
+    (log-odds > +1e-5) and take them all in (> -1e-5): every other cell is at least one measurement's log-odds away from 0, so
+    these counts do not depend on anyone's rounding -- the device's must equal the oracle's (coma_test.py:177-196,
+    utils/utils.py:43-76).  The bracket above is only about the cancelled remainder."""
+    assert len(obj.f1_counts_log) == len(oracle_counts)
+    for k, (got, want) in enumerate(zip(obj.f1_counts_log, oracle_counts)):
+        assert tuple(got[0]) == tuple(want[0]), (k, "log-odds > +1e-5", got[0], want[0])
+        assert tuple(got[1]) == tuple(want[1]), (k, "log-odds > -1e-5", got[1], want[1])
 
 
 def _check_f1_brackets(obj, fx):
@@ -233,6 +246,8 @@ def test_random_baseline_replays_reference_run(golden):
     ret, entropies, f1s = rb.execute()
     assert ret == int(fx["ret"]) == 0
     _check_curves(rb, entropies, f1s, fx)
+    from test_oracle_golden import oracle_random_run
+    _check_f1_counts(rb, oracle_random_run(fx)[2])
     # without hooks: device noise, host multinomial; the curve must still be a mapping run (entropy falls, F1 rises)
     torch.manual_seed(3)
     _, ent, f1 = RandomBaseline(params, None, 7).execute()
@@ -253,6 +268,8 @@ def test_lawn_mower_replays_reference_run(golden):
     ret, entropies, f1s = lm.execute()
     assert ret == 0
     _check_curves(lm, entropies, f1s, fx)
+    from test_oracle_golden import oracle_lawnmower_run
+    _check_f1_counts(lm, oracle_lawnmower_run(fx)[2])
     # the script does not depend on n_agents (the reference needs 8 memory slots; the shared map needs one)
     _, ent2, _ = LawnMower(make_params("small", experiment__baselines__lawnmower__altitude=10), None, 2).execute()
     assert len(ent2) == 16 and ent2[-1] < 0.8
@@ -281,6 +298,8 @@ def test_coma_test_replays_reference_run(golden):
     assert np.array_equal(np.array(altitudes), fx["altitudes"])
     np.testing.assert_allclose([ret, rel], [fx["ret"], fx["relative_return"]], rtol=1e-12)
     _check_curves(ct, entropies, f1s, fx)
+    from test_oracle_golden import oracle_comatest_run
+    _check_f1_counts(ct, oracle_comatest_run(fx)[3])
     # the GPU forward + argmax picks the recorded actions by itself (float32 conv on another device: allow a rare near-tie)
     assert np.mean(np.array(ct.greedy_actions) == fx["actions"]) >= 0.9
     ct2, out2 = run(False)

@@ -185,6 +185,10 @@ def test_evaluation_metrics_match_oracle():
         want = O.f1_target(glob[e], truth[e])
         assert worst - 1e-9 <= want <= best + 1e-9 and worst - 1e-9 <= float(f1[e]) <= best + 1e-9
         assert np.array_equal(strict[e, [0, 2]].sum(), truth[e].sum())          # tp + fn = number of target cells
+        # the decidable cells AS INTEGERS: the counts under both thresholds equal those of the exported probabilities (every cell
+        # but the exactly-cancelled ones is at least one measurement's log-odds away from 0)
+        assert tuple(int(v) for v in strict[e]) == O.f1_counts(glob[e], truth[e], 1e-5), e
+        assert tuple(int(v) for v in loose[e]) == O.f1_counts(glob[e], truth[e], -1e-5), e
 
 
 def test_evaluate_scores_the_freshly_sensed_measurements():
@@ -203,8 +207,9 @@ def test_evaluate_scores_the_freshly_sensed_measurements():
             return prefs.to(obs.device).expand(obs.shape[0], -1).contiguous(), None
 
     tr.actor = Stub()
-    out = tr.evaluate(waves=1)
-    ents, f1s = [], []
+    dev_counts = []
+    out = tr.evaluate(waves=1, counts_log=dev_counts)
+    ents, f1s, want_counts = [], [], []
     for ep_no in range(first, first + E):
         holder, seen = {}, {}
 
@@ -225,19 +230,27 @@ def test_evaluate_scores_the_freshly_sensed_measurements():
 
         ep._sense = sense
         g = O.init_prior_map(ep.d)
-        ent, f1 = [O.target_entropy(ep.d, g.copy(), ep.truth)], [O.f1_target(g, ep.truth)]
-        for t in range(d.budget + 1):
-            ep.step(t)
-            if t == 0:
-                g = O.fuse_map(ep.d, g, {i: dict(map2communicate=seen[(i, 0)]) for i in range(d.n_agents)}, None, "global")
-            g = O.fuse_map(ep.d, g, [seen[(i, t + 1)] for i in range(d.n_agents)], None, "global")
-            ent.append(O.target_entropy(ep.d, g.copy(), ep.truth))
-            f1.append(O.f1_target(g, ep.truth))
+        with O.record_f1_counts() as counts:
+            ent, f1 = [O.target_entropy(ep.d, g.copy(), ep.truth)], [O.f1_target(g, ep.truth)]
+            for t in range(d.budget + 1):
+                ep.step(t)
+                if t == 0:
+                    g = O.fuse_map(ep.d, g, {i: dict(map2communicate=seen[(i, 0)]) for i in range(d.n_agents)}, None, "global")
+                g = O.fuse_map(ep.d, g, [seen[(i, t + 1)] for i in range(d.n_agents)], None, "global")
+                ent.append(O.target_entropy(ep.d, g.copy(), ep.truth))
+                f1.append(O.f1_target(g, ep.truth))
         ents.append(ent)
         f1s.append(f1)
+        want_counts.append(counts)
     np.testing.assert_allclose(out["target_entropy"], np.mean(ents, axis=0), rtol=1e-5)
     # F1 thresholds at p > 0.5: exactly-cancelled cells are rounding noise on either side
     np.testing.assert_allclose(out["f1"], np.mean(f1s, axis=0), atol=0.05)
+    # ... and the decidable cells as integers: (tp, fp, fn) of every scored map of every env under the thresholds +-1e-5
+    assert len(dev_counts) == d.budget + 2
+    for k, (strict, lax) in enumerate(dev_counts):
+        for e in range(E):
+            assert tuple(strict[e].tolist()) == want_counts[e][k][0], (k, e, "log-odds > +1e-5")
+            assert tuple(lax[e].tolist()) == want_counts[e][k][1], (k, e, "log-odds > -1e-5")
     assert abs(out["f1"][-1] - np.mean(f1s, axis=0)[-1]) < 0.05 and out["f1"][1] > 0
 
 
@@ -411,6 +424,14 @@ def test_recorded_round_equals_eager_round():
         torch.manual_seed(12)
         tr.rollout("train")
         tr.update()
+    # The first update leaves the three weight sets different in their last bits (float atomics in the gradient kernels), and a
+    # sampled action can sit on an inverse-CDF boundary: the rollouts are compared from IDENTICAL weights (copied in place: the
+    # graphs hold the parameters' addresses), so that "the same actions" is a statement about the replay and not about luck.
+    with torch.no_grad():
+        for tr in (eager2, rec):
+            for net in ("actor", "critic"):
+                for p_dst, p_src in zip(getattr(tr, net).parameters(), getattr(eager, net).parameters()):
+                    p_dst.copy_(p_src)
     rec.capture_graphs()
 
     def flat(net):

@@ -135,6 +135,8 @@ EPISODES = {
     "episode_small27_e6": dict(name="small", over=dict(experiment__missions__n_agents=3, experiment__uav__fix_range=False,
                                                        experiment__uav__failure_rate=0.3, experiment__constraints__num_actions=27)),
     "episode_small5_e3": dict(name="small", over=dict(experiment__missions__n_agents=5, experiment__uav__communication_range=15)),
+    # the reference's default grid, 493 x 493 (11 feature bins that are not whole cells wide), 2 UAVs = BASELINE config 1's team
+    "episode_default_e2": dict(name="c1", over={}),
 }
 
 
@@ -171,8 +173,9 @@ def test_full_episode_replay(golden, tag):
     np.testing.assert_allclose(sum(r["absolute_reward"] for r in log), fx["abs_return"], rtol=RTOL)
     np.testing.assert_allclose(np.array([a["local_map"] for a in ep.agents]), fx["final_local"], rtol=RTOL)
     np.testing.assert_allclose(ep.global_map, fx["final_global"], rtol=RTOL)
-    np.testing.assert_allclose(log[0]["global_map"], fx["global_t0"], rtol=RTOL)
-    np.testing.assert_allclose(log[7]["global_map"], fx["global_t7"], rtol=RTOL)
+    if "global_t0" in fx:   # (the 493 x 493 fixture keeps only the final maps)
+        np.testing.assert_allclose(log[0]["global_map"], fx["global_t0"], rtol=RTOL)
+        np.testing.assert_allclose(log[7]["global_map"], fx["global_t7"], rtol=RTOL)
 
 
 def test_td_lambda(golden):
@@ -225,23 +228,30 @@ def test_exact_mode_differs_only_by_reference_quantisation(golden, tag):
 IG_CASES = {"ig_c1_e1": dict(name="c1", over={}), "ig_small3_e4": dict(name="small", over=dict(experiment__missions__n_agents=3))}
 
 
-@pytest.mark.parametrize("tag", list(IG_CASES))
-def test_ig_baseline_replay(golden, tag):
-    """BASELINE config 1 (2 UAVs, default 493 x 493 grid, greedy information-gain planner on the CPU) and a smaller case:
-    the oracle's IG_baseline restatement against the reference's own run (SURVEY Q18 known answers)."""
-    fx = golden(tag)
+def oracle_ig_run(fx, tag):
+    """The oracle's IG_baseline rerun from the draws the reference recorded: (execute()'s dict, the decidable F1 counts per evaluation)."""
     params = make_params(IG_CASES[tag]["name"], **IG_CASES[tag]["over"])
     n = params["experiment"]["missions"]["n_agents"]
     corr = unpack_correctness(fx)
     comm = fx["comm_draws"]
-    stage_of = {}
 
     def correctness(i, s, shape):
         # the reference draws in call order: n start sensings, then n per step
         return corr[s * n + i].reshape(shape)
 
     ig = O.OracleIGBaseline(params, int(fx["episode"]), correctness, comm_draw=lambda i, j, t: comm[(t * n + i) * n + j])
-    out = ig.execute()
+    with O.record_f1_counts() as counts:
+        out = ig.execute()
+    return out, counts
+
+
+@pytest.mark.parametrize("tag", list(IG_CASES))
+def test_ig_baseline_replay(golden, tag):
+    """BASELINE config 1 (2 UAVs, default 493 x 493 grid, greedy information-gain planner on the CPU) and a smaller case:
+    the oracle's IG_baseline restatement against the reference's own run (SURVEY Q18 known answers)."""
+    fx = golden(tag)
+    out, counts = oracle_ig_run(fx, tag)
+    _check_counts_bracket_recorded_f1(counts, fx["f1"])
     assert np.array_equal(np.array(out["altitudes"]), fx["altitudes"])
     np.testing.assert_allclose(np.array(out["gains"]), fx["gains"], rtol=RTOL, atol=1e-12)
     np.testing.assert_allclose(out["entropies"], fx["entropies"], rtol=RTOL)
@@ -261,9 +271,19 @@ def _unpack(fx):
     return unpack_correctness(fx)
 
 
-def test_random_baseline_curves(golden):
-    """random_baseline.py rerun by the oracle from the recorded draws (start cells from the legacy seed rule)."""
-    fx = golden("random_small3_e6")
+def _check_counts_bracket_recorded_f1(counts, recorded):
+    """The decidable counts (thresholds +-1e-5 in log-odds) bracket the F1 the reference recorded: strict tp with lax fp is the
+    lowest attainable score, lax tp with strict fp the highest; and tp + fn is the number of target cells under either."""
+    assert len(counts) == len(recorded)
+    for (s, l), want in zip(counts, recorded):
+        assert s[0] + s[2] == l[0] + l[2] and s[0] <= l[0] and s[1] <= l[1]
+        lo = 2 * s[0] / max(2 * s[0] + l[1] + s[2], 1)
+        hi = 2 * l[0] / max(2 * l[0] + s[1] + l[2], 1)
+        assert lo - 1e-12 <= want <= hi + 1e-12, (lo, want, hi)
+
+
+def oracle_random_run(fx):
+    """random_baseline.py rerun by the oracle from the recorded draws: (entropies, f1s, decidable F1 counts per evaluation)."""
     params = make_params("small", experiment__missions__n_agents=3)
     d = O.Derived(params)
     n, corr, ep = 3, _unpack(fx), int(fx["episode"])
@@ -276,30 +296,52 @@ def test_random_baseline_curves(golden):
             assert O.action_mask(d, pos[i])[a] == 1
             pos[i] = O.action_to_position(d, pos[i], a)
         visits.append([p.copy() for p in pos])
-    ent, f1 = O.shared_map_curves(d, truth, visits, lambda k: corr[k])
+    with O.record_f1_counts() as counts:
+        ent, f1 = O.shared_map_curves(d, truth, visits, lambda k: corr[k])
+    return ent, f1, counts
+
+
+def test_random_baseline_curves(golden):
+    """random_baseline.py rerun by the oracle from the recorded draws (start cells from the legacy seed rule)."""
+    fx = golden("random_small3_e6")
+    ent, f1, counts = oracle_random_run(fx)
     np.testing.assert_allclose(ent, fx["entropies"], rtol=1e-6)
     np.testing.assert_allclose(f1, fx["f1"], rtol=1e-9)   # incl. the exactly-cancelled cells (same float32 rounding noise)
+    _check_counts_bracket_recorded_f1(counts, fx["f1"])
 
 
-def test_lawn_mower_curves(golden):
-    fx = golden("lawnmower_small_e2")
+def oracle_lawnmower_run(fx):
     params = make_params("small", experiment__missions__n_agents=8, experiment__baselines__lawnmower__altitude=10)
     d = O.Derived(params)
     corr = _unpack(fx)
     paths = O.lawnmower_paths(10)
     visits = [[p[idx] for p in paths] for idx in range(15)]
-    ent, f1 = O.shared_map_curves(d, O.make_truth(d, int(fx["episode"])), visits, lambda k: corr[k])
+    with O.record_f1_counts() as counts:
+        ent, f1 = O.shared_map_curves(d, O.make_truth(d, int(fx["episode"])), visits, lambda k: corr[k])
+    return ent, f1, counts
+
+
+def test_lawn_mower_curves(golden):
+    fx = golden("lawnmower_small_e2")
+    ent, f1, counts = oracle_lawnmower_run(fx)
     np.testing.assert_allclose(ent, fx["entropies"], rtol=1e-6)
     np.testing.assert_allclose(f1, fx["f1"], rtol=1e-9)
+    _check_counts_bracket_recorded_f1(counts, fx["f1"])
+
+
+def oracle_comatest_run(fx):
+    params = make_params("small", experiment__missions__n_agents=3)
+    n, corr = 3, _unpack(fx)
+    with O.record_f1_counts() as counts:
+        ent, f1, stages = O.deployment_curves(params, int(fx["episode"]), lambda t, i: int(fx["actions"][t * n + i]),
+                                              lambda s, i: corr[s * n + i])
+    return ent, f1, stages, counts
 
 
 def test_coma_test_curves(golden):
     fx = golden("comatest_small3_e9")
-    params = make_params("small", experiment__missions__n_agents=3)
-    d = O.Derived(params)
-    n, corr = 3, _unpack(fx)
-    ent, f1, stages = O.deployment_curves(params, int(fx["episode"]), lambda t, i: int(fx["actions"][t * n + i]),
-                                          lambda s, i: corr[s * n + i])
+    ent, f1, stages, counts = oracle_comatest_run(fx)
+    _check_counts_bracket_recorded_f1(counts, fx["f1"])
     assert np.array_equal(stages, fx["positions"])
     np.testing.assert_allclose(ent, fx["entropies"], rtol=1e-6)
     np.testing.assert_allclose(f1, fx["f1"], rtol=1e-9)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Randomised sweep of the Philox-mode parity check (tests/test_hip_env_parity.py::test_production_randomness_matches_oracle):
+"""Randomised sweep of the Philox-mode parity check (tests/test_hip_env_parity.py::check_philox_episodes):
 random team sizes, action sets, comm ranges, link-failure rates, seeds and episodes on the 128 x 128 and 256 x 256 grids; every
 step of every episode against the oracle.  python tools/stress_parity.py [n_cases] [rng_seed]"""
 import os
@@ -10,7 +10,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for sub in ("tests", "oracle", "ipp-marl_amd"):
     sys.path.insert(0, os.path.join(ROOT, sub))
-from test_hip_env_parity import test_production_randomness_matches_oracle as check  # noqa: E402
+from test_hip_env_parity import check_philox_episodes as check  # noqa: E402
 from test_hip_dropin import test_batched_ig_policy_matches_oracle as check_ig  # noqa: E402
 from random_configs import random_case  # noqa: E402
 
