@@ -388,11 +388,6 @@ int ippm_host_philox(const uint32_t* ctr_key6, uint32_t* out4);           /* Phi
 int ippm_host_start_state(int32_t env_seed, int64_t episode, int32_t agent, int32_t spacing, int32_t space_x,
                           int32_t space_y, int32_t* out3);                /* state_space.py:28-51 */
 int ippm_host_truth_params(int64_t episode, int32_t* out2);               /* ground_truths.py:43-48 */
-/* The table the tile fusion's reward terms read their entropies from (utils/state.py:118-121 as a function of
- * a = min(|log-odds|, logit_clip)): coeff4 float [256][4] = per interval [k/16, (k+1)/16) the monomial coefficients in
- * t = 16 a - k of a cubic fitted in float64; *n_out = intervals in use.  <0 when logit_clip needs more than 256 intervals
- * (the kernel then evaluates exp / log2 directly). */
-int ippm_host_entropy_table(float logit_clip, float* coeff4, int32_t* n_out);
 
 #ifdef __cplusplus
 }

@@ -60,15 +60,6 @@ extern "C" int ippm_host_truth_params(int64_t episode, int32_t* out2) {
   return 0;
 }
 
-extern "C" int ippm_host_entropy_table(float logit_clip, float* coeff4, int32_t* n_out) {
-  if (!coeff4 || !n_out) { ippm_set_error("ippm_host_entropy_table: null argument"); return -1; }
-  int n = 0;
-  const int rc = ippm_entropy_table(logit_clip, coeff4, &n);
-  *n_out = n;
-  if (rc) ippm_set_error("ippm_host_entropy_table: logit_clip outside the table's range");
-  return rc;
-}
-
 extern "C" int ippm_ctx_create(const ippm_config* cfg, ippm_ctx** out) {
   if (!cfg || !out) { ippm_set_error("ippm_ctx_create: null argument"); return -1; }
   const ippm_config& c = *cfg;
@@ -103,21 +94,11 @@ extern "C" int ippm_ctx_create(const ippm_config* cfg, ippm_ctx** out) {
   ctx->knob_split = knob("IPPM_FUSE_SPLIT", 0);
   ctx->knob_tile_waves = knob("IPPM_TILE_WAVES", 0);
   ctx->knob_plan_builders = knob("IPPM_PLAN_BUILDERS", 0);
-  ctx->knob_no_htab = knob("IPPM_NO_HTAB", 0);   // A/B: the tile fusion's entropies from exp / log2 / rcp instead of the LDS table
   ctx->tiles = (ctx->vec == 4 && c.logit_prior == 0.f && c.grid_x < 32768 && c.grid_y <= 1024 && !knob("IPPM_NO_TILES", 0)) ? 1 : 0;
   int rc = ippm_check_hip(hipMalloc(&ctx->dcfg, sizeof(ippm_config)), "hipMalloc(cfg)");
   if (!rc) rc = ippm_check_hip(hipMemcpy(ctx->dcfg, cfg, sizeof(ippm_config), hipMemcpyHostToDevice), "hipMemcpy(cfg)");
   if (!rc) rc = ippm_check_hip(hipMalloc(&ctx->dcounters, IPPM_COUNTER_SLOTS * 8 * sizeof(unsigned long long)), "hipMalloc(counters)");
   if (!rc) rc = ippm_check_hip(hipMemset(ctx->dcounters, 0, IPPM_COUNTER_SLOTS * 8 * sizeof(unsigned long long)), "hipMemset(counters)");
-  if (!rc) {   // the entropy table of the tile fusion (a few KB, read by every wavefront of that kernel into LDS)
-    std::vector<float> tab((size_t)IPPM_HTAB_MAX * 4);
-    if (ippm_entropy_table(c.logit_clip, tab.data(), &ctx->htab_n) == 0) {
-      rc = ippm_check_hip(hipMalloc(&ctx->d_htab, sizeof(float) * 4 * IPPM_HTAB_MAX), "hipMalloc(htab)");
-      if (!rc) rc = ippm_check_hip(hipMemcpy(ctx->d_htab, tab.data(), sizeof(float) * 4 * IPPM_HTAB_MAX, hipMemcpyHostToDevice), "hipMemcpy(htab)");
-    } else {
-      ctx->htab_n = 0;   // a clip bound beyond the table's reach: the tile fusion evaluates the entropies directly
-    }
-  }
   if (rc) { ippm_ctx_destroy(ctx); return rc; }
   *out = ctx;
   return 0;
@@ -127,7 +108,6 @@ extern "C" int ippm_ctx_destroy(ippm_ctx* ctx) {
   if (!ctx) return 0;
   if (ctx->dcfg) (void)hipFree(ctx->dcfg);
   if (ctx->dcounters) (void)hipFree(ctx->dcounters);
-  if (ctx->d_htab) (void)hipFree(ctx->d_htab);
   for (int k = 0; k < IPPM_TIMED_CLASSES; ++k) {
     for (int i = 0; i < 2 * ctx->ev_made[k]; ++i) (void)hipEventDestroy(ctx->ev[k][i]);
     delete[] ctx->ev[k];

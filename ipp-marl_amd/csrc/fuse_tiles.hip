@@ -18,7 +18,6 @@
 // then the ordered clamp/add chain in registers and one store per slot.  Nothing is carried from item to item except the
 // wavefront's reward and counter sums, so register use is that of one item and the launch is many short independent chains.
 #include <algorithm>
-#include <cmath>
 
 #include "ippm_tiles.h"
 
@@ -30,55 +29,7 @@ typedef unsigned ippm_t_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int t_lane_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ float t_lane_f(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 
-// ---- H(|L|) from a table -------------------------------------------------------------------------------------------
-// The reward terms need the entropy of every changed global cell before and after the fusion: 8 evaluations per lane-load, each
-// exp + log2 + rcp on the quarter-rate unit (ippm_entropy_l: ~76 issue cycles) -- 40 % of this kernel's VALU time, and the kernel
-// is issue-bound.  H is a smooth function of a = min(|L|, lc) on [0, lc]: per interval of 1/16 a cubic through the four Chebyshev
-// nodes of the interval (float64 fit on the host; interpolation error <= max|d4H/da4| h^4 / 3072 < 1e-9, below the float32
-// rounding of the evaluation itself), coefficients as one float4 in LDS: 2 VALU for a * 16, v_fract + v_cvt + shift for
-// (t, index), one ds_read_b128, 3 FMA -- ~32 issue cycles and an LDS read on a unit this kernel does not otherwise use.
-__host__ static double htab_entropy(double a) {
-  const double e = std::exp(-a), d = 1.0 + e;
-  return std::log2(d) + a * 1.4426950408889634 * (e / d);
-}
-int ippm_entropy_table(float logit_clip, float* coeff4, int* n_out) {
-  const double lc = (double)logit_clip;
-  const int n = (int)std::floor(lc * IPPM_HTAB_PER_UNIT) + 1;
-  if (!(lc > 0.0) || n > IPPM_HTAB_MAX) return -1;
-  const double h = 1.0 / IPPM_HTAB_PER_UNIT;
-  for (int k = 0; k < IPPM_HTAB_MAX; ++k) {
-    double A[4][5];
-    for (int i = 0; i < 4; ++i) {
-      const double t = 0.5 + 0.5 * std::cos((2 * i + 1) * M_PI / 8.0);
-      A[i][0] = 1.0; A[i][1] = t; A[i][2] = t * t; A[i][3] = t * t * t;
-      A[i][4] = htab_entropy((k + t) * h);
-    }
-    for (int c = 0; c < 4; ++c) {   // Gauss-Jordan with partial pivoting on the 4 x 4 Vandermonde system
-      int piv = c;
-      for (int r = c + 1; r < 4; ++r) if (std::fabs(A[r][c]) > std::fabs(A[piv][c])) piv = r;
-      for (int j = 0; j < 5; ++j) std::swap(A[c][j], A[piv][j]);
-      for (int r = 0; r < 4; ++r) {
-        if (r == c) continue;
-        const double f = A[r][c] / A[c][c];
-        for (int j = c; j < 5; ++j) A[r][j] -= f * A[c][j];
-      }
-    }
-    for (int c = 0; c < 4; ++c) coeff4[k * 4 + c] = k < n ? (float)(A[c][4] / A[c][c]) : 0.f;
-  }
-  *n_out = n;
-  return 0;
-}
-// a16 = min(|L|, lc) * 16 -> H.  (index < the table's length by construction: a16 <= lc * 16 < n)
-__device__ __forceinline__ float tile_entropy_tab(const float4* __restrict__ tab, float l, float lc16) {
-  const float a16 = fminf(fabsf(l) * (float)IPPM_HTAB_PER_UNIT, lc16);
-  const float t = __builtin_amdgcn_fractf(a16);
-  const float4 c = tab[(int)a16];
-  return fmaf(fmaf(fmaf(c.w, t, c.z), t, c.y), t, c.x);
-}
-
 struct TileCtx {
-  const float4* htab;   // LDS
-  float lc16;
   float* local;
   float* global;
   const uint8_t* code;
@@ -98,7 +49,7 @@ struct TileAcc {   // per wavefront, over all its items (all of one env)
 };
 
 // One item with at most NA ops (spare slots first) and SLOTS loads in flight per lane.
-template <int NA, int SLOTS, bool MIS, bool TAB>
+template <int NA, int SLOTS, bool MIS>
 __device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e, int slot, int x0, int nr, int g0, int W, unsigned active) {
   const int map_abs = e * (w.n + 1) + slot;
   const bool is_global = slot == w.n;
@@ -262,8 +213,7 @@ __device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e,
         float s1 = 0.f, sD = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float hb = TAB ? tile_entropy_tab(w.htab, mv[q].v[j], w.lc16) : ippm_entropy_l(mv[q].v[j], w.lc);
-          const float ha = TAB ? tile_entropy_tab(w.htab, out[j], w.lc16) : ippm_entropy_l(out[j], w.lc);
+          const float hb = ippm_entropy_l(mv[q].v[j], w.lc), ha = ippm_entropy_l(out[j], w.lc);
           s1 += wa[j] * (hb - ha);
           sD += (wa[j] - wb[j]) * hb;
         }
@@ -283,12 +233,12 @@ __device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e,
 #ifndef IPPM_TILE_WAVES_PER_EU
 #define IPPM_TILE_WAVES_PER_EU 5
 #endif
-template <int NAMAX, bool MIS, bool TAB>
+template <int NAMAX, bool MIS>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NAMAX <= 6 && !MIS ? 6 : IPPM_TILE_WAVES_PER_EU, 8)))
 k_fuse_tiles(const int32_t* __restrict__ work, int n_envs, int env_cap, int n, int gx, int gy, int row_bytes, int TB, float lc, float wt,
              const int32_t* __restrict__ plan_ro, float* __restrict__ local, float* __restrict__ global,
              const uint8_t* __restrict__ code, int32_t* __restrict__ ws, double* __restrict__ sums,
-             unsigned long long* __restrict__ counters, const float4* __restrict__ htab_g, int htab_n) {
+             unsigned long long* __restrict__ counters) {
   // (argument order = latency order, as in k_sense_tiles: the work list's address and sizes arrive in SGPRs with the wavefront,
   // every config scalar by value -- the count and the first item are one scalar round trip away, the first item's cells two)
   const int env = blockIdx.x, first = blockIdx.y, step = gridDim.y;   // consecutive workgroups = consecutive envs
@@ -306,15 +256,7 @@ k_fuse_tiles(const int32_t* __restrict__ work, int n_envs, int env_cap, int n, i
   }
   const int count = tag & IPPM_WORK_COUNT;
   if (first >= count) return;
-  // the entropy table into LDS (a workgroup is one wavefront; the copy travels beside the first item's loads)
-  __shared__ float4 s_htab[TAB ? IPPM_HTAB_MAX : 1];
-  if (TAB) {
-    for (int k = lane; k < htab_n; k += 64) s_htab[k] = htab_g[k];
-    __syncthreads();
-  }
   TileCtx w;
-  w.htab = s_htab;
-  w.lc16 = lc * (float)IPPM_HTAB_PER_UNIT;
   w.local = local; w.global = global; w.code = code; w.plan = plan_ro; w.ws = ws;
   w.n = n; w.gx = gx; w.gy = gy;
   w.row_bytes = row_bytes;
@@ -330,15 +272,15 @@ k_fuse_tiles(const int32_t* __restrict__ work, int n_envs, int env_cap, int n, i
     const int slot = (unsigned)it.w >> 24, x0 = it.y & 0xFFFF, nr = it.y >> 16, g0 = it.z & 0xFFFF, W = it.z >> 16;
     const unsigned active = (unsigned)it.w & 0x00FFFFFFu;
     const int na = __popc(active);
-    if (na == 1) tile_item<1, 4, MIS, TAB>(w, acc, env, slot, x0, nr, g0, W, active);
-    else if (na == 2) tile_item<2, 4, MIS, TAB>(w, acc, env, slot, x0, nr, g0, W, active);
-    else if (na == 3) tile_item<3, 4, MIS, TAB>(w, acc, env, slot, x0, nr, g0, W, active);
-    else if (na == 4) tile_item<4, 4, MIS, TAB>(w, acc, env, slot, x0, nr, g0, W, active);
-    else if (NAMAX <= 6 || na <= 6) tile_item<(NAMAX < 6 ? NAMAX : 6), IPPM_TILE_SLOTS_MID, MIS, TAB>(w, acc, env, slot, x0, nr, g0, W, active);
-    else if (na <= 8) tile_item<8, IPPM_TILE_SLOTS_MID, MIS, TAB>(w, acc, env, slot, x0, nr, g0, W, active);
-    else if (NAMAX <= 10 || na <= 10) tile_item<10, 2, MIS, TAB>(w, acc, env, slot, x0, nr, g0, W, active);
-    else if (na <= 14) tile_item<14, 1, MIS, TAB>(w, acc, env, slot, x0, nr, g0, W, active);
-    else tile_item<18, 1, MIS, TAB>(w, acc, env, slot, x0, nr, g0, W, active);
+    if (na == 1) tile_item<1, 4, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
+    else if (na == 2) tile_item<2, 4, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
+    else if (na == 3) tile_item<3, 4, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
+    else if (na == 4) tile_item<4, 4, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
+    else if (NAMAX <= 6 || na <= 6) tile_item<(NAMAX < 6 ? NAMAX : 6), IPPM_TILE_SLOTS_MID, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
+    else if (na <= 8) tile_item<8, IPPM_TILE_SLOTS_MID, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
+    else if (NAMAX <= 10 || na <= 10) tile_item<10, 2, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
+    else if (na <= 14) tile_item<14, 1, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
+    else tile_item<18, 1, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
     it = nx;
   }
   // the wavefront's reward terms and work counters: one atomic per quantity
@@ -374,17 +316,14 @@ int ippm_launch_fuse_tiles(ippm_ctx* ctx, float* local, float* global, const uin
   // a launch smaller than the chip's wave slots leaves CUs idle: small batches take more wavefronts per env
   while ((long long)per_env * n_envs < 16384 && per_env * 2 <= env_cap && per_env < 256) per_env *= 2;
   dim3 grid((unsigned)n_envs, (unsigned)per_env), block(64);
-#define IPPM_FT_(NA, M, T) \
-  IPPM_LAUNCH(ctx, IPPM_T_FUSE, (k_fuse_tiles<NA, M, T>), grid, block, st, work, n_envs, env_cap, c.n_agents, c.grid_x, c.grid_y, c.tile_stride >> 2, \
-              (int)ippm_tile_bytes(c.tile_stride, 4), c.logit_clip, c.logit_weight_thr, ws, local, global, code, ws, sums, ctx->dcounters, ctx->d_htab, ctx->htab_n)
-#define IPPM_FT(NA, M) do { if (tab) IPPM_FT_(NA, M, true); else IPPM_FT_(NA, M, false); } while (0)
-  const bool tab = ctx->htab_n > 0 && ctx->d_htab && !ctx->knob_no_htab;
+#define IPPM_FT(NA, M) \
+  IPPM_LAUNCH(ctx, IPPM_T_FUSE, (k_fuse_tiles<NA, M>), grid, block, st, work, n_envs, env_cap, c.n_agents, c.grid_x, c.grid_y, c.tile_stride >> 2, \
+              (int)ippm_tile_bytes(c.tile_stride, 4), c.logit_clip, c.logit_weight_thr, ws, local, global, code, ws, sums, ctx->dcounters)
   const bool mis = (c.grid_y & 3) != 0;   // rows only 4-byte aligned: the instantiation with the cell-by-cell row-tail stores
   if (max_ops <= 6) { if (mis) IPPM_FT(6, true); else IPPM_FT(6, false); }
   else if (max_ops <= 10) { if (mis) IPPM_FT(10, true); else IPPM_FT(10, false); }
   else { if (mis) IPPM_FT(18, true); else IPPM_FT(18, false); }
 #undef IPPM_FT
-#undef IPPM_FT_
   IPPM_LAUNCH_CHECK("fuse_tiles");
   return 0;
 }

@@ -56,10 +56,8 @@ struct ippm_ctx {
   int vec;                   // 4: 16-byte lane groups (grid_y >= 44), else 1
   // tuning knobs, resolved ONCE at ippm_ctx_create (the work buffer's size, the plan kernel's item layout and the fusion launch
   // all derive from them and must agree for the context's lifetime)
-  int knob_wave_rows, knob_persist, knob_nowork, knob_split, knob_tile_waves, knob_plan_builders, knob_no_htab;
+  int knob_wave_rows, knob_persist, knob_nowork, knob_split, knob_tile_waves, knob_plan_builders;
   int tiles;                 // the config can take the one-trip tile form of the fusion (16-byte lane groups, prior 0.5)
-  float4* d_htab;            // entropy table of the tile fusion's reward terms (ippm_entropy_table; fuse_tiles.hip)
-  int htab_n;
   // kernel timing (ippm_kernel_timing): per kernel class a pool of event pairs attached to the dispatches themselves
   int timing;
   hipEvent_t* ev[IPPM_TIMED_CLASSES];
@@ -99,10 +97,6 @@ int ippm_launch_fuse_tiles(ippm_ctx* ctx, float* local, float* global, const uin
 #define IPPM_TILE_SLOTS_MID 2
 #endif
 __host__ __device__ inline int ippm_tile_slots(int na) { return na <= 4 ? 4 : (na <= 8 ? IPPM_TILE_SLOTS_MID : (na <= 10 ? 2 : 1)); }
-// H(|L|) as piecewise cubics in LDS (fuse_tiles.hip): IPPM_HTAB_PER_UNIT intervals per unit of log-odds over [0, logit_clip]
-#define IPPM_HTAB_PER_UNIT 16
-#define IPPM_HTAB_MAX 256
-int ippm_entropy_table(float logit_clip, float* coeff4, int* n_out);   // host: float [n][4], fuse_tiles.hip
 int ippm_launch_plan(ippm_ctx* ctx, const int32_t* rect, const int32_t* pos, const uint8_t* comm, int32_t* ws, int global_maps,
                      int n_envs, int agent_sel, hipStream_t st);
 int ippm_check_hip(hipError_t err, const char* what);

@@ -101,7 +101,6 @@ PROTOTYPES = {
     "ippm_terrain_pack": [P, P, P, P, I32, P],
     "ippm_area_weights": [I32, I32, P, P, P],
     "ippm_host_philox": [P, P],
-    "ippm_host_entropy_table": [C.c_float, P, P],
     "ippm_host_start_state": [I32, I64, I32, I32, I32, I32, P],
     "ippm_host_truth_params": [I64, P],
 }

@@ -40,6 +40,15 @@ def hot_layout(shapes, align: int = 2 << 20):
     return spans, total
 
 
+PLACEMENT_SLACK_MB = 66      # the k-th candidate of VecEnv.tune_placement asks for 66 * (k % 16) MB more than the planes need
+
+
+def placement_alive_cap(free_bytes: int, arena_bytes: int) -> int:
+    """How many candidate arenas VecEnv.tune_placement keeps allocated at once: what fits in half of the free device memory
+    (each with the largest slack), at least the arena in use and one candidate."""
+    return max(2, int(0.5 * free_bytes // (arena_bytes + ((PLACEMENT_SLACK_MB * 15) << 20))) + 1)
+
+
 class VecEnv:
     def __init__(self, params: Dict, n_envs: int, device: str = "cuda:0", philox_seed: int = 3, terrain: str = "split",
                  track_area: bool = True):
@@ -426,22 +435,48 @@ class VecEnv:
             return sum(tm[k]["avg_us"] * tm[k]["launches"] for k in ("sense", "fuse") if k in tm) / T
 
         score()                            # (the process's first episodes run 2-4 % slow whatever the allocation: not a sample)
-        scores, arenas = [score()], [self._arena]
+        # Rejected candidates stay allocated while the search runs (a released block is what the next request would get back), but
+        # never more of them than fit in HALF of the memory that is free now: beyond that the worst ones are handed back to the
+        # driver.  At config 4's per-GPU shape the arena is ~10 GB: 24 candidates would be 240 GB next to a trainer's activations.
+        _, total = hot_layout(self._hot_shapes)
+        slack = lambda k: PLACEMENT_SLACK_MB * (k % 16)    # noqa: E731  (varies the request so that no cached block fits it exactly)
+        free_b, _ = torch.cuda.mem_get_info(self.device)
+        max_alive = placement_alive_cap(free_b, total)     # (the arena in use counts as one)
+        scores, arenas = [score()], [self._arena]      # arenas[k] is None once released
+        stopped = "draws exhausted"
         for k in range(1, draws):
             # the two kinds are 7-8 % apart and each is sharp to 1 %: a candidate well below the worst seen is a good one
             if min(scores) < 0.96 * max(scores) and not os.environ.get("IPPM_PLACEMENT_NO_EARLY"):
+                stopped = "a fast allocation found"
                 break
-            self._place_hot(slack_mb=66 * (k % 16))   # (the earlier candidates stay allocated: every draw is a new block)
+            # ... and a box on which six draws in a row differ by less than 2 % has one kind only: nothing to search for
+            if k >= 6 and max(scores) < 1.02 * min(scores) and not os.environ.get("IPPM_PLACEMENT_NO_EARLY"):
+                stopped = "no spread between the first draws"
+                break
+            alive = [i for i, a in enumerate(arenas) if a is not None]
+            if len(alive) >= max_alive:    # hand the slowest candidates back (never the best one)
+                best_now = min(alive, key=scores.__getitem__)
+                drop = sorted((i for i in alive if i != best_now), key=scores.__getitem__, reverse=True)[:len(alive) - max_alive + 1]
+                self._use_arena(arenas[best_now])
+                for i in drop:
+                    arenas[i] = None
+                torch.cuda.empty_cache()
+            try:
+                self._place_hot(slack_mb=slack(k))
+            except torch.cuda.OutOfMemoryError:
+                stopped = "out of memory"
+                break
             arenas.append(self._arena)
             scores.append(score())
-        best = min(range(len(scores)), key=scores.__getitem__)
+        best = min((i for i, a in enumerate(arenas) if a is not None), key=scores.__getitem__)
         self._use_arena(arenas[best])
         del arenas
         torch.cuda.empty_cache()           # the rejected allocations go back to the driver
         self._boxes_valid = False
         self._pending_t = None
         self._obs_t = None
-        return {"draws": len(scores), "max_draws": draws, "kept": best, "map_kernels_us_per_step": [round(v, 1) for v in scores]}
+        return {"draws": len(scores), "max_draws": draws, "kept": best, "map_kernels_us_per_step": [round(v, 1) for v in scores],
+                "stopped": stopped, "max_candidates_alive": max_alive}
 
     def event_times_us(self, clear: bool = True) -> Dict[str, Dict[str, float]]:
         """{kernel class: {"launches", "avg_us", "min_us", "kernel"}} of the launches made while ``profile`` was set

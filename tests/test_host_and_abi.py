@@ -195,31 +195,3 @@ def test_hot_plane_layout_is_aligned_and_disjoint():
         end = off + n
     assert total % (2 << 20) == 0 and total >= end and total - end < (2 << 20)
 
-
-def test_entropy_table_of_the_tile_fusion():
-    """ippm_host_entropy_table: the piecewise cubics the tile fusion's reward terms read H(|L|) from (utils/state.py:118-121 in
-    log-odds) against a float64 evaluation -- evaluated exactly as the kernel evaluates it (float32 index / fraction / Horner)."""
-    import ctypes as C
-    from ippmarl import _ffi
-    lib = _ffi.load_library()
-    lc = np.float32(np.log(0.9999 / 0.0001))
-    tab = np.zeros((256, 4), dtype=np.float32)
-    n = np.zeros(1, dtype=np.int32)
-    assert lib.ippm_host_entropy_table(C.c_float(float(lc)), tab.ctypes.data, n.ctypes.data) == 0
-    assert n[0] == int(np.floor(float(lc) * 16)) + 1 == 148 and not tab[n[0]:].any()
-    rng = np.random.RandomState(5)
-    l = np.concatenate([rng.uniform(-12, 12, 400000), [0.0, 1e-7, -1e-7, float(lc), -float(lc), 100.0, np.inf, -np.inf]]).astype(np.float32)
-    a16 = np.minimum(np.abs(l) * np.float32(16), lc * np.float32(16)).astype(np.float32)
-    idx = a16.astype(np.int32)
-    assert idx.min() >= 0 and idx.max() < n[0]
-    t = (a16 - idx.astype(np.float32)).astype(np.float32)
-    c = tab[idx]
-    h = (((c[:, 3] * t + c[:, 2]).astype(np.float32) * t + c[:, 1]).astype(np.float32) * t + c[:, 0]).astype(np.float32)
-    a = np.minimum(np.abs(l.astype(np.float64)), float(lc))
-    e = np.exp(-a)
-    want = np.log2(1 + e) + a * np.log2(np.e) * e / (1 + e)
-    assert np.abs(h - want).max() < 1.5e-7          # float32 rounding of a value <= 1; the cubic itself is good to 1e-9
-    c64, t64 = c.astype(np.float64), a * 16 - idx
-    assert np.abs(((c64[:, 3] * t64 + c64[:, 2]) * t64 + c64[:, 1]) * t64 + c64[:, 0] - want)[: 400000].max() < 6.5e-8   # (the float32 rounding of the coefficients: half an ulp of 1)
-    # a clip bound the table cannot hold is refused (the kernel then evaluates exp / log2 directly)
-    assert lib.ippm_host_entropy_table(C.c_float(17.0), tab.ctypes.data, n.ctypes.data) < 0
