@@ -127,6 +127,8 @@ def main():
                     help="ground truth: the power-law random field of ground_truths.py:25-40 generated on the device, or "
                          "the half-plane split the reference flies over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-terrain-prefetch", dest="terrain_prefetch", action="store_false", help="synthesise each wave's terrain "
+                    "inside its reset instead of beside the previous wave's steps (VecEnv.prefetch_terrain)")
     ap.add_argument("--roofline-steps", type=int, default=90, help="env steps (resets included) of the roofline leg that follows "
                     "the timed region: every K3 / fusion / plan / reset launch of it carries start/stop events bound to the "
                     "dispatch itself; 0 = no roofline leg")
@@ -193,6 +195,10 @@ def main():
     def reset():
         env.reset(episode_ids(1, wave[0], E, rank, world))   # disjoint episodes per rank and wave
         wave[0] += 1
+        if args.terrain_prefetch:
+            # the next wave's terrain is synthesised on a side stream beside this wave's steps (same work, inside the same timed
+            # region: every reset of the timed loop is followed by one synthesis); the reset then copies 8 MB of packed truth
+            env.prefetch_terrain(episode_ids(1, wave[0], E, rank, world))
 
     def one_step(t):
         if args.graphs:
@@ -445,7 +451,8 @@ def main():
             "config": {"workload": ("BASELINE.json configs[1]: " if is_c1 else "NOT the metric's config (a parity-test shape): ") + shape,
                        "envs_per_gpu": E, "n_agents": N, "grid": grid,
                        "episode_steps": T, "terrain": args.terrain, "parallelism": f"env-sharded x{world} (no data-path collective)",
-                       "launches_per_step": 3, "hip_graphs": bool(args.graphs), "roofline_steps": args.roofline_steps},
+                       "launches_per_step": 3, "hip_graphs": bool(args.graphs), "roofline_steps": args.roofline_steps,
+                       "terrain_prefetch": bool(args.terrain_prefetch and args.terrain == "random_field")},
             "ranks": world,
             "collective": collective if args.train_rounds > 0 else None,
             "faults": faults,

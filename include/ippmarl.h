@@ -22,7 +22,8 @@
  *   pos       int32  [E,N,3]      UAV position in metres (x,y,z)
  *   rect      int32  [E,N,4]      clipped footprint [yu,yd,xl,xr], half-open when sliced (cameras.py:62-77)
  *   truth     uint8  [E,TRB]      ground truth, BIT-PACKED: cell (x,y) = bit (x*gy+y) of the env's little-endian bit string,
- *                                 TRB = ceil(gx*gy/32)*4 bytes
+ *                                 TRB = ceil(gx*gy/32)*4 bytes (ceil((gx*gy+8)/32)*4 when gy is not a multiple of 4: one spare byte
+ *                                 behind the last cell's, for the 2-byte loads of groups that straddle a byte)
  *   local     float  [E,N,gx,gy]  per-agent occupancy belief, stored as LOG-ODDS ln(p/(1-p)) (0 = prior 0.5);
  *   global    float  [E,gx,gy]    fused team belief, log-odds.  ippm_logodds_to_prob / ippm_prob_to_logodds
  *                                 convert at the boundary (DESIGN.md "log-odds storage")

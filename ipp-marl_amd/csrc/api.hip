@@ -76,6 +76,10 @@ extern "C" int ippm_ctx_create(const ippm_config* cfg, ippm_ctx** out) {
   for (int k = 0; k < c.space_z; ++k)
     if (2 * c.radius_x[k] > c.tile_stride || 2 * c.radius_y[k] + 3 > c.tile_stride) return bad("tile_stride too small for the footprint");
   if (c.spacing <= 0 || c.budget <= 0) return bad("spacing and budget must be positive");
+  // lattice indices come from ippm_div_small (one float reciprocal): exact for 0 <= metres < 2^20 and spacing <= 2^14 only
+  if (c.spacing > (1 << 14)) return bad("spacing above 16384 m");
+  if (c.x_dim_m < 0 || c.y_dim_m < 0 || c.x_dim_m >= (1 << 20) || c.y_dim_m >= (1 << 20)) return bad("x_dim / y_dim must lie in [0, 2^20) metres");
+  if (c.min_altitude < 0 || (long long)c.min_altitude + (long long)c.space_z * c.spacing >= (1 << 20)) return bad("altitudes must lie in [0, 2^20) metres");
   ippm_ctx* ctx = new ippm_ctx();
   std::memset(ctx, 0, sizeof(*ctx));
   ctx->cfg = c;

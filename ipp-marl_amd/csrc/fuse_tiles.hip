@@ -24,6 +24,12 @@
 typedef unsigned ippm_t_u4 __attribute__((ext_vector_type(4)));
 #define IPPM_T_RSRC(ptr, bytes) __builtin_amdgcn_make_buffer_rsrc((void*)(ptr), 0, (int)(bytes), 0x00020000)
 #define IPPM_T_OOB 0x7FFFFFF0
+#ifndef IPPM_T_LOAD_AUX    // cache policy of the map accesses (variant builds; bit 1 = non-temporal on gfx950)
+#define IPPM_T_LOAD_AUX 0
+#endif
+#ifndef IPPM_T_STORE_AUX
+#define IPPM_T_STORE_AUX 0
+#endif
 #define IPPM_T_FAR (-(1 << 20))   // column of a lane-load past the item's end: no op covers it
 
 __device__ __forceinline__ int t_lane_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
@@ -107,7 +113,7 @@ __device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e,
     off[q] = valid ? (row * w.gy + g * 4) * 4 : IPPM_T_OOB;
     coff[q] = row * w.row_bytes + g;
     ycol[q] = valid ? g * 4 : IPPM_T_FAR;
-    const ippm_t_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rmap, off[q], 0, 0);
+    const ippm_t_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rmap, off[q], 0, IPPM_T_LOAD_AUX);
     mv[q].v[0] = __uint_as_float(v.x); mv[q].v[1] = __uint_as_float(v.y); mv[q].v[2] = __uint_as_float(v.z); mv[q].v[3] = __uint_as_float(v.w);
   }
   if constexpr (!SCALAR_OPS) {
@@ -194,7 +200,7 @@ __device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e,
         __builtin_amdgcn_raw_buffer_store_b32(v.y, rmap, tail && ycol[q] + 1 < w.gy ? off[q] + 4 : IPPM_T_OOB, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b32(v.z, rmap, tail && ycol[q] + 2 < w.gy ? off[q] + 8 : IPPM_T_OOB, 0, 0);
       } else {
-        __builtin_amdgcn_raw_buffer_store_b128(v, rmap, off[q], 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rmap, off[q], 0, IPPM_T_STORE_AUX);
       }
     }
     if (is_global) {

@@ -122,7 +122,11 @@ __device__ __forceinline__ uint32_t ippm_truth4(const uint8_t* tr, size_t lin, s
   return (w >> (lin & 7)) & 0xFu;
 }
 __device__ __forceinline__ uint32_t ippm_truth1(const uint8_t* tr, size_t lin) { return (tr[lin >> 3] >> (lin & 7)) & 1u; }
-__host__ __device__ __forceinline__ size_t ippm_truth_bytes(int gx, int gy) { return (((size_t)gx * gy + 31) / 32) * 4; }
+// (grids that are not a multiple of 4 wide read a group's four bits with a 2-byte load at any byte address: the plane then holds one
+//  byte beyond the last cell's, so that the load at the last byte stays inside the plane -- a partly out-of-range buffer load returns 0)
+__host__ __device__ __forceinline__ size_t ippm_truth_bytes(int gx, int gy) {
+  return (((size_t)gx * gy + ((gy & 3) ? 8 : 0) + 31) / 32) * 4;
+}
 __host__ __device__ __forceinline__ size_t ippm_tile_bytes(int S, int vec) { return vec == 4 ? (size_t)S * (S / 4) : (size_t)S * S; }
 
 __device__ __forceinline__ float ippm_clipf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }

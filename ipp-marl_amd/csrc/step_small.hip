@@ -491,7 +491,7 @@ k_plan_step(int32_t* __restrict__ pos, const int32_t* __restrict__ rect, int32_t
     if (tiled && lane == 0) __hip_atomic_store(&s_ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // the plans are in LDS
   }
   PLAN_STAMP(2);
-  if (tiled && wv != k1_wave) {
+  if (tiled && (wv != k1_wave || k1_wave == 0)) {   // (fewer than 3 wavefronts: the planning wavefront builds, then does K1)
     // Tile items: builder b takes maps b, b + nb, ...; an interval's items go wherever the env's running count says (an LDS
     // atomic), so no builder waits for another; the last one to finish writes the env's count.
     const int nb = waves - (k1_wave > 0 ? 1 : 0), b = (k1_wave > 0 && wv > k1_wave) ? wv - 1 : wv;

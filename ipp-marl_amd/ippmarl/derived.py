@@ -135,7 +135,8 @@ class DerivedConstants:
 
     @property
     def truth_bytes(self) -> int:
-        return (self.grid_x * self.grid_y + 31) // 32 * 4
+        # (grids not a multiple of 4 wide: room for the 2-byte load at the last cell's byte, as ippm_truth_bytes)
+        return (self.grid_x * self.grid_y + (8 if self.grid_y % 4 else 0) + 31) // 32 * 4
 
     @property
     def tile_bytes(self) -> int:

@@ -43,7 +43,9 @@ class COMATrainer:
         self.frozen_target = copy.deepcopy(self.critic).to(self.device).eval()
         # graphs: the round is launch-bound at small env counts (the reference's own 5 episodes per round: ~3000 launches of a
         # few microseconds of work each, Python between them); capture_graphs() records every rollout step and the whole update
-        # into hipGraphs.  The optimizers then keep their step counters on the device.
+        # into hipGraphs.  graphs=True changes the optimizer IMPLEMENTATION for every round of this trainer, recorded or not: both
+        # Adam instances are torch's fused capturable form (step counters on the device, one kernel per step), whose update agrees
+        # with the default form to float32 rounding, not bit for bit; their state is not part of save_actor's pickle.
         self.graphs = bool(graphs)
         self._step_graphs = self._update_graph = None
         self.actor_learner = ActorLearner(params, self.actor, self.device, ctx=self.env.ctx, capturable=self.graphs)
@@ -89,6 +91,9 @@ class COMATrainer:
         for t in range(self.T):
             if replay:
                 self._step_graphs[t].replay()
+                # (the host-side bookkeeping of the env that a replayed step skips: the step counter, no fusion pending, the
+                #  observations held are those of step t)
+                env.t, env._pending_t, env._obs_t = t + 1, None, t
                 continue
             reward = self._rollout_step(t, w, policy, mode == "train", self.eps_dev if self.graphs else self.eps)
             if self.keep_rollout_log:

@@ -113,6 +113,13 @@ class VecEnv:
         self._profile = False    # time the kernels with events bound to their dispatches (bench.py's roofline legs)
         self._ep_host = None     # pinned staging buffer of reset()'s episode ids, and the event of its last copy
         self._ep_copied = None
+        # terrain of the NEXT episodes, synthesised on a side stream while the current episodes are stepped (prefetch_terrain)
+        self._side = None
+        self._next_ids = None    # host copy of the episode ids whose terrain `_truth_next` holds (or will hold: `_next_ready`)
+        self._truth_next = None
+        self._episode_next = None
+        self._next_host = None
+        self._next_ready = None
 
     # ------------------------------------------------------------------------------------------------
     def _place_hot(self, slack_mb: int = 0):
@@ -219,11 +226,16 @@ class VecEnv:
             packed = d.pack_truth(torch.as_tensor(truth).cpu().numpy().reshape(self.E, d.grid_x, d.grid_y))
             self.truth.copy_(torch.from_numpy(packed).to(self.device))
         elif terrain == "random_field":
-            if self._field is None:
-                from .terrain import RandomFieldTerrain
-                self._field = RandomFieldTerrain(d, self.ctx, self.device,
-                                                 self.params["sensor"]["simulation"]["cluster_radius"])
-            self._field.generate(self.episode, self.truth, self.stream)
+            if self._next_ids is not None and np.array_equal(self._next_ids, ep.numpy()):
+                # synthesised ahead of time on the side stream (prefetch_terrain): the packed truth planes are 8 MB at config 2,
+                # copied rather than swapped so that every recorded launch keeps reading `truth`
+                torch.cuda.current_stream(self.device).wait_event(self._next_ready)
+                self.truth.copy_(self._truth_next)
+            else:
+                if self._next_ready is not None:   # the side stream may still be using the generator's scratch buffers
+                    torch.cuda.current_stream(self.device).wait_event(self._next_ready)
+                self._terrain().generate(self.episode, self.truth, self.stream)
+            self._next_ids = None
         elif terrain != "split":
             raise ValueError(f"unknown terrain {terrain!r}")
         if start_positions is not None:
@@ -238,6 +250,41 @@ class VecEnv:
             self._boxes_valid = True
         else:
             self._sense(stage=0, flips=flips)
+
+    def _terrain(self):
+        if self._field is None:
+            from .terrain import RandomFieldTerrain
+            self._field = RandomFieldTerrain(self.d, self.ctx, self.device, self.params["sensor"]["simulation"]["cluster_radius"])
+        return self._field
+
+    def prefetch_terrain(self, episodes) -> None:
+        """Starts synthesising the random-field terrain of ``episodes`` (the ids the NEXT reset will be given) on a side stream,
+        so that it runs beside the current episodes' steps instead of in front of the next reset: the synthesis (spectrum, two
+        FFT passes, threshold: ~300 us for 1024 fields of 256^2) is latency-bound at 16 wavefronts per CU and needs nothing but
+        the episode numbers (mapping/ground_truths.py:16-40 draws the field from the episode's own stream).  A reset that is
+        given exactly these ids takes the prefetched planes; any other reset ignores them and synthesises in line."""
+        if self.terrain != "random_field":
+            return
+        d = self.d
+        ep = torch.as_tensor(episodes, dtype=torch.int64).reshape(self.E)
+        main = torch.cuda.current_stream(self.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            self._truth_next = torch.zeros_like(self.truth)
+            self._episode_next = torch.zeros_like(self.episode)
+            self._next_host = torch.empty(self.E, dtype=torch.int64).pin_memory()
+        if self._next_ready is not None:
+            self._next_ready.synchronize()     # the previous prefetch has read the staging buffer (and the scratch is free)
+        self._next_host.copy_(ep)
+        started = torch.cuda.Event()
+        started.record(main)                   # after everything queued so far: an in-line synthesis of reset() included
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(started)
+            self._episode_next.copy_(self._next_host, non_blocking=True)
+            self._terrain().generate(self._episode_next, self._truth_next, self._side.cuda_stream)
+            self._next_ready = torch.cuda.Event()
+            self._next_ready.record(self._side)
+        self._next_ids = ep.numpy().copy()
 
     def sense(self, stage: int, flips: Optional[torch.Tensor] = None, agent: int = -1, close_step: bool = False):
         """K3 at the current positions, called from outside the batched step (drop-in Agent / Mapping): the maps are then
@@ -480,7 +527,9 @@ class VecEnv:
 
     def event_times_us(self, clear: bool = True) -> Dict[str, Dict[str, float]]:
         """{kernel class: {"launches", "avg_us", "min_us", "kernel"}} of the launches made while ``profile`` was set
-        (synchronises the stream)."""
+        (synchronises the stream, and the side stream of prefetch_terrain)."""
+        if self._side is not None:
+            self._side.synchronize()
         return self.ctx.kernel_times(self.stream, reset=clear)
 
     def counters(self, reset: bool = False) -> dict:

@@ -85,6 +85,12 @@ def _oracle_philox_episode(params, episode, seed, truth=None):
     return philox_episode(params, episode, seed, truth)
 
 
+# 85 x 85 cells: not a multiple of 4 wide AND 85^2 = 25 (mod 32), so the last cell's truth bit sits in the last-but-one byte group
+# of the packed plane -- the 2-byte truth loads of the row-straddling groups reach the plane's end (ippm_truth_bytes keeps a spare byte)
+EDGE_85 = ("default", dict(sensor__pixel__number_x=12, sensor__pixel__number_y=12, sensor__field_of_view__angle_x=70.0,
+                           sensor__field_of_view__angle_y=70.0), 3)
+
+
 @pytest.mark.parametrize("name,over,n_envs", [
     ("small", dict(), 6),
     ("small", dict(experiment__uav__failure_rate=0.35, experiment__uav__fix_range=False, experiment__missions__n_agents=6), 4),
@@ -107,6 +113,7 @@ def _oracle_philox_episode(params, episode, seed, truth=None):
     # 20 m sets its cells to exactly 0 or 1, i.e. +-inf in log-odds storage, until the next fusion clips them
     ("small", dict(experiment__constraints__min_altitude=15, experiment__constraints__max_altitude=20,
                    experiment__constraints__num_actions=27, experiment__uav__communication_range=10), 2),
+    EDGE_85,
 ])
 def test_production_randomness_matches_oracle(name, over, n_envs):
     """Philox mode (what bench/training use): device RNG streams, uniform random policy, every step vs the oracle."""
@@ -200,6 +207,7 @@ def check_philox_episodes(name, over, n_envs, seed=0x1234567ABC, first_episode=1
     # noise-free altitudes (20 m is outside the sensor model's table): returns at 1e-5 in this form (float64 lane sums)
     ("small", dict(experiment__constraints__min_altitude=15, experiment__constraints__max_altitude=20,
                    experiment__constraints__num_actions=27, experiment__uav__communication_range=10), 2),
+    EDGE_85,
 ])
 @pytest.mark.parametrize("fused_step", [False, True])
 def test_untracked_env_step_matches_oracle(name, over, n_envs, fused_step):
@@ -338,6 +346,30 @@ def test_random_field_terrain_native_path(name):
     solo.reset([int(eps[1])])
     assert np.array_equal(solo.truth_map.numpy()[0], got[1])
     assert not np.array_equal(got[0], got[2])
+
+
+def test_terrain_prefetch_is_the_inline_terrain():
+    """VecEnv.prefetch_terrain: the field of the next episodes synthesised on a side stream beside the current episodes' steps is
+    bit for bit the field reset() synthesises in line; a reset with other ids than the prefetched ones ignores the prefetch."""
+    from ippmarl.vec_env import POLICY_UNIFORM
+    params = make_params("c2")
+    E = 48
+    a = _env(params, E, terrain="random_field", track_area=False)
+    b = _env(params, E, terrain="random_field", track_area=False)
+    waves = [np.arange(1, E + 1) + 1000 * w for w in range(4)]
+    for w, ids in enumerate(waves):
+        a.reset(ids)
+        b.reset(ids)
+        if w + 1 < len(waves):
+            # wave 1 is prefetched correctly, wave 2 with the WRONG ids (reset must fall back), wave 3 correctly again
+            b.prefetch_terrain(waves[w + 1] if w != 1 else waves[w + 1] + 7)
+        for t in range(a.d.budget + 1):
+            ra, _, _ = a.steps(t, policy=POLICY_UNIFORM, features=False)
+            rb, _, _ = b.steps(t, policy=POLICY_UNIFORM, features=False)
+        torch.cuda.synchronize()
+        assert torch.equal(a.truth, b.truth), w
+        assert torch.equal(a.glob, b.glob) and torch.equal(a.local, b.local) and torch.equal(a.pos, b.pos), w
+        assert not torch.equal(a.truth[0], a.truth[1])
 
 
 def test_episode_on_random_field_terrain_matches_oracle():
@@ -585,7 +617,9 @@ def test_c_abi_error_paths():
     d = DerivedConstants(make_params("small"))
     # rejected configurations
     for mutate, needle in ((lambda c: setattr(c, "prior", 1.5), "prior"), (lambda c: setattr(c, "n_agents", 40), "n_agents"),
-                           (lambda c: setattr(c, "n_actions", 5), "num_actions"), (lambda c: setattr(c, "tile_stride", 8), "tile_stride")):
+                           (lambda c: setattr(c, "n_actions", 5), "num_actions"), (lambda c: setattr(c, "tile_stride", 8), "tile_stride"),
+                           (lambda c: setattr(c, "x_dim_m", 1 << 20), "x_dim"), (lambda c: setattr(c, "spacing", 20000), "spacing"),
+                           (lambda c: setattr(c, "min_altitude", -5), "altitudes")):
         cfg = _ffi.make_config(d)
         mutate(cfg)
         h = C.c_void_p()

@@ -16,11 +16,16 @@ g = df.groupby(["k", grid])["us"].agg(["count", "mean", "min", "max", "sum"]).so
 print(g[g["sum"] > (float(sys.argv[2]) if len(sys.argv) > 2 else 50)].round(1).to_string())
 
 # idle time in front of each kernel of the env step (end of the previous kernel on the device -> start of this one)
-step = df[df["k"].str.contains("k_plan_step|k_sense_|k_fuse_rows")].sort_values("start").reset_index(drop=True)
+# (the three launches of a step: the plan kernel, the fusion in either of its forms, K3 in either of its forms)
+step = df[df["k"].str.contains("k_plan_step|k_sense_tiles|k_sense_update|k_fuse_tiles|k_fuse_rows")].sort_values("start").reset_index(drop=True)
 if len(step) > 12:
     step["gap_us"] = (step["start"] - step["end"].shift(1)) / 1e3
     tail = step.iloc[len(step) // 2:]
     print("\nidle time before each step kernel (second half of the run):")
     print(tail.groupby("k")["gap_us"].agg(["count", "mean", "min", "max"]).round(1).to_string())
     span = (tail["end"].iloc[-1] - tail["start"].iloc[0]) / 1e3
-    print("span per step kernel triple: %.1f us, kernel time %.1f us" % (span / (len(tail) / 3), tail["us"].sum() / (len(tail) / 3)))
+    kinds = tail["k"].str.extract(r"(k_plan_step|k_sense|k_fuse)")[0]
+    triples = int(kinds.value_counts().min())     # complete steps in the window
+    assert kinds.nunique() == 3, "the window does not hold all three kernels of a step: %s" % sorted(kinds.dropna().unique())
+    print("span per step (plan + fusion + K3; resets included in the span): %.1f us, of which these three kernels %.1f us"
+          % (span / triples, tail["us"].sum() / triples))
