@@ -90,7 +90,7 @@ def cpu_baseline(args, seconds=10.0):
             "reference_probe": REFERENCE_PROBE}
 
 
-def spawn_ranks(n: int) -> int:
+def spawn_ranks(n: int, ipc_mode: str = "keep", retry: bool = True) -> int:
     """`python bench.py --gpus N` outside a launcher: re-run this command as N ranks (one per GPU) under
     torch.distributed.run on a free local port.  The ranks' stdout is ours, so rank 0's JSON line comes out as usual."""
     import socket
@@ -98,11 +98,42 @@ def spawn_ranks(n: int) -> int:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL needs it)
     env.setdefault("OMP_NUM_THREADS", "4")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
+    # HSA_ENABLE_IPC_MODE_LEGACY: the image this was built on exports 0 ("the host driver only supports dmabuf IPC": without it RCCL
+    # fails with hipIpcGetMemHandle: invalid argument).  It is read when the HSA runtime starts, so it cannot be changed inside a
+    # rank: the launcher tries the environment's own value first (--ipc-legacy keep; or the value forced by --ipc-legacy 0 / unset)
+    # and, if the ranks fail, ONCE more with the other setting, and says on stderr which one worked.
+    first = ipc_env_setting(env, ipc_mode)
+    order = [first, "unset" if first == "0" else "0"]
+    rc = 1
+    for attempt, setting in enumerate(order):
+        e = dict(env)
+        e.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
+        if setting != "unset":
+            e["HSA_ENABLE_IPC_MODE_LEGACY"] = setting
+        e["IPPM_BENCH_IPC_SETTING"] = f"HSA_ENABLE_IPC_MODE_LEGACY={setting} (attempt {attempt + 1})"
+        with socket.socket() as sock:   # a fresh port per attempt
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        rc = subprocess.call(cmd, env=e)
+        if rc == 0:
+            if attempt:
+                print(f"bench.py: the ranks ran with HSA_ENABLE_IPC_MODE_LEGACY={setting} after failing with {order[0]}", file=sys.stderr)
+            return 0
+        print(f"bench.py: {n} ranks failed (exit {rc}) with HSA_ENABLE_IPC_MODE_LEGACY={setting}"
+              + ("; retrying once with the other setting" if attempt == 0 and retry else ""), file=sys.stderr)
+        if not retry:
+            break
+    return rc
+
+
+def ipc_env_setting(env, mode: str) -> str:
+    """The first HSA_ENABLE_IPC_MODE_LEGACY setting the launcher tries: "keep" = whatever the environment holds."""
+    if mode == "keep":
+        return env.get("HSA_ENABLE_IPC_MODE_LEGACY", "unset")
+    return mode
 
 
 def newest_pmc_summary():
@@ -143,12 +174,16 @@ def main():
                     "print {\"ranks\": N, ...} and stop before any GPU work (the CPU test of the self-launch)")
     ap.add_argument("--placement-draws", type=int, default=24, help="allocations of the env's hot planes tried before the run "
                     "(VecEnv.tune_placement; 1 = take what the allocator hands out)")
+    ap.add_argument("--ipc-legacy", default="keep", choices=["keep", "0", "1", "unset"], help="HSA_ENABLE_IPC_MODE_LEGACY the ranks "
+                    "started by `--gpus N` run under: keep = the environment's own value (this image exports 0: the host driver only "
+                    "supports dmabuf IPC); if the ranks fail they are started ONCE more with the other setting (--no-ipc-retry: not)")
+    ap.add_argument("--no-ipc-retry", dest="ipc_retry", action="store_false")
     ap.add_argument("--calib", action="store_true", help="PMC calibration: 3 device-to-device copies of the local maps (known "
                     "bytes read and written by a 16 B/lane streaming kernel) before the timed loop")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(spawn_ranks(args.gpus))   # not under a launcher: start the ranks ourselves and relay rank 0's line
+        raise SystemExit(spawn_ranks(args.gpus, args.ipc_legacy, args.ipc_retry))   # not under a launcher: start the ranks ourselves and relay rank 0's line
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -163,7 +198,7 @@ def main():
         dist.all_reduce(ids)
         if rank == 0:
             print(json.dumps({"ranks": dist.get_world_size(), "n_gpus": world, "rank_id_sum": int(ids[0]),
-                              "backend": dist.get_backend()}), flush=True)
+                              "backend": dist.get_backend(), "launcher_ipc_setting": os.environ.get("IPPM_BENCH_IPC_SETTING")}), flush=True)
         dist.destroy_process_group()
         return
     if world > 1:
@@ -174,7 +209,16 @@ def main():
             if n_dev < world:
                 raise SystemExit(f"--gpus {world} with RCCL needs {world} visible GPUs, found {n_dev} "
                                  "(--dist-backend gloo lets the ranks share a GPU for a dry run of the control flow)")
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+            try:
+                dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+                probe = torch.ones(1, device=f"cuda:{local_rank}")
+                dist.all_reduce(probe)          # the first collective is where an IPC problem shows (communicator set-up is lazy)
+                torch.cuda.synchronize()
+                assert int(probe[0]) == world
+            except Exception as exc:   # noqa: BLE001
+                raise SystemExit(f"rank {rank}: RCCL did not come up ({type(exc).__name__}: {exc}); HSA_ENABLE_IPC_MODE_LEGACY="
+                                 f"{os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', 'unset')} -- it is read when the HSA runtime starts: "
+                                 "relaunch with the other setting (`python bench.py --gpus N` does that by itself, once)")
         else:
             dist.init_process_group(args.dist_backend)
         local_rank %= n_dev
@@ -402,8 +446,12 @@ def main():
                     "allreduce_bytes": tr.reducer.bytes_reduced}
             gathered = [None] * world
             dist.all_gather_object(gathered, mine)
+            if dist.get_backend() == "nccl" and len({(r["host"], r["device"]) for r in gathered}) != world:
+                raise SystemExit(f"{world} ranks over RCCL but only {len({(r['host'], r['device']) for r in gathered})} distinct (host, device) "
+                                 f"pairs: {gathered}")
             collective = {"backend": dist.get_backend(), "library": "RCCL over xGMI" if dist.get_backend() == "nccl" else dist.get_backend(),
-                          "world_size": dist.get_world_size(), "allreduce_calls": tr.reducer.calls,
+                          "world_size": dist.get_world_size(), "hsa_enable_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "unset"),
+                          "launcher_ipc_setting": os.environ.get("IPPM_BENCH_IPC_SETTING"), "allreduce_calls": tr.reducer.calls,
                           "allreduce_bytes": tr.reducer.bytes_reduced,
                           "per_update": {"calls": tr.reducer.calls // (args.train_rounds + 1),
                                          "bytes": tr.reducer.bytes_reduced // (args.train_rounds + 1)},

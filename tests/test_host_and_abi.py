@@ -113,6 +113,69 @@ def test_bench_starts_its_own_ranks():
     assert rec["ranks"] == 2 and rec["n_gpus"] == 2 and rec["rank_id_sum"] == 1 and rec["backend"] == "gloo"
 
 
+def test_eight_ranks_rendezvous_and_only_rank_zero_speaks():
+    """The 8-GPU command shape of the driver, on CPU: `python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8`
+    (here with --rendezvous-only over gloo): 8 ranks meet on 127.0.0.1, all-reduce their rank ids (0 + ... + 7 = 28), rank 0 alone
+    prints; and a launcher that starts a different number of ranks than --gpus says so instead of running."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+
+    def run(nproc, gpus):
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr",
+                               "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(gpus),
+                               "--rendezvous-only", "--dist-backend", "gloo"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+
+    out = run(8, 8)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["ranks"] == 8 and rec["n_gpus"] == 8 and rec["rank_id_sum"] == 28 and rec["backend"] == "gloo"
+    bad = run(2, 8)
+    assert bad.returncode != 0 and "--gpus 8 but the launcher started 2 ranks" in (bad.stderr + bad.stdout)
+
+
+def test_launcher_retries_once_with_the_other_ipc_setting(monkeypatch):
+    """bench.spawn_ranks: the ranks are started with the environment's HSA_ENABLE_IPC_MODE_LEGACY; if they fail, once more with
+    the other setting; every attempt gets a fresh port and tells the ranks which setting it is."""
+    import bench
+    calls = []
+
+    def fake_call(cmd, env):
+        calls.append((cmd, env.get("HSA_ENABLE_IPC_MODE_LEGACY", "unset"), env["IPPM_BENCH_IPC_SETTING"]))
+        return 1 if len(calls) == 1 else 0
+
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert bench.spawn_ranks(8) == 0
+    assert [c[1] for c in calls] == ["0", "unset"] and "attempt 2" in calls[1][2]
+    ports = [c[0][c[0].index("--master-port") + 1] for c in calls]
+    assert all("--nproc-per-node=8" in c[0] for c in calls) and all(p.isdigit() for p in ports)
+    calls.clear()
+    assert bench.spawn_ranks(4, ipc_mode="unset", retry=False) == 1 and [c[1] for c in calls] == ["unset"]
+    calls.clear()
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY")
+    bench.spawn_ranks(2)
+    assert [c[1] for c in calls] == ["unset", "0"]
+
+
+def test_placement_search_memory_bound():
+    """VecEnv.tune_placement keeps rejected candidates allocated only within half of the free device memory."""
+    from ippmarl.vec_env import placement_alive_cap
+    GB = 1 << 30
+    assert placement_alive_cap(280 * GB, int(1.7 * GB)) >= 24          # config 2 on an empty MI355X: the whole search fits
+    assert placement_alive_cap(280 * GB, int(9.7 * GB)) == 14          # config 4's per-GPU shape: 13 candidates + the arena in use
+    assert placement_alive_cap(30 * GB, int(9.7 * GB)) == 2            # next to a trainer's activations: one candidate at a time
+    assert placement_alive_cap(0, GB) == 2
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from ippmarl import _ffi
     monkeypatch.setattr(_ffi, "_lib", None)
