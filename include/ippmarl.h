@@ -381,6 +381,11 @@ int ippm_terrain_spectrum(ippm_ctx* ctx, const int64_t* episode, const float* am
 int ippm_terrain_field(ippm_ctx* ctx, const int64_t* episode, const float* amp, const float* spec, float* work, float* field,
                        uint32_t* range_keys, int32_t n_envs, void* stream);
 int ippm_terrain_pack(ippm_ctx* ctx, const float* field, const uint32_t* range_keys, uint8_t* truth, int32_t n_envs, void* stream);
+/* ippm_terrain_truth = ippm_terrain_field(spec = NULL) + ippm_terrain_pack without ever storing the field: the second transform
+ * pass runs twice (once for the field's min / max, once more for the threshold bits, same arithmetic), which moves half the bytes
+ * of writing the field and reading it back.  work: complex64 [E,gy/2+1,gx] scratch, range_keys: uint32 [E,2] scratch. */
+int ippm_terrain_truth(ippm_ctx* ctx, const int64_t* episode, const float* amp, float* work, uint32_t* range_keys, uint8_t* truth,
+                       int32_t n_envs, void* stream);
 
 /* Host helpers (no GPU needed): exported so that CPU-only tests can pin the device's integer streams and
  * resize weights to NumPy / the oracle. */

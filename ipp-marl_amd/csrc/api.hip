@@ -103,6 +103,18 @@ extern "C" int ippm_ctx_create(const ippm_config* cfg, ippm_ctx** out) {
   if (!rc) rc = ippm_check_hip(hipMemcpy(ctx->dcfg, cfg, sizeof(ippm_config), hipMemcpyHostToDevice), "hipMemcpy(cfg)");
   if (!rc) rc = ippm_check_hip(hipMalloc(&ctx->dcounters, IPPM_COUNTER_SLOTS * 8 * sizeof(unsigned long long)), "hipMalloc(counters)");
   if (!rc) rc = ippm_check_hip(hipMemset(ctx->dcounters, 0, IPPM_COUNTER_SLOTS * 8 * sizeof(unsigned long long)), "hipMemset(counters)");
+  if (!rc) {   // the 1024-th roots of unity for the terrain transforms, float64 rounded once
+    std::vector<float2> roots(1024);
+    for (int k = 0; k < 1024; ++k) {
+      const double a = 2.0 * M_PI * (double)k / 1024.0;
+      roots[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    for (int q = 0; q < 4; ++q) {   // exact values on the axes
+      roots[256 * q] = make_float2(q == 0 ? 1.f : (q == 2 ? -1.f : 0.f), q == 1 ? 1.f : (q == 3 ? -1.f : 0.f));
+    }
+    rc = ippm_check_hip(hipMalloc(&ctx->d_roots, sizeof(float2) * 1024), "hipMalloc(roots)");
+    if (!rc) rc = ippm_check_hip(hipMemcpy(ctx->d_roots, roots.data(), sizeof(float2) * 1024, hipMemcpyHostToDevice), "hipMemcpy(roots)");
+  }
   if (rc) { ippm_ctx_destroy(ctx); return rc; }
   *out = ctx;
   return 0;
@@ -112,6 +124,7 @@ extern "C" int ippm_ctx_destroy(ippm_ctx* ctx) {
   if (!ctx) return 0;
   if (ctx->dcfg) (void)hipFree(ctx->dcfg);
   if (ctx->dcounters) (void)hipFree(ctx->dcounters);
+  if (ctx->d_roots) (void)hipFree(ctx->d_roots);
   for (int k = 0; k < IPPM_TIMED_CLASSES; ++k) {
     for (int i = 0; i < 2 * ctx->ev_made[k]; ++i) (void)hipEventDestroy(ctx->ev[k][i]);
     delete[] ctx->ev[k];

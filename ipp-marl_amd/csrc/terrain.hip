@@ -4,6 +4,9 @@
 #include "ippm_internal.h"
 
 #define IPPM_DOMAIN_TERRAIN 3u
+#ifndef IPPM_TERRAIN_ABL   // variant builds: timing ablations (1: no spectrum draw, 2 / 4: no first / second register FFT, 8: no stores)
+#define IPPM_TERRAIN_ABL 0
+#endif
 
 static inline hipStream_t S_(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
@@ -57,22 +60,44 @@ __device__ __forceinline__ uint32_t bitrev(uint32_t v, int bits) { return __brev
 // Bin (kx, ky) of the half spectrum of N(0,1) white noise, up to a common factor: generic bins are a + ib with
 // a, b ~ N(0,1); on the self-mirrored columns ky in {0, gy/2} bin (gx - kx) is the conjugate of bin kx and the four
 // self-conjugate bins are real with twice the variance.
-__device__ __forceinline__ float2 terrain_bin(uint64_t ep, uint32_t k0, uint32_t k1, int gx, int gy, int kx, int ky, float amp) {
-  const bool edge = ky == 0 || 2 * ky == gy;
-  int cx = kx;
-  bool conj = false;
-  if (edge && 2 * kx > gx) { cx = gx - kx; conj = true; }
-  const bool self = edge && (cx == 0 || 2 * cx == gx);
-  const uint32_t bin = (uint32_t)cx * (uint32_t)(gy / 2 + 1) + (uint32_t)ky;
-  Philox4 ph = ippm_philox(bin, (uint32_t)ep, ippm_stream_word(0u, 1u, IPPM_DOMAIN_TERRAIN), (uint32_t)(ep >> 32), k0, k1);
-  const float u1 = ((float)(ph.v[0] >> 8) + 1.0f) * (1.0f / 16777216.0f);
-  const float u2 = (float)(ph.v[1] >> 8) * (1.0f / 16777216.0f);
+//
+// Randomness: one Philox call serves TWO bins -- bins kx and kx + gx/2 of a column share call number (kx mod gx/2) * (gy/2 + 1) + ky,
+// the lower one takes words (0, 1), the upper one words (2, 3) -- because the call is most of a bin's cost (45 of ~60 instructions)
+// and pass X is issue-bound; the pairing is by wave number, not by thread, so any kernel geometry draws the same spectrum (a
+// thread of pass X holds kx = i1 * N2 + i2 for all i1: both partners).
+__device__ __forceinline__ uint32_t terrain_call(int gx, int gy, int cx, int ky) {   // (cx: the bin whose numbers are drawn)
+  return (uint32_t)(cx & (gx / 2 - 1)) * (uint32_t)(gy / 2 + 1) + (uint32_t)ky;
+}
+__device__ __forceinline__ float2 terrain_bin_from(uint32_t w1, uint32_t w2, bool self, bool conj, float amp) {
+  const float u1 = ((float)(w1 >> 8) + 1.0f) * (1.0f / 16777216.0f);
+  const float u2 = (float)(w2 >> 8) * (1.0f / 16777216.0f);
   // hardware transcendentals (v_log_f32, v_sin_f32 / v_cos_f32 take revolutions): a few ulp off the libm forms, which a
   // noise generator does not care about -- what is checked is the transform of whatever spectrum is drawn
   const float r = __builtin_sqrtf(-1.3862943611f * __builtin_amdgcn_logf(u1));   // -2 ln u = -2 ln2 log2 u
   const float sn = __builtin_amdgcn_sinf(u2), cs = __builtin_amdgcn_cosf(u2);
   if (self) return make_float2(amp * 1.41421356237f * r * cs, 0.0f);
   return make_float2(amp * r * cs, conj ? -amp * r * sn : amp * r * sn);
+}
+// one bin on its own (the spectrum kernel of the tests; pass X draws pairs, below)
+__device__ __forceinline__ float2 terrain_bin(uint64_t ep, uint32_t k0, uint32_t k1, int gx, int gy, int kx, int ky, float amp) {
+  const bool edge = ky == 0 || 2 * ky == gy;
+  int cx = kx;
+  bool conj = false;
+  if (edge && 2 * kx > gx) { cx = gx - kx; conj = true; }
+  const bool self = edge && (cx == 0 || 2 * cx == gx);
+  Philox4 ph = ippm_philox(terrain_call(gx, gy, cx, ky), (uint32_t)ep, ippm_stream_word(0u, 1u, IPPM_DOMAIN_TERRAIN), (uint32_t)(ep >> 32), k0, k1);
+  const bool upper = 2 * cx >= gx;
+  return terrain_bin_from(upper ? ph.v[2] : ph.v[0], upper ? ph.v[3] : ph.v[1], self, conj, amp);
+}
+// bins kx (< gx/2) and kx + gx/2 of a GENERIC column ky (0 < ky < gy/2) from one call.  (On the self-mirrored columns ky in
+// {0, gy/2} the upper bin is the conjugate of bin gx/2 - kx, which belongs to another call: pass X gives those two columns a
+// workgroup of their own that draws bin by bin -- inside a generic workgroup their one lane in sixteen made every wavefront
+// run both forms.)
+__device__ __forceinline__ void terrain_bin_pair(uint64_t ep, uint32_t k0, uint32_t k1, int gx, int gy, int kx, int ky, float amp_lo,
+                                                 float amp_hi, float2& lo, float2& hi) {
+  Philox4 ph = ippm_philox(terrain_call(gx, gy, kx, ky), (uint32_t)ep, ippm_stream_word(0u, 1u, IPPM_DOMAIN_TERRAIN), (uint32_t)(ep >> 32), k0, k1);
+  lo = terrain_bin_from(ph.v[0], ph.v[1], false, false, amp_lo);
+  hi = terrain_bin_from(ph.v[2], ph.v[3], false, false, amp_hi);
 }
 
 __global__ __launch_bounds__(256) void k_terrain_spectrum(const ippm_config* __restrict__ c, const int64_t* __restrict__ episode,
@@ -131,18 +156,18 @@ struct FourStep {
   float2 xbuf[Q * SEQ];
   float2 twn[N1 * N2];
 
-  __device__ __forceinline__ void init_twiddles() {
-    for (int i = threadIdx.x; i < N1 * N2; i += THREADS) {
-      float sn, cs;
-      sincospif(2.0f * (float)i / (float)(N1 * N2), &sn, &cs);
-      twn[i] = make_float2(cs, sn);
-    }
+  // W_n^i = e^{2 pi i / n} from the context's table of the 1024-th roots of unity (float64 on the host, rounded once): a
+  // sincospif per thread and workgroup was 60 instructions in front of every workgroup's first load
+  __device__ __forceinline__ void init_twiddles(const float2* __restrict__ roots1024) {
+    for (int i = threadIdx.x; i < N1 * N2; i += THREADS) twn[i] = roots1024[i * (1024 / (N1 * N2))];
     __syncthreads();
   }
   __device__ __forceinline__ void run(float2 (&v)[N1], float2 (&o)[N2], int q_in, int i2, bool in_active, int q_out, int k1,
                                       bool out_active) {
     if (in_active) {
+#if !(IPPM_TERRAIN_ABL & 2)
       fft_reg<N1>(v);
+#endif
 #pragma unroll
       for (int k = 0; k < N1; ++k) xbuf[q_in * SEQ + k * (N2 + 1) + i2] = cmul(v[k], twn[i2 * k]);
     }
@@ -150,7 +175,9 @@ struct FourStep {
     if (out_active) {
 #pragma unroll
       for (int i = 0; i < N2; ++i) o[i] = xbuf[q_out * SEQ + k1 * (N2 + 1) + i];
+#if !(IPPM_TERRAIN_ABL & 4)
       fft_reg<N2>(o);
+#endif
     }
   }
 };
@@ -162,55 +189,81 @@ __device__ __forceinline__ uint32_t order_key(float f) {
 }
 __device__ __forceinline__ float key_value(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
 
-// pass X: sequences are the ky columns of the half spectrum (length gx = N1 * N2), Q columns per workgroup
+// pass X: sequences are the ky columns of the half spectrum (length gx = N1 * N2), Q columns per workgroup.  Workgroups
+// 0 .. gridDim.x - 2 take the generic columns 1 .. gy/2 - 1, the last one the two self-mirrored columns 0 and gy/2.
 template <int N1, int N2, int Q, bool GEN>
 __global__ __launch_bounds__((FourStep<N1, N2, Q>::THREADS)) void k_terrain_fft_x(const ippm_config* __restrict__ c,
                                                                                const int64_t* __restrict__ episode,
                                                                                const float* __restrict__ amp,
                                                                                const float2* __restrict__ spec,
                                                                                float2* __restrict__ work,
-                                                                               uint32_t* __restrict__ range_keys) {
+                                                                               uint32_t* __restrict__ range_keys,
+                                                                               const float2* __restrict__ roots1024) {
   __shared__ FourStep<N1, N2, Q> fs;
-  const int e = blockIdx.y, gx = N1 * N2, gy = c->grid_y, hy = gy / 2 + 1, c0 = blockIdx.x * Q, tid = threadIdx.x;
+  const int e = blockIdx.y, gx = N1 * N2, gy = c->grid_y, hy = gy / 2 + 1, tid = threadIdx.x;
+  const bool edge_wg = blockIdx.x == gridDim.x - 1;
   if (range_keys && blockIdx.x == 0 && tid == 0) {   // pass Y accumulates the field's (min, max) here
     range_keys[2 * e] = 0xFFFFFFFFu;
     range_keys[2 * e + 1] = 0u;
   }
-  fs.init_twiddles();
+  fs.init_twiddles(roots1024);
   const int q_in = tid % Q, i2 = tid / Q, k1 = tid % N1, q_out = tid / N1;
   const bool in_active = i2 < N2, out_active = q_out < Q;
+  // column of slot q: -1 = none
+  auto column = [&](int q) { return edge_wg ? (q == 0 ? 0 : (q == 1 ? gy / 2 : -1)) : (1 + (int)blockIdx.x * Q + q < gy / 2 ? 1 + (int)blockIdx.x * Q + q : -1); };
   float2 v[N1], o[N2];
   if (in_active) {
-    const int ky = c0 + q_in;
+    const int ky = column(q_in);
     const uint64_t ep = GEN ? (uint64_t)episode[e] : 0;
     const uint32_t k0 = (uint32_t)c->philox_seed, k1s = (uint32_t)(c->philox_seed >> 32);
 #pragma unroll
-    for (int i1 = 0; i1 < N1; ++i1) {
-      const int kx = i1 * N2 + i2;
-      v[i1] = make_float2(0.0f, 0.0f);
-      if (ky < hy) {
-        if (GEN) v[i1] = terrain_bin(ep, k0, k1s, gx, gy, kx, ky, amp[(size_t)kx * hy + ky]);
-        else v[i1] = spec[((size_t)e * gx + kx) * hy + ky];
+    for (int i1 = 0; i1 < N1; ++i1) v[i1] = make_float2(0.0f, 0.0f);
+    if (ky >= 0) {
+      if (GEN && edge_wg) {     // (workgroup-uniform) bin by bin: conjugate pairs and the four real bins
+#pragma unroll
+        for (int i1 = 0; i1 < N1; ++i1) {
+          const int kx = i1 * N2 + i2;
+          v[i1] = terrain_bin(ep, k0, k1s, gx, gy, kx, ky, amp[(size_t)kx * hy + ky]);
+        }
+      } else if (GEN) {
+#pragma unroll
+        for (int i1 = 0; i1 < N1 / 2; ++i1) {   // bins kx and kx + gx/2 come from one Philox call
+          const int kx = i1 * N2 + i2;
+          terrain_bin_pair(ep, k0, k1s, gx, gy, kx, ky, amp[(size_t)kx * hy + ky], amp[(size_t)(kx + gx / 2) * hy + ky], v[i1], v[i1 + N1 / 2]);
+        }
+      } else {
+#pragma unroll
+        for (int i1 = 0; i1 < N1; ++i1) v[i1] = spec[((size_t)e * gx + i1 * N2 + i2) * hy + ky];
       }
     }
   }
   fs.run(v, o, q_in, i2, in_active, q_out, k1, out_active);
-  if (out_active && c0 + q_out < hy) {
-    float2* dst = work + ((size_t)e * hy + c0 + q_out) * gx + k1;
+  const int ky_out = out_active ? column(q_out) : -1;
+  if (ky_out >= 0) {
+    float2* dst = work + ((size_t)e * hy + ky_out) * gx + k1;
 #pragma unroll
     for (int k2 = 0; k2 < N2; ++k2) dst[N1 * k2] = o[k2];
   }
 }
 
-// pass Y: sequences are the x rows (length gy = N1 * N2 after the Hermitian extension), Q rows per workgroup
-template <int N1, int N2, int Q>
+// pass Y: sequences are the x rows (length gy = N1 * N2 after the Hermitian extension).  The rows are real, so ONE complex
+// transform yields TWO of them: with A, B the Hermitian-extended spectra of rows xa and xb, the inverse transform of A + iB is
+// a + ib with a, b the two real rows.  A workgroup takes 2 Q rows (xa = x0 + q, xb = x0 + Q + q): half the transforms of the
+// row-by-row form, and pass Y is issue-bound.
+// MODE 0: the field is written and its (min, max) accumulated (ippm_terrain_field).  The episode reset never needs the field
+// itself -- only its threshold bits, and those need the field's (min, max) first -- so it runs the pass twice instead of writing
+// 268 MB and reading them back: MODE 1 accumulates (min, max) and stores nothing, MODE 2 recomputes the rows (bit for bit the
+// same arithmetic) and writes the truth bits (f - min) / (max - min) >= 0.5 straight into the packed plane.
+template <int N1, int N2, int Q, int MODE>
 __global__ __launch_bounds__((FourStep<N1, N2, Q>::THREADS)) void k_terrain_fft_y(const ippm_config* __restrict__ c,
                                                                                const float2* __restrict__ work,
                                                                                float* __restrict__ field,
-                                                                               uint32_t* __restrict__ range_keys) {
+                                                                               uint32_t* __restrict__ range_keys,
+                                                                               const float2* __restrict__ roots1024,
+                                                                               uint32_t* __restrict__ truth32, int truth_words) {
   __shared__ FourStep<N1, N2, Q> fs;
-  const int e = blockIdx.y, gx = c->grid_x, gy = N1 * N2, hy = gy / 2 + 1, x0 = blockIdx.x * Q, tid = threadIdx.x;
-  fs.init_twiddles();
+  const int e = blockIdx.y, gx = c->grid_x, gy = N1 * N2, hy = gy / 2 + 1, x0 = blockIdx.x * 2 * Q, tid = threadIdx.x;
+  fs.init_twiddles(roots1024);
   const int q_in = tid % Q, i2 = tid / Q, k1 = tid % N1, q_out = tid / N1;
   const bool in_active = i2 < N2, out_active = q_out < Q;
   float2 v[N1], o[N2];
@@ -219,21 +272,50 @@ __global__ __launch_bounds__((FourStep<N1, N2, Q>::THREADS)) void k_terrain_fft_
 #pragma unroll
     for (int i1 = 0; i1 < N1; ++i1) {
       const int i = i1 * N2 + i2, m = 2 * i > gy ? gy - i : i;   // bins above gy/2 are the conjugate mirror
-      float2 t = src[(size_t)m * gx];
-      if (2 * i > gy) t.y = -t.y;
-      if (i == 0 || 2 * i == gy) t.y = 0.0f;                     // self-mirrored bins of a real transform
-      v[i1] = t;
+      float2 a = src[(size_t)m * gx], b = src[(size_t)m * gx + Q];
+      if (2 * i > gy) { a.y = -a.y; b.y = -b.y; }
+      if (i == 0 || 2 * i == gy) { a.y = 0.0f; b.y = 0.0f; }     // self-mirrored bins of a real transform
+      v[i1] = make_float2(a.x - b.y, a.y + b.x);                 // A + iB
     }
   }
   fs.run(v, o, q_in, i2, in_active, q_out, k1, out_active);
+  if (MODE == 2) {
+    // threshold and pack: for one k2 a wavefront holds columns k1 + N1 k2 of 64 / N1 rows, i.e. N1 consecutive bits of each of
+    // those rows' bit strings; lane L < 64 / N1 collects row L's chunks into 32-bit words and stores every completed word
+    static_assert(N1 == 8 || N1 == 16 || N1 == 32, "a chunk must not straddle a 32-bit word");
+    const float lo = key_value(range_keys[2 * e]), span = key_value(range_keys[2 * e + 1]) - lo;
+    const int lane = tid & 63, rows_per_wave = 64 / N1;
+    const int my_q = (tid >> 6) * rows_per_wave + lane;          // the row (slot) this lane stores for, if lane < rows_per_wave
+    const bool storer = lane < rows_per_wave && my_q < Q;
+    uint32_t* out = truth32 + (size_t)e * truth_words;
+    const size_t row_a = ((size_t)(x0 + my_q) * gy) >> 5, row_b = ((size_t)(x0 + Q + my_q) * gy) >> 5;
+    uint32_t wa = 0, wb = 0;
+#pragma unroll
+    for (int k2 = 0; k2 < N2; ++k2) {
+      const uint64_t ba = __ballot(out_active && (o[k2].x - lo) / span >= 0.5f);
+      const uint64_t bb = __ballot(out_active && (o[k2].y - lo) / span >= 0.5f);
+      const uint32_t mask = N1 == 32 ? 0xFFFFFFFFu : ((1u << (N1 & 31)) - 1u);
+      const int sh = (k2 * N1) & 31;
+      wa |= ((uint32_t)(ba >> ((N1 * lane) & 63)) & mask) << sh;
+      wb |= ((uint32_t)(bb >> ((N1 * lane) & 63)) & mask) << sh;
+      if (((k2 + 1) * N1) % 32 == 0) {   // (compile time) a word is complete
+        if (storer) { out[row_a + ((k2 * N1) >> 5)] = wa; out[row_b + ((k2 * N1) >> 5)] = wb; }
+        wa = 0; wb = 0;
+      }
+    }
+    return;
+  }
   float lo = INFINITY, hi = -INFINITY;
   if (out_active) {
     float* dst = field + ((size_t)e * gx + x0 + q_out) * gy + k1;
 #pragma unroll
     for (int k2 = 0; k2 < N2; ++k2) {
-      dst[N1 * k2] = o[k2].x;
-      lo = fminf(lo, o[k2].x);
-      hi = fmaxf(hi, o[k2].x);
+      if (MODE == 0) {
+        dst[N1 * k2] = o[k2].x;
+        dst[(size_t)Q * gy + N1 * k2] = o[k2].y;
+      }
+      lo = fminf(lo, fminf(o[k2].x, o[k2].y));
+      hi = fmaxf(hi, fmaxf(o[k2].x, o[k2].y));
     }
   }
   if (range_keys) {   // wavefront, then workgroup reduction; one atomic pair per workgroup
@@ -417,30 +499,56 @@ extern "C" int ippm_terrain_spectrum(ippm_ctx* ctx, const int64_t* episode, cons
   return 0;
 }
 
+static int terrain_launch_x(ippm_ctx* ctx, const int64_t* episode, const float* amp, const float2* spec2, float2* work2,
+                            uint32_t* range_keys, int n_envs, hipStream_t st) {
+  const int gx = ctx->cfg.grid_x, gy = ctx->cfg.grid_y;
+  // generic columns 1 .. gy/2 - 1 in workgroups of Q, then one workgroup for the self-mirrored columns 0 and gy/2
+#define LAUNCH_X(N1, N2, Q)                                                                                                  \
+  {                                                                                                                          \
+    const dim3 grid((gy / 2 - 1 + Q - 1) / Q + 1, n_envs), block(FourStep<N1, N2, Q>::THREADS);                              \
+    if (spec2) IPPM_LAUNCH(ctx, IPPM_T_TERRAIN, (k_terrain_fft_x<N1, N2, Q, false>), grid, block, st, ctx->dcfg, episode, amp, spec2, work2, \
+                           range_keys, ctx->d_roots);                                                                        \
+    else IPPM_LAUNCH(ctx, IPPM_T_TERRAIN, (k_terrain_fft_x<N1, N2, Q, true>), grid, block, st, ctx->dcfg, episode, amp, spec2, work2,        \
+                     range_keys, ctx->d_roots);                                                                              \
+  }
+  TERRAIN_DISPATCH(gx, LAUNCH_X)
+#undef LAUNCH_X
+  IPPM_LAUNCH_CHECK("terrain_fft_x");
+  return 0;
+}
+
+template <int MODE>
+static int terrain_launch_y(ippm_ctx* ctx, const float2* work2, float* field, uint32_t* range_keys, uint8_t* truth, int n_envs,
+                            hipStream_t st) {
+  const int gx = ctx->cfg.grid_x, gy = ctx->cfg.grid_y;
+#define LAUNCH_Y(N1, N2, Q)                                                                                                  \
+  IPPM_LAUNCH(ctx, IPPM_T_TERRAIN, (k_terrain_fft_y<N1, N2, Q, MODE>), dim3(gx / (2 * Q), n_envs), dim3(FourStep<N1, N2, Q>::THREADS), st, \
+              ctx->dcfg, work2, field, range_keys, ctx->d_roots, reinterpret_cast<uint32_t*>(truth), (int)(ippm_truth_bytes(gx, gy) >> 2))
+  TERRAIN_DISPATCH(gy, LAUNCH_Y)
+#undef LAUNCH_Y
+  IPPM_LAUNCH_CHECK("terrain_fft_y");
+  return 0;
+}
+
 extern "C" int ippm_terrain_field(ippm_ctx* ctx, const int64_t* episode, const float* amp, const float* spec, float* work,
                                   float* field, uint32_t* range_keys, int32_t n_envs, void* stream) {
   if (!ctx || !work || !field) { ippm_set_error("ippm_terrain_field: null argument"); return -1; }
   if (!spec && (!episode || !amp)) { ippm_set_error("ippm_terrain_field: needs either spec or (episode, amp)"); return -1; }
   if (terrain_pow2_check(ctx, "ippm_terrain_field")) return -1;
   if (n_envs <= 0) return 0;
-  const int gx = ctx->cfg.grid_x, gy = ctx->cfg.grid_y, hy = gy / 2 + 1;
-  const float2* spec2 = reinterpret_cast<const float2*>(spec);
-  float2* work2 = reinterpret_cast<float2*>(work);
-#define LAUNCH_X(N1, N2, Q)                                                                                                  \
-  if (spec)                                                                                                                  \
-    IPPM_LAUNCH(ctx, IPPM_T_TERRAIN, (k_terrain_fft_x<N1, N2, Q, false>), dim3((hy + Q - 1) / Q, n_envs), dim3(FourStep<N1, N2, Q>::THREADS), \
-                       S_(stream), ctx->dcfg, episode, amp, spec2, work2, range_keys);                                                 \
-  else                                                                                                                       \
-    IPPM_LAUNCH(ctx, IPPM_T_TERRAIN, (k_terrain_fft_x<N1, N2, Q, true>), dim3((hy + Q - 1) / Q, n_envs), dim3(FourStep<N1, N2, Q>::THREADS), \
-                       S_(stream), ctx->dcfg, episode, amp, spec2, work2, range_keys)
-  TERRAIN_DISPATCH(gx, LAUNCH_X)
-#undef LAUNCH_X
-  IPPM_LAUNCH_CHECK("terrain_fft_x");
-#define LAUNCH_Y(N1, N2, Q)                                                                                                  \
-  IPPM_LAUNCH(ctx, IPPM_T_TERRAIN, (k_terrain_fft_y<N1, N2, Q>), dim3(gx / Q, n_envs), dim3(FourStep<N1, N2, Q>::THREADS), S_(stream),   \
-                     ctx->dcfg, (const float2*)work2, field, range_keys)
-  TERRAIN_DISPATCH(gy, LAUNCH_Y)
-#undef LAUNCH_Y
-  IPPM_LAUNCH_CHECK("terrain_fft_y");
-  return 0;
+  if (int rc = terrain_launch_x(ctx, episode, amp, reinterpret_cast<const float2*>(spec), reinterpret_cast<float2*>(work), range_keys, n_envs,
+                                S_(stream))) return rc;
+  return terrain_launch_y<0>(ctx, reinterpret_cast<const float2*>(work), field, range_keys, nullptr, n_envs, S_(stream));
+}
+
+// The episode reset's form: spectrum drawn in pass X, pass Y once for the field's (min, max) and once more for the threshold
+// bits -- the field itself is never stored.
+extern "C" int ippm_terrain_truth(ippm_ctx* ctx, const int64_t* episode, const float* amp, float* work, uint32_t* range_keys,
+                                  uint8_t* truth, int32_t n_envs, void* stream) {
+  if (!ctx || !episode || !amp || !work || !range_keys || !truth) { ippm_set_error("ippm_terrain_truth: null argument"); return -1; }
+  if (terrain_pow2_check(ctx, "ippm_terrain_truth")) return -1;
+  if (n_envs <= 0) return 0;
+  if (int rc = terrain_launch_x(ctx, episode, amp, nullptr, reinterpret_cast<float2*>(work), range_keys, n_envs, S_(stream))) return rc;
+  if (int rc = terrain_launch_y<1>(ctx, reinterpret_cast<const float2*>(work), nullptr, range_keys, nullptr, n_envs, S_(stream))) return rc;
+  return terrain_launch_y<2>(ctx, reinterpret_cast<const float2*>(work), nullptr, range_keys, truth, n_envs, S_(stream));
 }

@@ -99,6 +99,7 @@ PROTOTYPES = {
     "ippm_terrain_spectrum": [P, P, P, P, I32, P],
     "ippm_terrain_field": [P, P, P, P, P, P, P, I32, P],
     "ippm_terrain_pack": [P, P, P, P, I32, P],
+    "ippm_terrain_truth": [P, P, P, P, P, P, I32, P],
     "ippm_area_weights": [I32, I32, P, P, P],
     "ippm_host_philox": [P, P],
     "ippm_host_start_state": [I32, I64, I32, I32, I32, I32, P],

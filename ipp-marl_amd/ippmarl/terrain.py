@@ -9,8 +9,10 @@ it actually flies over.  ``VecEnv.reset(..., terrain="random_field")`` flies ove
 discarded — tests that compare against the oracle hand the generated truth to both sides.
 
 Device work (csrc/terrain.hip): power-of-two grids draw the half spectrum directly and invert it in two hand-written
-LDS passes (``ippm_terrain_field``) — rocFFT's batched 2-D real transforms were 4x slower on this shape; other grid
-sizes (the default 493 x 493) use ``ippm_terrain_noise`` + rocFFT via torch.fft.  ``ippm_terrain_pack`` thresholds.
+LDS passes — rocFFT's batched 2-D real transforms were 4x slower on this shape — the second of them run twice, for the
+field's min / max and for its threshold bits, so that the field is never stored (``ippm_terrain_truth``;
+``ippm_terrain_field`` + ``ippm_terrain_pack`` are the same arithmetic with the field written out); other grid sizes
+(the default 493 x 493) use ``ippm_terrain_noise`` + rocFFT via torch.fft and ``ippm_terrain_pack``.
 """
 from typing import Optional
 
@@ -58,18 +60,18 @@ class RandomFieldTerrain:
         E = episode.numel()
         for lo in range(0, E, self.chunk):
             n = min(self.chunk, E - lo)
-            if self._noise is None or self._noise.shape[0] < n:
-                self._noise = torch.empty(n, gx, gy, dtype=torch.float32, device=self.device)
-            noise = self._noise[:n]
             ep, tr = episode[lo:lo + n], truth[lo:lo + n]
             if self.native:
                 if self._work is None or self._work.shape[0] < n:
                     self._work = torch.empty(n, gy // 2 + 1, gx, 2, dtype=torch.float32, device=self.device)
                     self._keys = torch.empty(n, 2, dtype=torch.int32, device=self.device)
-                self.ctx.call("ippm_terrain_field", _ffi.ptr(ep), _ffi.ptr(self.amp), None, _ffi.ptr(self._work), _ffi.ptr(noise),
-                              _ffi.ptr(self._keys), n, stream)
-                self.ctx.call("ippm_terrain_pack", _ffi.ptr(noise), _ffi.ptr(self._keys), _ffi.ptr(tr), n, stream)
+                # (the field itself is never stored: second pass once for its min / max, once more for the threshold bits)
+                self.ctx.call("ippm_terrain_truth", _ffi.ptr(ep), _ffi.ptr(self.amp), _ffi.ptr(self._work), _ffi.ptr(self._keys), _ffi.ptr(tr),
+                              n, stream)
                 continue
+            if self._noise is None or self._noise.shape[0] < n:
+                self._noise = torch.empty(n, gx, gy, dtype=torch.float32, device=self.device)
+            noise = self._noise[:n]
             self.ctx.call("ippm_terrain_noise", _ffi.ptr(ep), _ffi.ptr(noise), n, stream)
             if self.real_fft:
                 field = torch.fft.irfft2(torch.fft.rfft2(noise) * self.amp, s=(gx, gy))

@@ -311,14 +311,16 @@ def test_random_field_terrain_native_path(name):
     env.ctx.call("ippm_terrain_spectrum", _ffi.ptr(env.episode), _ffi.ptr(amp_dev), _ffi.ptr(spec), E, env.stream)
     S = spec.cpu().numpy().astype(np.float64)
     S = S[..., 0] + 1j * S[..., 1]
-    # a generic bin against the host Philox + Box-Muller; stream word = (stage 1, domain 3)
-    kx, ky = 5, 9
-    w = _ffi.host_philox(kx * hy + ky, int(eps[1]) & 0xFFFFFFFF, (1 << 8) | (3 << 24), int(eps[1]) >> 32, 3, 0)
-    u1, u2 = ((w[0] >> 8) + 1.0) / 2 ** 24, (w[1] >> 8) / 2 ** 24
-    r = np.sqrt(-2.0 * np.log(u1)) * amp[kx, ky]
-    # (the device uses the hardware log2 / sin / cos: a few float32 ulp of the radius off the libm values)
-    np.testing.assert_allclose([S[1, kx, ky].real, S[1, kx, ky].imag], [r * np.cos(2 * np.pi * u2), r * np.sin(2 * np.pi * u2)],
-                               rtol=1e-4, atol=3e-6 * r)
+    # generic bins against the host Philox + Box-Muller; stream word = (stage 1, domain 3).  One call serves two bins: kx and
+    # kx + gx/2 share call (kx mod gx/2) * hy + ky, the lower takes words (0, 1), the upper words (2, 3)
+    for kx, ky in ((5, 9), (gx // 2 + 7, 3), (gx - 1, gy // 2 - 1)):
+        w = _ffi.host_philox((kx % (gx // 2)) * hy + ky, int(eps[1]) & 0xFFFFFFFF, (1 << 8) | (3 << 24), int(eps[1]) >> 32, 3, 0)
+        w1, w2 = (w[0], w[1]) if kx < gx // 2 else (w[2], w[3])
+        u1, u2 = ((w1 >> 8) + 1.0) / 2 ** 24, (w2 >> 8) / 2 ** 24
+        r = np.sqrt(-2.0 * np.log(u1)) * amp[kx, ky]
+        # (the device uses the hardware log2 / sin / cos: a few float32 ulp of the radius off the libm values)
+        np.testing.assert_allclose([S[1, kx, ky].real, S[1, kx, ky].imag], [r * np.cos(2 * np.pi * u2), r * np.sin(2 * np.pi * u2)],
+                                   rtol=1e-4, atol=3e-6 * r)
     # Hermitian structure of the self-mirrored columns; white-noise statistics of the generic bins
     for col in (0, gy // 2):
         assert np.array_equal(S[:, 1:gx // 2, col], np.conj(S[:, :gx // 2:-1, col]))
