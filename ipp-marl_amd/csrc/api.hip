@@ -98,6 +98,7 @@ extern "C" int ippm_ctx_create(const ippm_config* cfg, ippm_ctx** out) {
   ctx->knob_split = knob("IPPM_FUSE_SPLIT", 0);
   ctx->knob_tile_waves = knob("IPPM_TILE_WAVES", 0);
   ctx->knob_plan_builders = knob("IPPM_PLAN_BUILDERS", 0);
+  ctx->knob_k3_dense = knob("IPPM_K3_DENSE", 1);   // 0: the power-of-two lane layout of round 3 (A/B: tools/ab_knobs.py)
   ctx->tiles = (ctx->vec == 4 && c.logit_prior == 0.f && c.grid_x < 32768 && c.grid_y <= 1024 && !knob("IPPM_NO_TILES", 0)) ? 1 : 0;
   int rc = ippm_check_hip(hipMalloc(&ctx->dcfg, sizeof(ippm_config)), "hipMalloc(cfg)");
   if (!rc) rc = ippm_check_hip(hipMemcpy(ctx->dcfg, cfg, sizeof(ippm_config), hipMemcpyHostToDevice), "hipMemcpy(cfg)");

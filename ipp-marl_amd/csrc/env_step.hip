@@ -309,7 +309,7 @@ typedef unsigned ippm_k3_u4 __attribute__((ext_vector_type(4)));
 // are compile-time so that the production instantiation <4, false, false> carries neither the second Philox call and the
 // cell-by-cell tail stores nor the flips resource (the kernel sits at the SGPR limit: every uniform it holds less is a
 // v_writelane / v_readlane pair less in its instruction stream).
-template <int VEC, bool MIS, bool FLIPS, bool REC>
+template <int VEC, bool MIS, bool FLIPS, bool REC, bool DENSE>
 __global__ void __launch_bounds__(256)
 k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int stage, int rows_per_part, int gy, int gx,
               float* __restrict__ local, const uint8_t* __restrict__ truth, const int64_t* __restrict__ episode,
@@ -359,15 +359,26 @@ k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int sta
   const int yu = r[0], yd = r[1], xl = r[2], xr = r[3];
   if (rect_out && part == 0 && threadIdx.x < 4) rect_out[(size_t)(e * n + i) * 4 + threadIdx.x] = r[threadIdx.x];
   const int h = xr - xl, w = yd - yu;
-  const int r0 = part * rows_per_part, r1 = min(h, r0 + rows_per_part);
+  const int y0 = yu & ~(VEC - 1), tile_y0 = yu & ~3;
+  const int groups = (yd - y0 + VEC - 1) / VEC;
+  // DENSE: the three loads of a lane are lane-loads t = q * 64 + lane of the wavefront's rows in row-major order, (row t / W,
+  // group t % W) with W = groups -- a load instruction then covers 64 consecutive groups (2.7 whole 368-byte row segments of a
+  // 15 m footprint) instead of eight 128-byte pieces of eight rows; a wavefront takes floor(192 / W) rows, a part four times that
+  int dense_rpw = 0;
+  unsigned dense_inv = 0;
+  int part_rows = rows_per_part;
+  if (DENSE) {
+    dense_inv = (unsigned)(65536.0f * __builtin_amdgcn_rcpf((float)max(groups, 1))) + 1u;   // floor(t / W) = (t * inv) >> 16 for t <= 192, W <= 192
+    dense_rpw = (int)(((unsigned)(CH * 64) * dense_inv) >> 16);
+    part_rows = 4 * dense_rpw;
+  }
+  const int r0 = part * part_rows, r1 = min(h, r0 + part_rows);
   // the reward of the step whose global fusion ran in the launch before this one: any one thread per env completes it (last:
   // nothing of this launch waits for it)
   if (w <= 0 || r0 >= r1) {
     if (sums && part == 0 && blockIdx.y == 0 && threadIdx.x == 0) ippm_reward_finalize_env(c, sums, reward, e);
     return;
   }
-  const int y0 = yu & ~(VEC - 1), tile_y0 = yu & ~3;
-  const int groups = (yd - y0 + VEC - 1) / VEC;
   constexpr bool mis = MIS;   // rows start at addresses that are only 4-byte aligned
   int shift = 3;
   while (shift < 6 && ((groups + (1 << shift) - 1) >> shift) > CH) ++shift;
@@ -381,20 +392,31 @@ k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int sta
   const __amdgpu_buffer_rsrc_t rflip = IPPM_K3_RSRC(FLIPS ? flips + (size_t)(e * n + i) * TB : code, FLIPS ? TB : 0);
   const uint32_t sw = ippm_stream_word((uint32_t)i, (uint32_t)stage, IPPM_DOMAIN_FLIP);
   float amax = 0.f;
-  for (int gbase = 0; gbase < groups; gbase += CH * lpr) {     // one trip unless the footprint is wider than 3 x 64 groups
-    for (int row = r0 + wv * rpw + sub; row < r1; row += 4 * rpw) {  // one trip for rows_per_part = 4 * rpw
-      const int x = xl + row;
+  for (int gbase = 0; gbase < (DENSE ? 1 : groups); gbase += CH * lpr) {     // one trip unless the footprint is wider than 3 x 64 groups
+    for (int row0 = r0 + wv * (DENSE ? dense_rpw : rpw) + (DENSE ? 0 : sub); row0 < r1; row0 += 4 * rpw) {  // one trip for the common footprints
       CellVec<VEC> m[CH];
       uint32_t tw[CH], fw[CH];
-      int cellv[CH];
+      int cellv[CH], rowv[CH], yv[CH];
       bool on[CH];
 #pragma unroll
       for (int q = 0; q < CH; ++q) {
-        const int gidx = gbase + gl + q * lpr;
-        on[q] = gidx < groups;
-        const int y = y0 + gidx * VEC;
+        int row, y;
+        if (DENSE) {
+          const unsigned t = (unsigned)(q * 64 + lane);
+          const int rr = (int)((t * dense_inv) >> 16);
+          const int gi = (int)t - rr * groups;
+          row = row0 + rr;
+          on[q] = rr < dense_rpw && row < r1;
+          y = y0 + gi * VEC;
+        } else {
+          const int gidx = gbase + gl + q * lpr;
+          on[q] = gidx < groups;
+          row = row0;
+          y = y0 + gidx * VEC;
+        }
+        const int x = xl + row;
         const int cell = x * gy + y;
-        cellv[q] = cell;
+        cellv[q] = cell; rowv[q] = row; yv[q] = y;
         if (VEC == 4) {
           const ippm_k3_u4 t = __builtin_amdgcn_raw_buffer_load_b128(rmap, on[q] ? cell * 4 : IPPM_K3_OOB, 0, IPPM_K3_LOAD_AUX);
           m[q].v[0] = __uint_as_float(t.x); m[q].v[1 % VEC] = __uint_as_float(t.y);
@@ -410,12 +432,13 @@ k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int sta
       }
 #pragma unroll
       for (int q = 0; q < CH; ++q) {
-        if (gbase + q * lpr >= groups) continue;   // wave-uniform: narrow footprints use one or two of the three passes
-        const int gidx = gbase + gl + q * lpr;
-        int y = y0 + gidx * VEC;
+        // wave-uniform: narrow footprints use one or two of the three passes
+        if (DENSE ? (q * 64 >= dense_rpw * groups) : (gbase + q * lpr >= groups)) continue;
+        int y = yv[q];
         // (the column masks below do not depend on the row: left alone they are hoisted in front of the loads, ~60 instructions
         // between the wavefront's start and its first memory request)
         asm volatile("" : "+v"(y));
+        const int row = rowv[q];
         const int cell = cellv[q];
         const uint32_t tbits = VEC == 4 ? (tw[q] >> (cell & 7)) & 0xFu : (tw[q] >> (cell & 7)) & 1u;
         uint32_t flipbits;
@@ -460,6 +483,7 @@ k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int sta
         }
         __builtin_amdgcn_raw_buffer_store_b8((unsigned char)obs, rcode, on[q] ? (int)tile_index<VEC>(row, y - tile_y0, S) : IPPM_K3_OOB, 0, 0);
       }
+      if (DENSE) break;   // (a part is exactly one trip of its four wavefronts)
     }
   }
   if (ws && __any(amax > lc) && lane == 0) ws[(size_t)(e * (n + 1) + i) * IPPM_WS_WORDS + WS_FLAG_S] = 1;
@@ -765,22 +789,36 @@ extern "C" int ippm_sense_step(ippm_ctx* ctx, const int64_t* episode, const int3
     int h_max = 1;
     for (int k = 0; k < c.space_z; ++k) h_max = std::max(h_max, 2 * c.radius_x[k]);
     const int rows_per_part = std::max(4, env_int("IPPM_K3_ROWS", 32));
-    const int parts = (h_max + rows_per_part - 1) / rows_per_part;
+    int parts = (h_max + rows_per_part - 1) / rows_per_part;
+    // dense lane mapping (k_sense_tiles<..., DENSE>): a part is 4 * floor(192 / W) rows, W = the footprint's 4-cell groups (one
+    // more than its width needs when it starts off a group boundary); every altitude must get at least two rows per wavefront
+    bool dense = ctx->vec == 4 && ctx->knob_k3_dense != 0;
+    if (dense) {
+      int need = 1;
+      for (int k = 0; k < c.space_z; ++k) {
+        const int wmax = (2 * c.radius_y[k] + 3) / 4 + 1, rpw = 192 / std::max(1, wmax);
+        if (rpw < 2) { dense = false; break; }
+        need = std::max(need, (2 * c.radius_x[k] + 4 * rpw - 1) / (4 * rpw));
+      }
+      if (dense) parts = need;
+    }
     if (n_envs > 65535) { ippm_set_error("ippm_sense_step: more than 65535 envs per launch"); return -1; }
     dim3 grid((unsigned)parts, (unsigned)(agent_sel >= 0 ? 1 : c.n_agents), (unsigned)n_envs);
     int32_t* rect_out = rect_in == rect ? nullptr : rect;
-#define IPPM_K3T_(V, M, F, R)                                                                                               \
-  IPPM_LAUNCH(ctx, IPPM_T_SENSE, (k_sense_tiles<V, M, F, R>), grid, block, S_(stream), rect_in, c.n_agents, agent_sel, stage, rows_per_part, \
+#define IPPM_K3T__(V, M, F, R, D)                                                                                           \
+  IPPM_LAUNCH(ctx, IPPM_T_SENSE, (k_sense_tiles<V, M, F, R, D>), grid, block, S_(stream), rect_in, c.n_agents, agent_sel, stage, rows_per_part, \
               c.grid_y, c.grid_x, local, truth, episode, code, c.tile_stride, c.logit_clip, (uint32_t)c.philox_seed,                 \
               (uint32_t)(c.philox_seed >> 32), ctx->dcfg, pos, flips, rect_out, ws, sums, reward, ctx->dcounters)
+#define IPPM_K3T_(V, M, F, R) do { if (dense) IPPM_K3T__(V, M, F, R, true); else IPPM_K3T__(V, M, F, R, false); } while (0)
 #define IPPM_K3T(V, M, F) do { if (rect_in) IPPM_K3T_(V, M, F, true); else IPPM_K3T_(V, M, F, false); } while (0)
     const bool mis = (c.grid_y & 3) != 0;
     if (ctx->vec == 4) {
       if (flips) { if (mis) IPPM_K3T(4, true, true); else IPPM_K3T(4, false, true); }
       else { if (mis) IPPM_K3T(4, true, false); else IPPM_K3T(4, false, false); }
     } else {
-      if (flips) IPPM_K3T(1, false, true); else IPPM_K3T(1, false, false);
+      if (flips) IPPM_K3T__(1, false, true, false, false); else IPPM_K3T__(1, false, false, false, false);
     }
+#undef IPPM_K3T__
 #undef IPPM_K3T_
 #undef IPPM_K3T
     IPPM_LAUNCH_CHECK("sense_tiles");

@@ -56,7 +56,7 @@ struct ippm_ctx {
   int vec;                   // 4: 16-byte lane groups (grid_y >= 44), else 1
   // tuning knobs, resolved ONCE at ippm_ctx_create (the work buffer's size, the plan kernel's item layout and the fusion launch
   // all derive from them and must agree for the context's lifetime)
-  int knob_wave_rows, knob_persist, knob_nowork, knob_split, knob_tile_waves, knob_plan_builders;
+  int knob_wave_rows, knob_persist, knob_nowork, knob_split, knob_tile_waves, knob_plan_builders, knob_k3_dense;
   float2* d_roots;           // e^{2 pi i k / 1024}, k = 0..1023: the twiddle table of the terrain transforms (terrain.hip)
   int tiles;                 // the config can take the one-trip tile form of the fusion (16-byte lane groups, prior 0.5)
   // kernel timing (ippm_kernel_timing): per kernel class a pool of event pairs attached to the dispatches themselves

@@ -745,7 +745,7 @@ def test_kernel_timing_reports_dispatch_durations():
     env.steps(6, policy=POLICY_UNIFORM, features=False)          # not timed
     times = env.event_times_us()
     assert {"sense", "fuse", "plan"} <= set(times)
-    for cls, kernel in (("sense", "k_sense_tiles<4, false, false, true>"), ("fuse", "k_fuse_tiles<6, false>"), ("plan", "k_plan_step")):
+    for cls, kernel in (("sense", "k_sense_tiles<4, false, false, true, true>"), ("fuse", "k_fuse_tiles<6, false>"), ("plan", "k_plan_step")):
         rec = times[cls]
         assert rec["launches"] == 5 and rec["kernel"] == kernel, (cls, rec)
         assert 1.0 < rec["min_us"] <= rec["avg_us"] < 2000.0, (cls, rec)
