@@ -67,7 +67,7 @@ extern "C" {
 #define IPPM_STEP_COMM 1   /* comm matrix + local-fusion plans */
 #define IPPM_STEP_GLOBAL 2 /* global-fusion plan */
 #define IPPM_STEP_MOVE 4   /* K1 mask/act/move (+ footprints of the new positions) */
-#define IPPM_STEP_TILES 8  /* write the work list as one-trip tile items (for ippm_fuse_step WITHOUT area sums) */
+#define IPPM_STEP_TILES 8  /* write the work list as one-trip tile items (ippm_fuse_step on a context that has the tile form) */
 #define IPPM_SENSE_REC_WORDS 8  /* words per agent of ippm_plan_step's rect_next / ippm_sense_step's rect_in */
 
 /* Derived constants, computed on the host in float64 with the reference's expression order

@@ -309,14 +309,15 @@ typedef unsigned ippm_k3_u4 __attribute__((ext_vector_type(4)));
 // are compile-time so that the production instantiation <4, false, false> carries neither the second Philox call and the
 // cell-by-cell tail stores nor the flips resource (the kernel sits at the SGPR limit: every uniform it holds less is a
 // v_writelane / v_readlane pair less in its instruction stream).
-template <int VEC, bool MIS, bool FLIPS, bool REC, bool DENSE>
+template <int VEC, bool MIS, bool FLIPS, bool REC, bool DENSE, bool TRACK>
 __global__ void __launch_bounds__(256)
 k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int stage, int rows_per_part, int gy, int gx,
               float* __restrict__ local, const uint8_t* __restrict__ truth, const int64_t* __restrict__ episode,
               uint8_t* __restrict__ code, int S_arg, float lc_arg, uint32_t k0_arg, uint32_t k1_arg,
               const ippm_config* __restrict__ c, const int32_t* __restrict__ pos,
               const uint8_t* __restrict__ flips, int32_t* __restrict__ rect_out, int32_t* __restrict__ ws,
-              double* __restrict__ sums, float* __restrict__ reward, unsigned long long* __restrict__ counters) {
+              double* __restrict__ sums, float* __restrict__ reward, unsigned long long* __restrict__ counters,
+              double* __restrict__ area) {
   // Argument order = latency order.  A workgroup lives for one trip, so what stands in front of its map loads is paid by every
   // wavefront: with the config fields behind the config pointer behind the kernel-argument load, the footprint came in three
   // dependent scalar round trips.  The first 14 argument words arrive in SGPRs with the wavefront (kernel-argument preload,
@@ -378,6 +379,16 @@ k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int sta
   if (w <= 0 || r0 >= r1) {
     if (sums && part == 0 && blockIdx.y == 0 && threadIdx.x == 0) ippm_reward_finalize_env(c, sums, reward, e);
     return;
+  }
+  // TRACK: the map's 11 x 11 area sums (K6's view of it, ippm_tiles.h) follow the cells this workgroup changes: weighted sigmoid
+  // differences into a 12 x 12 float64 tile in LDS, one global atomic per touched bin at the end
+  __shared__ double s_area[TRACK ? (IPPM_FEAT + 1) * IPPM_AREA_LD : 1];
+  float inv_gx = 0.f, inv_gy = 0.f;
+  if (TRACK) {
+    area_lds_clear(s_area);
+    inv_gx = __builtin_amdgcn_rcpf((float)gx);
+    inv_gy = __builtin_amdgcn_rcpf((float)gy);
+    __syncthreads();
   }
   constexpr bool mis = MIS;   // rows start at addresses that are only 4-byte aligned
   int shift = 3;
@@ -457,6 +468,7 @@ k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int sta
         for (int j = 0; j < VEC; ++j) inm |= ((unsigned)(y + j - yu) < (unsigned)w) ? (1u << j) : 0u;
         const uint32_t obs = (tbits ^ flipbits) & inm;
         // mappings.py:109-124 in log-odds: clip the prior belief, add the measurement's log-odds (minus logit(prior))
+        float dsig[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
           const float old = m[q].v[j];
@@ -464,6 +476,22 @@ k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int sta
           const uint32_t im = ippm_bitmask(inm, j);
           m[q].v[j] = ippm_blend(im, l, old);
           amax = fmaxf(amax, fabsf(ippm_masked(im, l)));
+          if (TRACK) dsig[j] = sigmoid_diff(m[q].v[j], old);   // (exactly 0 for the cells outside the footprint's columns)
+        }
+        if (TRACK && VEC == 4 && on[q]) {
+          float sd = 0.f, cA = 0.f;
+          const AreaCols<VEC> ac = area_cols<VEC>(y, gy, inv_gy);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) { sd += dsig[j]; cA += ac.wA[j] * dsig[j]; }
+          const float cB = 11.f * sd - cA;
+          const int n11 = 11 * (xl + row), rb = area_bin(n11, inv_gx);
+          const float nA = (float)min((rb + 1) * gx - n11, 11), nB = 11.f - nA;
+          double* pa = s_area + rb * IPPM_AREA_LD + ac.cb;
+          const float v00 = nA * cA, v01 = nA * cB, v10 = nB * cA, v11 = nB * cB;
+          if (v00 != 0.f) atomicAdd(pa, (double)v00);
+          if (v01 != 0.f) atomicAdd(pa + 1, (double)v01);
+          if (v10 != 0.f) atomicAdd(pa + IPPM_AREA_LD, (double)v10);
+          if (v11 != 0.f) atomicAdd(pa + IPPM_AREA_LD + 1, (double)v11);
         }
         const int off = on[q] ? cell * 4 : IPPM_K3_OOB;
         if (VEC == 4) {
@@ -490,6 +518,10 @@ k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int sta
   if (counters && part == 0 && threadIdx.x == 0)
     atomicAdd(&counters[(tile & (IPPM_COUNTER_SLOTS - 1)) * 8 + 0], (unsigned long long)h * w);
   if (sums && part == 0 && blockIdx.y == 0 && threadIdx.x == 0) ippm_reward_finalize_env(c, sums, reward, e);
+  if (TRACK) {
+    __syncthreads();
+    area_lds_commit(s_area, area + (size_t)(e * (n + 1) + i) * IPPM_FEAT * IPPM_FEAT);
+  }
 }
 
 
@@ -783,8 +815,9 @@ extern "C" int ippm_sense_step(ippm_ctx* ctx, const int64_t* episode, const int3
   const int maps = agent_sel >= 0 ? n_envs : n_envs * ctx->cfg.n_agents;
   const int tail = sums ? grid1(n_envs) : 0;
   dim3 block(256);
-  if (!area && !env_int("IPPM_K3_CLASSIC", 0)) {
-    // tile form: one trip per workgroup for the common footprints (rows_per_part = 4 wavefronts x 8 rows)
+  if ((!area || ctx->vec == 4) && !env_int("IPPM_K3_CLASSIC", 0)) {
+    // tile form: one trip per workgroup for the common footprints (rows_per_part = 4 wavefronts x 8 rows); with the area sums
+    // tracked in its TRACK instantiation (16-byte layout only: k_sense_update below keeps the narrow grids)
     const ippm_config& c = ctx->cfg;
     int h_max = 1;
     for (int k = 0; k < c.space_z; ++k) h_max = std::max(h_max, 2 * c.radius_x[k]);
@@ -805,10 +838,11 @@ extern "C" int ippm_sense_step(ippm_ctx* ctx, const int64_t* episode, const int3
     if (n_envs > 65535) { ippm_set_error("ippm_sense_step: more than 65535 envs per launch"); return -1; }
     dim3 grid((unsigned)parts, (unsigned)(agent_sel >= 0 ? 1 : c.n_agents), (unsigned)n_envs);
     int32_t* rect_out = rect_in == rect ? nullptr : rect;
-#define IPPM_K3T__(V, M, F, R, D)                                                                                           \
-  IPPM_LAUNCH(ctx, IPPM_T_SENSE, (k_sense_tiles<V, M, F, R, D>), grid, block, S_(stream), rect_in, c.n_agents, agent_sel, stage, rows_per_part, \
+#define IPPM_K3T___(V, M, F, R, D, T)                                                                                       \
+  IPPM_LAUNCH(ctx, IPPM_T_SENSE, (k_sense_tiles<V, M, F, R, D, T>), grid, block, S_(stream), rect_in, c.n_agents, agent_sel, stage, rows_per_part, \
               c.grid_y, c.grid_x, local, truth, episode, code, c.tile_stride, c.logit_clip, (uint32_t)c.philox_seed,                 \
-              (uint32_t)(c.philox_seed >> 32), ctx->dcfg, pos, flips, rect_out, ws, sums, reward, ctx->dcounters)
+              (uint32_t)(c.philox_seed >> 32), ctx->dcfg, pos, flips, rect_out, ws, sums, reward, ctx->dcounters, area)
+#define IPPM_K3T__(V, M, F, R, D) do { if (area) IPPM_K3T___(V, M, F, R, D, true); else IPPM_K3T___(V, M, F, R, D, false); } while (0)
 #define IPPM_K3T_(V, M, F, R) do { if (dense) IPPM_K3T__(V, M, F, R, true); else IPPM_K3T__(V, M, F, R, false); } while (0)
 #define IPPM_K3T(V, M, F) do { if (rect_in) IPPM_K3T_(V, M, F, true); else IPPM_K3T_(V, M, F, false); } while (0)
     const bool mis = (c.grid_y & 3) != 0;
@@ -816,8 +850,9 @@ extern "C" int ippm_sense_step(ippm_ctx* ctx, const int64_t* episode, const int3
       if (flips) { if (mis) IPPM_K3T(4, true, true); else IPPM_K3T(4, false, true); }
       else { if (mis) IPPM_K3T(4, true, false); else IPPM_K3T(4, false, false); }
     } else {
-      if (flips) IPPM_K3T__(1, false, true, false, false); else IPPM_K3T__(1, false, false, false, false);
+      if (flips) IPPM_K3T___(1, false, true, false, false, false); else IPPM_K3T___(1, false, false, false, false, false);
     }
+#undef IPPM_K3T___
 #undef IPPM_K3T__
 #undef IPPM_K3T_
 #undef IPPM_K3T

@@ -612,9 +612,10 @@ extern "C" int ippm_fuse_global_reward(ippm_ctx* ctx, float* global, const uint8
 extern "C" int ippm_fuse_step(ippm_ctx* ctx, float* local, float* global, const uint8_t* code, int32_t* ws, double* sums,
                               double* area, const int32_t* work, int32_t n_envs, void* stream) {
   if (!ctx || !local || !global || !code || !ws || !sums) { ippm_set_error("ippm_fuse_step: null argument"); return -1; }
-  // without area sums the work list may be in the one-trip tile form (ippm_plan_step with IPPM_STEP_TILES): fuse_tiles.hip
-  if (!area && work && ctx->tiles && !ctx->knob_nowork && !ctx->knob_split)
-    return ippm_launch_fuse_tiles(ctx, local, global, code, ws, sums, work, n_envs, S_(stream));
+  // the work list may be in the one-trip tile form (ippm_plan_step with IPPM_STEP_TILES): fuse_tiles.hip; a list of the other
+  // form is skipped and counted by whichever kernel is handed it
+  if (work && ctx->tiles && !ctx->knob_nowork && !ctx->knob_split)
+    return ippm_launch_fuse_tiles(ctx, local, global, code, ws, sums, area, work, n_envs, S_(stream));
   if (ctx->knob_split) {  // measurement aid: K4 and K5 as two launches, so that a kernel trace shows them apart
     if (int rc = launch_fuse(ctx, local, global, code, ws, sums, area, nullptr, n_envs * ctx->cfg.n_agents, 0, -1, n_envs, S_(stream))) return rc;
     return launch_fuse(ctx, local, global, code, ws, sums, area, nullptr, 0, n_envs, -1, n_envs, S_(stream));

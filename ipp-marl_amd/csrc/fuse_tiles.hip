@@ -44,7 +44,49 @@ struct TileCtx {
   int n, gx, gy, row_bytes, TB, n_envs;
   float lc, wt;
   int lane;
+  // TRACK: the 11 x 11 area sums of the maps (ippm_tiles.h) are kept up to date: a 12 x 12 float64 tile in LDS per wavefront,
+  // flushed to the item's map with one global atomic per touched bin when the item is done
+  double* s_area;
+  double* area;
+  float inv_gx, inv_gy;
 };
+
+// The item's contribution to the area sums of its map: per lane-load the weighted sigmoid differences of its four cells into
+// the (at most) 2 x 2 bins the group meets.  `old4` / `new4`: the cells as loaded and as stored (a lane-load past the item's
+// end loaded zeros and stores nothing: zero difference).
+__device__ __forceinline__ void tile_area_slot(const TileCtx& w, int x, int y, const float* old4, const float* new4) {
+  float d[4], sd = 0.f, cA = 0.f;
+  const AreaCols<4> ac = area_cols<4>(y, w.gy, w.inv_gy);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    d[j] = sigmoid_diff(new4[j], old4[j]);
+    sd += d[j];
+    cA += ac.wA[j] * d[j];
+  }
+  const float cB = 11.f * sd - cA;
+  const int n11 = 11 * x, rb = area_bin(n11, w.inv_gx);
+  const float nA = (float)min((rb + 1) * w.gx - n11, 11), nB = 11.f - nA;
+  double* p = w.s_area + rb * IPPM_AREA_LD + ac.cb;
+  const float v00 = nA * cA, v01 = nA * cB, v10 = nB * cA, v11 = nB * cB;
+  if (v00 != 0.f) atomicAdd(p, (double)v00);                       // ds_add_f64
+  if (v01 != 0.f) atomicAdd(p + 1, (double)v01);
+  if (v10 != 0.f) atomicAdd(p + IPPM_AREA_LD, (double)v10);
+  if (v11 != 0.f) atomicAdd(p + IPPM_AREA_LD + 1, (double)v11);
+}
+// (a workgroup is one wavefront: __syncthreads() is the LDS ordering point between the atomics above and the reads here)
+__device__ __forceinline__ void tile_area_flush(const TileCtx& w, int map_abs) {
+  __syncthreads();
+  double* dst = w.area + (size_t)map_abs * IPPM_FEAT * IPPM_FEAT;
+  for (int k = w.lane; k < IPPM_FEAT * IPPM_AREA_LD; k += 64) {
+    const double v = w.s_area[k];
+    const int rb = k / IPPM_AREA_LD, cb = k - rb * IPPM_AREA_LD;
+    if (v != 0.0) {
+      if (cb < IPPM_FEAT) atomicAdd(&dst[rb * IPPM_FEAT + cb], v);
+      w.s_area[k] = 0.0;
+    }
+  }
+  __syncthreads();
+}
 
 struct TileAcc {   // per wavefront, over all its items (all of one env)
   // sum w(a) (H(b) - H(a)) and sum (w(a) - w(b)) H(b); the increment of T = sum w H is aD - a1.  float64 per lane, fed with the
@@ -55,7 +97,7 @@ struct TileAcc {   // per wavefront, over all its items (all of one env)
 };
 
 // One item with at most NA ops (spare slots first) and SLOTS loads in flight per lane.
-template <int NA, int SLOTS, bool MIS>
+template <int NA, int SLOTS, bool MIS, bool TRACK>
 __device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e, int slot, int x0, int nr, int g0, int W, unsigned active) {
   const int map_abs = e * (w.n + 1) + slot;
   const bool is_global = slot == w.n;
@@ -203,6 +245,7 @@ __device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e,
         __builtin_amdgcn_raw_buffer_store_b128(v, rmap, off[q], 0, IPPM_T_STORE_AUX);
       }
     }
+    if (TRACK) tile_area_slot(w, x0 + (int)(((unsigned)(q * 64 + w.lane) * inv) >> 16), ycol[q] == IPPM_T_FAR ? 0 : ycol[q], mv[q].v, out);
     if (is_global) {
       // information-gain terms (utils/reward.py:68-82) of the cells the step changed; an untouched cell contributes exact zeros
       // (same weight, same entropy).  Slots whose touched cells all have weight 0 before and after (believed free, still
@@ -229,6 +272,7 @@ __device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e,
     }
   }
   if (__any(amax > w.lc) && w.lane == 0) w.ws[(size_t)map_abs * IPPM_WS_WORDS + WS_FLAG_A] = 1;
+  if (TRACK) tile_area_flush(w, map_abs);
   if (is_global) { acc.cells_g += cells; acc.ops_g += opcells; }
   else { acc.cells_l += cells; acc.ops_l += opcells; }
 }
@@ -239,12 +283,12 @@ __device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e,
 #ifndef IPPM_TILE_WAVES_PER_EU
 #define IPPM_TILE_WAVES_PER_EU 5
 #endif
-template <int NAMAX, bool MIS>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NAMAX <= 6 && !MIS ? 6 : IPPM_TILE_WAVES_PER_EU, 8)))
+template <int NAMAX, bool MIS, bool TRACK>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NAMAX <= 6 && !MIS && !TRACK ? 6 : (TRACK ? 4 : IPPM_TILE_WAVES_PER_EU), 8)))
 k_fuse_tiles(const int32_t* __restrict__ work, int n_envs, int env_cap, int n, int gx, int gy, int row_bytes, int TB, float lc, float wt,
              const int32_t* __restrict__ plan_ro, float* __restrict__ local, float* __restrict__ global,
              const uint8_t* __restrict__ code, int32_t* __restrict__ ws, double* __restrict__ sums,
-             unsigned long long* __restrict__ counters) {
+             unsigned long long* __restrict__ counters, double* __restrict__ area) {
   // (argument order = latency order, as in k_sense_tiles: the work list's address and sizes arrive in SGPRs with the wavefront,
   // every config scalar by value -- the count and the first item are one scalar round trip away, the first item's cells two)
   const int env = blockIdx.x, first = blockIdx.y, step = gridDim.y;   // consecutive workgroups = consecutive envs
@@ -262,7 +306,15 @@ k_fuse_tiles(const int32_t* __restrict__ work, int n_envs, int env_cap, int n, i
   }
   const int count = tag & IPPM_WORK_COUNT;
   if (first >= count) return;
+  __shared__ double s_area[TRACK ? IPPM_FEAT * IPPM_AREA_LD + IPPM_AREA_LD : 1];
+  if (TRACK) {
+    for (int k = lane; k < IPPM_FEAT * IPPM_AREA_LD + IPPM_AREA_LD; k += 64) s_area[k] = 0.0;
+    __syncthreads();
+  }
   TileCtx w;
+  w.s_area = s_area; w.area = area;
+  w.inv_gx = TRACK ? __builtin_amdgcn_rcpf((float)gx) : 0.f;
+  w.inv_gy = TRACK ? __builtin_amdgcn_rcpf((float)gy) : 0.f;
   w.local = local; w.global = global; w.code = code; w.plan = plan_ro; w.ws = ws;
   w.n = n; w.gx = gx; w.gy = gy;
   w.row_bytes = row_bytes;
@@ -278,15 +330,15 @@ k_fuse_tiles(const int32_t* __restrict__ work, int n_envs, int env_cap, int n, i
     const int slot = (unsigned)it.w >> 24, x0 = it.y & 0xFFFF, nr = it.y >> 16, g0 = it.z & 0xFFFF, W = it.z >> 16;
     const unsigned active = (unsigned)it.w & 0x00FFFFFFu;
     const int na = __popc(active);
-    if (na == 1) tile_item<1, 4, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
-    else if (na == 2) tile_item<2, 4, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
-    else if (na == 3) tile_item<3, 4, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
-    else if (na == 4) tile_item<4, 4, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
-    else if (NAMAX <= 6 || na <= 6) tile_item<(NAMAX < 6 ? NAMAX : 6), IPPM_TILE_SLOTS_MID, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
-    else if (na <= 8) tile_item<8, IPPM_TILE_SLOTS_MID, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
-    else if (NAMAX <= 10 || na <= 10) tile_item<10, 2, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
-    else if (na <= 14) tile_item<14, 1, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
-    else tile_item<18, 1, MIS>(w, acc, env, slot, x0, nr, g0, W, active);
+    if (na == 1) tile_item<1, 4, MIS, TRACK>(w, acc, env, slot, x0, nr, g0, W, active);
+    else if (na == 2) tile_item<2, 4, MIS, TRACK>(w, acc, env, slot, x0, nr, g0, W, active);
+    else if (na == 3) tile_item<3, 4, MIS, TRACK>(w, acc, env, slot, x0, nr, g0, W, active);
+    else if (na == 4) tile_item<4, 4, MIS, TRACK>(w, acc, env, slot, x0, nr, g0, W, active);
+    else if (NAMAX <= 6 || na <= 6) tile_item<(NAMAX < 6 ? NAMAX : 6), IPPM_TILE_SLOTS_MID, MIS, TRACK>(w, acc, env, slot, x0, nr, g0, W, active);
+    else if (na <= 8) tile_item<8, IPPM_TILE_SLOTS_MID, MIS, TRACK>(w, acc, env, slot, x0, nr, g0, W, active);
+    else if (NAMAX <= 10 || na <= 10) tile_item<10, 2, MIS, TRACK>(w, acc, env, slot, x0, nr, g0, W, active);
+    else if (na <= 14) tile_item<14, 1, MIS, TRACK>(w, acc, env, slot, x0, nr, g0, W, active);
+    else tile_item<18, 1, MIS, TRACK>(w, acc, env, slot, x0, nr, g0, W, active);
     it = nx;
   }
   // the wavefront's reward terms and work counters: one atomic per quantity
@@ -309,7 +361,7 @@ k_fuse_tiles(const int32_t* __restrict__ work, int n_envs, int env_cap, int n, i
 
 // ippm_fuse_step without area sums on a config that has the tile form (ippm_ctx::tiles); `work` must have been written by
 // ippm_plan_step with IPPM_STEP_TILES.
-int ippm_launch_fuse_tiles(ippm_ctx* ctx, float* local, float* global, const uint8_t* code, int32_t* ws, double* sums,
+int ippm_launch_fuse_tiles(ippm_ctx* ctx, float* local, float* global, const uint8_t* code, int32_t* ws, double* sums, double* area,
                            const int32_t* work, int n_envs, hipStream_t st) {
   const ippm_config& c = ctx->cfg;
   const int max_ops = c.n_agents + 1;
@@ -322,14 +374,16 @@ int ippm_launch_fuse_tiles(ippm_ctx* ctx, float* local, float* global, const uin
   // a launch smaller than the chip's wave slots leaves CUs idle: small batches take more wavefronts per env
   while ((long long)per_env * n_envs < 16384 && per_env * 2 <= env_cap && per_env < 256) per_env *= 2;
   dim3 grid((unsigned)n_envs, (unsigned)per_env), block(64);
-#define IPPM_FT(NA, M) \
-  IPPM_LAUNCH(ctx, IPPM_T_FUSE, (k_fuse_tiles<NA, M>), grid, block, st, work, n_envs, env_cap, c.n_agents, c.grid_x, c.grid_y, c.tile_stride >> 2, \
-              (int)ippm_tile_bytes(c.tile_stride, 4), c.logit_clip, c.logit_weight_thr, ws, local, global, code, ws, sums, ctx->dcounters)
+#define IPPM_FT_(NA, M, T) \
+  IPPM_LAUNCH(ctx, IPPM_T_FUSE, (k_fuse_tiles<NA, M, T>), grid, block, st, work, n_envs, env_cap, c.n_agents, c.grid_x, c.grid_y, c.tile_stride >> 2, \
+              (int)ippm_tile_bytes(c.tile_stride, 4), c.logit_clip, c.logit_weight_thr, ws, local, global, code, ws, sums, ctx->dcounters, area)
+#define IPPM_FT(NA, M) do { if (area) IPPM_FT_(NA, M, true); else IPPM_FT_(NA, M, false); } while (0)
   const bool mis = (c.grid_y & 3) != 0;   // rows only 4-byte aligned: the instantiation with the cell-by-cell row-tail stores
   if (max_ops <= 6) { if (mis) IPPM_FT(6, true); else IPPM_FT(6, false); }
   else if (max_ops <= 10) { if (mis) IPPM_FT(10, true); else IPPM_FT(10, false); }
   else { if (mis) IPPM_FT(18, true); else IPPM_FT(18, false); }
 #undef IPPM_FT
+#undef IPPM_FT_
   IPPM_LAUNCH_CHECK("fuse_tiles");
   return 0;
 }

@@ -88,8 +88,8 @@ int ippm_work_env_cap(const ippm_ctx* ctx, int n_envs);    // items an env's sli
 // The tile form of the list (IPPM_STEP_TILES; fuse_tiles.hip): [E] counts tagged IPPM_WORK_TILED, then from word (E + 3) & ~3 on
 // [E][cap] items of 4 words {env, x0 | rows << 16, first group | groups << 16, op mask | map slot << 24}, cap = ippm_tile_env_cap().
 int ippm_tile_env_cap(const ippm_ctx* ctx);
-int ippm_launch_fuse_tiles(ippm_ctx* ctx, float* local, float* global, const uint8_t* code, int32_t* ws, double* sums,
-                           const int32_t* work, int n_envs, hipStream_t st);   // fuse_tiles.hip
+int ippm_launch_fuse_tiles(ippm_ctx* ctx, float* local, float* global, const uint8_t* code, int32_t* ws, double* sums, double* area,
+                           const int32_t* work, int n_envs, hipStream_t st);   // fuse_tiles.hip (area != nullptr: area sums tracked)
 #define IPPM_WORK_TILED 0x40000000     // tag of a count written in the tile form (a kernel of the other form skips the list)
 #define IPPM_WORK_OVERFLOW 0x20000000  // the env's items did not fit (never, by the bound of ippm_tile_env_cap)
 #define IPPM_WORK_COUNT 0x0FFFFFFF

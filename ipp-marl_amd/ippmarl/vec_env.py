@@ -91,7 +91,7 @@ class VecEnv:
         self.work = z(int(words[0]), dtype=torch.int32)
         yes = np.zeros(1, dtype=np.int32)
         self.ctx.call("ippm_tile_form", yes.ctypes.data)
-        self._tile_form = bool(yes[0])   # the fusion without area sums runs in one-trip tile items (16-byte layout, prior 0.5)
+        self._tile_form = bool(yes[0])   # the fusion runs in one-trip tile items (16-byte layout, prior 0.5), area sums tracked or not
         # 11x11 area sums of every map (slot N = global): the input of the K6 feature builders.  track_area=True: K3 / K4 /
         # K5 keep them up to date as they write maps (the batched training path); False: rebuilt by a streaming pass right
         # before the features are needed (env-only stepping never needs them; the single-env drop-in engine, whose maps
@@ -311,8 +311,8 @@ class VecEnv:
                       self._p(self.comm), self._p(self.ws), agent, self.E, self.stream)
 
     def _plan_step(self, t: int, flags: int, comm_draws=None, policy: int = 0, probs=None, actions=None):
-        if not self.track_area and flags & (_ffi.STEP_COMM | _ffi.STEP_GLOBAL):
-            flags |= _ffi.STEP_TILES   # the fusion without area sums takes the work list as one-trip tile items
+        if self._tile_form and flags & (_ffi.STEP_COMM | _ffi.STEP_GLOBAL):
+            flags |= _ffi.STEP_TILES   # the fusion takes the work list as one-trip tile items (16-byte layout, prior 0.5)
         self.ctx.call("ippm_plan_step", self._p(self.episode), self._p(self.pos), self._p(self.comm_range), self._p(comm_draws),
                       self._p(self.comm), self._p(self.rect), self._p(self.ws), t, flags, self._p(probs), self._p(actions), policy,
                       self._p(self.mask), self._p(self.action), self._p(self.fault), self._p(self.rect_next), self._p(self.work), self.E,

@@ -540,7 +540,22 @@ def test_graph_replay_matches_eager():
             rb, _ = b.step_graphed(t)
             assert torch.equal(a.pos, b.pos) and torch.equal(a.action, b.action) and torch.equal(a.mask, b.mask), (wave, t)
             assert torch.equal(ra, rb), (wave, t)
-            assert torch.equal(a.work, b.work), (wave, t)   # the step's work list (a replay must rebuild it, not append to it)
+            # the step's work list (a replay must rebuild it, not append to it): the same items per env -- in the tile form their
+            # order within an env's slice is whatever the builders' LDS atomics made it
+            E = a.E
+            assert torch.equal(a.work[:E], b.work[:E]), (wave, t)
+            wa, wb = a.work.cpu().numpy(), b.work.cpu().numpy()
+            d = a.d   # (ippm_tile_env_cap: items an env's slice holds)
+            ops, G = d.n_agents + 1, (d.grid_y + 3) // 4
+            slots = 4 if ops <= 4 else (2 if ops <= 10 else 1)
+            base, cap = (E + 3) & ~3, ops * (-(-d.grid_x * G // (32 * slots)) + ops * (2 * ops - 1) * ((G + 63) // 64))
+            assert base + E * cap * 4 <= len(wa)
+            for e in (0, 7, E - 1):
+                n_items = int(wa[e]) & 0x0FFFFFFF
+                assert int(wa[e]) & 0x40000000 and 0 < n_items <= cap
+                ia = wa[base + e * cap * 4: base + (e * cap + n_items) * 4].reshape(-1, 4)
+                ib = wb[base + e * cap * 4: base + (e * cap + n_items) * 4].reshape(-1, 4)
+                assert sorted(map(tuple, ia)) == sorted(map(tuple, ib)), (wave, t, e)
         assert torch.equal(a.local, b.local) and torch.equal(a.glob, b.glob)
         a.reset(eps + 100)
         b.reset(eps + 100)
@@ -745,7 +760,10 @@ def test_kernel_timing_reports_dispatch_durations():
     env.steps(6, policy=POLICY_UNIFORM, features=False)          # not timed
     times = env.event_times_us()
     assert {"sense", "fuse", "plan"} <= set(times)
-    for cls, kernel in (("sense", "k_sense_tiles<4, false, false, true, true>"), ("fuse", "k_fuse_tiles<6, false>"), ("plan", "k_plan_step")):
+    # (template arguments as the launch site spells them: K3 <cells per lane, misaligned rows, explicit flips, sense records, dense lane
+    #  mapping, area sums>, the fusion <max ops, misaligned rows, area sums>)
+    for cls, kernel in (("sense", "k_sense_tiles<4, false, false, true, true, false>"), ("fuse", "k_fuse_tiles<6, false, false>"),
+                        ("plan", "k_plan_step")):
         rec = times[cls]
         assert rec["launches"] == 5 and rec["kernel"] == kernel, (cls, rec)
         assert 1.0 < rec["min_us"] <= rec["avg_us"] < 2000.0, (cls, rec)
