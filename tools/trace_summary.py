@@ -15,13 +15,21 @@ df["k"] = df[name].str.replace("void ", "").str.slice(0, 44)
 g = df.groupby(["k", grid])["us"].agg(["count", "mean", "min", "max", "sum"]).sort_values("sum", ascending=False)
 print(g[g["sum"] > (float(sys.argv[2]) if len(sys.argv) > 2 else 50)].round(1).to_string())
 
+# (bench.py --calib brackets its loops between three k_stream_copy launches and the copy-rate yardstick at the end: only what
+#  lies between them is the bench loop -- the placement search runs before, the COMA leg after)
+copies = df.sort_values("start").reset_index(drop=True)
+is_copy = copies["k"].str.contains("k_stream_copy").to_numpy()
+lo = next((i + 3 for i in range(len(copies) - 2) if is_copy[i] and is_copy[i + 1] and is_copy[i + 2]), None)
+if lo is not None:
+    hi = next((i for i in range(lo, len(copies)) if is_copy[i]), len(copies))
+    df = copies.iloc[lo:hi].copy()
 # idle time in front of each kernel of the env step (end of the previous kernel on the device -> start of this one)
 # (the three launches of a step: the plan kernel, the fusion in either of its forms, K3 in either of its forms)
 step = df[df["k"].str.contains("k_plan_step|k_sense_tiles|k_sense_update|k_fuse_tiles|k_fuse_rows")].sort_values("start").reset_index(drop=True)
 if len(step) > 12:
     step["gap_us"] = (step["start"] - step["end"].shift(1)) / 1e3
     tail = step.iloc[len(step) // 2:]
-    print("\nidle time before each step kernel (second half of the run):")
+    print("\nidle time before each step kernel (second half of the bench loop):")
     print(tail.groupby("k")["gap_us"].agg(["count", "mean", "min", "max"]).round(1).to_string())
     span = (tail["end"].iloc[-1] - tail["start"].iloc[0]) / 1e3
     kinds = tail["k"].str.extract(r"(k_plan_step|k_sense|k_fuse)")[0]
