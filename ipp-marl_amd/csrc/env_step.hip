@@ -296,6 +296,9 @@ k_sense_update(const ippm_config* __restrict__ c, const int64_t* __restrict__ ep
 typedef unsigned ippm_k3_u4 __attribute__((ext_vector_type(4)));
 #define IPPM_K3_RSRC(ptr, bytes) __builtin_amdgcn_make_buffer_rsrc((void*)(ptr), 0, (int)(bytes), 0x00020000)
 #define IPPM_K3_OOB 0x7FFFFFF0
+#ifndef IPPM_K3_WAVES      // wavefronts per workgroup of k_sense_tiles (variant builds: 2 / 8)
+#define IPPM_K3_WAVES 4
+#endif
 #ifndef IPPM_K3_LOAD_AUX   // cache policy of the map accesses (bit 1 = non-temporal on gfx950)
 #define IPPM_K3_LOAD_AUX 0
 #endif
@@ -310,7 +313,7 @@ typedef unsigned ippm_k3_u4 __attribute__((ext_vector_type(4)));
 // cell-by-cell tail stores nor the flips resource (the kernel sits at the SGPR limit: every uniform it holds less is a
 // v_writelane / v_readlane pair less in its instruction stream).
 template <int VEC, bool MIS, bool FLIPS, bool REC, bool DENSE, bool TRACK>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(64 * IPPM_K3_WAVES)
 k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int stage, int rows_per_part, int gy, int gx,
               float* __restrict__ local, const uint8_t* __restrict__ truth, const int64_t* __restrict__ episode,
               uint8_t* __restrict__ code, int S_arg, float lc_arg, uint32_t k0_arg, uint32_t k1_arg,
@@ -371,7 +374,7 @@ k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int sta
   if (DENSE) {
     dense_inv = (unsigned)(65536.0f * __builtin_amdgcn_rcpf((float)max(groups, 1))) + 1u;   // floor(t / W) = (t * inv) >> 16 for t <= 192, W <= 192
     dense_rpw = (int)(((unsigned)(CH * 64) * dense_inv) >> 16);
-    part_rows = 4 * dense_rpw;
+    part_rows = IPPM_K3_WAVES * dense_rpw;
   }
   const int r0 = part * part_rows, r1 = min(h, r0 + part_rows);
   // the reward of the step whose global fusion ran in the launch before this one: any one thread per env completes it (last:
@@ -404,7 +407,7 @@ k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int sta
   const uint32_t sw = ippm_stream_word((uint32_t)i, (uint32_t)stage, IPPM_DOMAIN_FLIP);
   float amax = 0.f;
   for (int gbase = 0; gbase < (DENSE ? 1 : groups); gbase += CH * lpr) {     // one trip unless the footprint is wider than 3 x 64 groups
-    for (int row0 = r0 + wv * (DENSE ? dense_rpw : rpw) + (DENSE ? 0 : sub); row0 < r1; row0 += 4 * rpw) {  // one trip for the common footprints
+    for (int row0 = r0 + wv * (DENSE ? dense_rpw : rpw) + (DENSE ? 0 : sub); row0 < r1; row0 += IPPM_K3_WAVES * rpw) {  // one trip for the common footprints
       CellVec<VEC> m[CH];
       uint32_t tw[CH], fw[CH];
       int cellv[CH], rowv[CH], yv[CH];
@@ -821,7 +824,8 @@ extern "C" int ippm_sense_step(ippm_ctx* ctx, const int64_t* episode, const int3
     const ippm_config& c = ctx->cfg;
     int h_max = 1;
     for (int k = 0; k < c.space_z; ++k) h_max = std::max(h_max, 2 * c.radius_x[k]);
-    const int rows_per_part = std::max(4, env_int("IPPM_K3_ROWS", 32));
+    const int rows_per_part = std::max(4, env_int("IPPM_K3_ROWS", 8 * IPPM_K3_WAVES));
+    block = dim3(64 * IPPM_K3_WAVES);
     int parts = (h_max + rows_per_part - 1) / rows_per_part;
     // dense lane mapping (k_sense_tiles<..., DENSE>): a part is 4 * floor(192 / W) rows, W = the footprint's 4-cell groups (one
     // more than its width needs when it starts off a group boundary); every altitude must get at least two rows per wavefront
@@ -831,7 +835,7 @@ extern "C" int ippm_sense_step(ippm_ctx* ctx, const int64_t* episode, const int3
       for (int k = 0; k < c.space_z; ++k) {
         const int wmax = (2 * c.radius_y[k] + 3) / 4 + 1, rpw = 192 / std::max(1, wmax);
         if (rpw < 2) { dense = false; break; }
-        need = std::max(need, (2 * c.radius_x[k] + 4 * rpw - 1) / (4 * rpw));
+        need = std::max(need, (2 * c.radius_x[k] + IPPM_K3_WAVES * rpw - 1) / (IPPM_K3_WAVES * rpw));
       }
       if (dense) parts = need;
     }
