@@ -492,12 +492,14 @@ class VecEnv:
         scores, arenas = [score()], [self._arena]      # arenas[k] is None once released
         stopped = "draws exhausted"
         for k in range(1, draws):
-            # the two kinds are 7-8 % apart and each is sharp to 1 %: a candidate well below the worst seen is a good one
-            if min(scores) < 0.96 * max(scores) and not os.environ.get("IPPM_PLACEMENT_NO_EARLY"):
+            # the two kinds are 7-8 % apart and each is sharp to 1 %: a candidate well below the MEDIAN of the draws is a good one
+            # (below the worst is not enough: a slow outlier among slow draws -- 121, 121, 126 -- would end the search on a bad one)
+            med = float(np.median(scores))
+            if k >= 2 and min(scores) < 0.96 * med and not os.environ.get("IPPM_PLACEMENT_NO_EARLY"):
                 stopped = "a fast allocation found"
                 break
-            # ... and a box on which six draws in a row differ by less than 2 % has one kind only: nothing to search for
-            if k >= 6 and max(scores) < 1.02 * min(scores) and not os.environ.get("IPPM_PLACEMENT_NO_EARLY"):
+            # ... and a box on which twelve draws in a row differ by less than 2 % has one kind only: nothing to search for
+            if k >= 12 and max(scores) < 1.02 * min(scores) and not os.environ.get("IPPM_PLACEMENT_NO_EARLY"):
                 stopped = "no spread between the first draws"
                 break
             alive = [i for i, a in enumerate(arenas) if a is not None]
