@@ -415,13 +415,19 @@ def main():
                 "rollout_agent_env_steps_per_s": tr.E * tr.N * tr.T * world * args.train_rounds / roll_s,
                 "note": "one update = TD(lambda) targets + data_passes x batch_number minibatch steps of critic and actor "
                         "(reference round: 25+25 Adam steps on 300 transitions); nets float32 in PyTorch-ROCm"}
-        # kernel times of one more learned-policy rollout (area sums tracked by K3/K4/K5, K6 = 121-cell assembly), untimed above
+        # kernel times of one more learned-policy rollout (area sums tracked by K3/K4/K5, K6 = 121-cell assembly), untimed above.
+        # A training-mode rollout (actions sampled from the epsilon-mixed policy): a greedy one after two updates of a random net
+        # sends every UAV wherever that net happens to point -- all down to 5 m in one process, all up in the next -- and the map
+        # kernels' work with them (sense 27 .. 49 us, fuse 55 .. 116 us between processes); the cells per step say what was done.
         tr.env.profile = True
         tr.env.counters(reset=True)
-        tr.rollout("eval")
+        tr.rollout("train")
         tr.env.profile = False
         kt = tr.env.event_times_us()
+        cc = tr.env.counters()
         coma["rollout_kernel_us"] = {k: round(v["avg_us"], 2) for k, v in kt.items()}
+        coma["rollout_kernel_us"]["cells_per_step"] = {"sense": cc["sense_cells"] / tr.T, "fuse_local": cc["fuse_local_cells"] / tr.T,
+                                                       "fuse_global": cc["fuse_global_cells"] / tr.T}
         coma["rollout_kernel_us"]["kernels"] = {k: v["kernel"] for k, v in kt.items()}
         coma["rollout_kernel_us"]["note"] = ("dispatch-bound start/stop events (kernel-only durations); sense/fuse here also maintain "
                                              "the 11x11 area sums of every map, which is what lets the K6 builders skip the maps")

@@ -45,7 +45,7 @@ def _job(args):
     return philox_episode(*args)
 
 
-def philox_episodes(params, episodes, seed, truths=None, min_parallel_cells=1 << 17):
+def philox_episodes(params, episodes, seed, truths=None, min_parallel_cells=1 << 19):
     """[philox_episode(...)] for every episode of a batch; in worker processes when the grid is large enough to pay for them."""
     truths = [None] * len(episodes) if truths is None else list(truths)
     jobs = [(params, int(ep), seed, tr) for ep, tr in zip(episodes, truths)]
