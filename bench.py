@@ -53,7 +53,12 @@ PIXELS = {128: 15, 256: 30, 512: 60, 1024: 120}
 def bench_params(args):
     from ippmarl.params import grid256_params
     number = PIXELS[args.grid]   # other BASELINE.json grid sizes are parity-test configs; 256 is the metric's
-    return grid256_params(experiment__missions__n_agents=args.agents, sensor__pixel__number_x=number, sensor__pixel__number_y=number)
+    over = dict(experiment__missions__n_agents=args.agents, sensor__pixel__number_x=number, sensor__pixel__number_y=number)
+    if getattr(args, "actions", None):            # BASELINE config 5's shape: 27 actions (3-D moves), per-episode comm range
+        over["experiment__constraints__num_actions"] = args.actions
+    if getattr(args, "episode_comm_range", False):
+        over["experiment__uav__fix_range"] = False
+    return grid256_params(**over)
 
 
 def cpu_baseline(args, seconds=10.0):
@@ -154,6 +159,9 @@ def main():
     ap.add_argument("--envs", type=int, default=1024, help="envs per GPU")
     ap.add_argument("--agents", type=int, default=4)
     ap.add_argument("--grid", type=int, default=256, choices=sorted(PIXELS))
+    ap.add_argument("--actions", type=int, default=None, choices=[4, 6, 9, 27], help="action set (default: params.yaml's 6)")
+    ap.add_argument("--episode-comm-range", action="store_true", help="per-episode comm range from {0, 15, 25, 100} m "
+                    "(experiment.uav.fix_range: False, BASELINE config 5's comm-range masking)")
     ap.add_argument("--terrain", default="random_field", choices=["random_field", "split"],
                     help="ground truth: the power-law random field of ground_truths.py:25-40 generated on the device, or "
                          "the half-plane split the reference flies over")
@@ -235,6 +243,7 @@ def main():
     # episode each, before anything is timed
     placement = env.tune_placement(args.placement_draws)
     E, N, T = env.E, env.d.n_agents, env.d.budget + 1
+    env_actions = env.d.n_actions
     wave = [0]
 
     def reset():
@@ -494,8 +503,9 @@ def main():
                                              "hip_graphs": "16 rollout-step graphs + 1 update graph per round (COMATrainer.capture_graphs)"}
     if rank == 0:
         total_steps = E * N * args.steps * world
-        is_c1 = (N, grid[0], E) == (4, 256, 1024)
-        shape = f"{N} UAVs, {grid[0]}x{grid[1]} grid, {E} batched envs per GPU, random policy, env-step kernels only"
+        is_c1 = (N, grid[0], E) == (4, 256, 1024) and env_actions == 6 and not args.episode_comm_range
+        shape = (f"{N} UAVs, {grid[0]}x{grid[1]} grid, {E} batched envs per GPU, random policy over {env_actions} actions"
+                 f"{', per-episode comm range' if args.episode_comm_range else ''}, env-step kernels only")
         out = {
             "metric": f"agent-env steps/s ({N} UAVs, {grid[0]}x{grid[1]} grid, random policy, env-step HIP kernels)",
             "value": total_steps / dt, "unit": "agent-env steps/s", "n_gpus": world, "steps": args.steps,

@@ -365,7 +365,7 @@ __global__ void k_action_mask(const ippm_config* __restrict__ c, const int32_t* 
 #else
 #define PLAN_STAMP(k) do { } while (0)
 #endif
-#define IPPM_PLAN_BUILDERS 6   // most wavefronts that build tile items next to wavefront 0 (maps are dealt out round-robin)
+#define IPPM_PLAN_BUILDERS 14  // most wavefronts that build tile items next to wavefront 0 (maps are dealt out round-robin); + K1 = 16 wavefronts
 #define IPPM_PLAN_BUILDERS_DEFAULT 3   // measured at 1024 envs x 4 UAVs: 1 / 2 / 3 / 5 builders -> 32.6 / 25.8 / 21.1 / 26.5 us (16 wavefronts
                                        // per CU is what one round of the launch holds; a sixth wavefront per env makes it two rounds)
 __global__ void __launch_bounds__(64 * (1 + IPPM_PLAN_BUILDERS))
@@ -621,7 +621,13 @@ extern "C" int ippm_plan_step(ippm_ctx* ctx, const int64_t* episode, int32_t* po
     }
   }
   const bool tile_list = plans && work && (flags & IPPM_STEP_TILES);
-  const int plan_waves = tile_list ? 1 + std::min(ctx->cfg.n_agents + 1, ctx->knob_plan_builders > 0 ? std::min(ctx->knob_plan_builders, IPPM_PLAN_BUILDERS) : IPPM_PLAN_BUILDERS_DEFAULT) : 1;
+  // builders: 3 at large batches (a round of the launch holds 16 wavefronts per CU: a sixth wavefront per env at 1024 envs makes it
+  // two rounds); small batches of large teams (config 5's shape: 64 envs x 16 UAVs, 17 plans of up to 17 ops, thousands of items
+  // per map) take a builder per map as long as the whole launch stays within one round of the chip
+  int builders = IPPM_PLAN_BUILDERS_DEFAULT;
+  while (builders < std::min(ctx->cfg.n_agents + 1, IPPM_PLAN_BUILDERS) && (long long)n_envs * (builders + 3) <= 4096) ++builders;
+  if (ctx->knob_plan_builders > 0) builders = std::min(ctx->knob_plan_builders, IPPM_PLAN_BUILDERS);
+  const int plan_waves = tile_list ? 1 + std::min(ctx->cfg.n_agents + 1, builders) : 1;
   IPPM_LAUNCH(ctx, IPPM_T_PLAN, k_plan_step, dim3(n_envs), dim3(64 * plan_waves), S_(stream), pos, rect, ws, ctx->cfg.n_agents, flags, t, policy,
                      ctx->dcfg, episode, comm_range, draws, comm, probs, action_in, mask, action, fault, rect_next, -1, plans ? work : nullptr,
                      ippm_fuse_wave_rows(ctx, n_envs), (flags & IPPM_STEP_TILES) ? ippm_tile_env_cap(ctx) : ippm_work_env_cap(ctx, n_envs),

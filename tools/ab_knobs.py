@@ -23,11 +23,13 @@ def main():
     ap.add_argument("--envs", type=int, default=1024)
     ap.add_argument("--agents", type=int, default=4)
     ap.add_argument("--grid", type=int, default=256)
+    ap.add_argument("--actions", type=int, default=None)
+    ap.add_argument("--episode-comm-range", action="store_true")
     ap.add_argument("--tracked", action="store_true", help="the training sequence: area sums tracked, two plan launches per step")
     ap.add_argument("--draws", type=int, default=8, help="placement search on the first env before the comparison")
     ap.add_argument("settings", nargs="+")
     a = ap.parse_args()
-    a.actions, a.terrain = None, "random_field"
+    a.terrain = "random_field"
     envs = []
     for setting in a.settings:
         pairs = [kv.split("=", 1) for kv in setting.split()]

@@ -1,0 +1,5 @@
+#!/bin/bash
+python tools/ab_knobs.py --envs 64 --agents 16 --grid 1024 --actions 27 --episode-comm-range --rounds 3 --draws 1 "" "IPPM_PLAN_BUILDERS=3" 2>&1 | tail -3
+python tools/ab_knobs.py --rounds 4 --draws 1 "" "IPPM_PLAN_BUILDERS=3" 2>&1 | tail -3
+python tools/ab_knobs.py --envs 1024 --agents 8 --grid 512 --rounds 2 --draws 1 "" 2>&1 | tail -1
+timeout 600 python -m pytest tests -m gpu -q -x -k "production_randomness or untracked or graph_replay or full_size" 2>&1 | tail -2
