@@ -624,7 +624,7 @@ extern "C" int ippm_plan_step(ippm_ctx* ctx, const int64_t* episode, int32_t* po
   // builders: 3 at large batches (a round of the launch holds 16 wavefronts per CU: a sixth wavefront per env at 1024 envs makes it
   // two rounds); small batches of large teams (config 5's shape: 64 envs x 16 UAVs, 17 plans of up to 17 ops, thousands of items
   // per map) take a builder per map as long as the whole launch stays within one round of the chip
-  int builders = IPPM_PLAN_BUILDERS_DEFAULT;
+  int builders = ctx->cfg.n_agents >= 7 ? 5 : IPPM_PLAN_BUILDERS_DEFAULT;   // (8 UAVs x 1024 envs: 3 / 5 / 7 / 9 builders -> 59.6 / 51.3 / 50.7 / 53.2 us)
   while (builders < std::min(ctx->cfg.n_agents + 1, IPPM_PLAN_BUILDERS) && (long long)n_envs * (builders + 3) <= 4096) ++builders;
   if (ctx->knob_plan_builders > 0) builders = std::min(ctx->knob_plan_builders, IPPM_PLAN_BUILDERS);
   const int plan_waves = tile_list ? 1 + std::min(ctx->cfg.n_agents + 1, builders) : 1;
