@@ -248,8 +248,8 @@ __global__ __launch_bounds__((FourStep<N1, N2, Q>::THREADS)) void k_terrain_fft_
 
 // pass Y: sequences are the x rows (length gy = N1 * N2 after the Hermitian extension).  The rows are real, so ONE complex
 // transform yields TWO of them: with A, B the Hermitian-extended spectra of rows xa and xb, the inverse transform of A + iB is
-// a + ib with a, b the two real rows.  A workgroup takes 2 Q rows (xa = x0 + q, xb = x0 + Q + q): half the transforms of the
-// row-by-row form, and pass Y is issue-bound.
+// a + ib with a, b the two real rows.  A workgroup takes 2 Q rows, slot q the NEIGHBOURS xa = x0 + 2 q, xb = xa + 1 (their
+// spectra are one 16-byte load per bin): half the transforms of the row-by-row form.
 // MODE 0: the field is written and its (min, max) accumulated (ippm_terrain_field).  The episode reset never needs the field
 // itself -- only its threshold bits, and those need the field's (min, max) first -- so it runs the pass twice instead of writing
 // 268 MB and reading them back: MODE 1 accumulates (min, max) and stores nothing, MODE 2 recomputes the rows (bit for bit the
@@ -268,11 +268,12 @@ __global__ __launch_bounds__((FourStep<N1, N2, Q>::THREADS)) void k_terrain_fft_
   const bool in_active = i2 < N2, out_active = q_out < Q;
   float2 v[N1], o[N2];
   if (in_active) {
-    const float2* src = work + (size_t)e * hy * gx + x0 + q_in;
+    const float2* src = work + (size_t)e * hy * gx + x0 + 2 * q_in;   // (16-byte aligned: x0 and gx are even)
 #pragma unroll
     for (int i1 = 0; i1 < N1; ++i1) {
       const int i = i1 * N2 + i2, m = 2 * i > gy ? gy - i : i;   // bins above gy/2 are the conjugate mirror
-      float2 a = src[(size_t)m * gx], b = src[(size_t)m * gx + Q];
+      const float4 ab = *reinterpret_cast<const float4*>(src + (size_t)m * gx);
+      float2 a = make_float2(ab.x, ab.y), b = make_float2(ab.z, ab.w);
       if (2 * i > gy) { a.y = -a.y; b.y = -b.y; }
       if (i == 0 || 2 * i == gy) { a.y = 0.0f; b.y = 0.0f; }     // self-mirrored bins of a real transform
       v[i1] = make_float2(a.x - b.y, a.y + b.x);                 // A + iB
@@ -288,7 +289,7 @@ __global__ __launch_bounds__((FourStep<N1, N2, Q>::THREADS)) void k_terrain_fft_
     const int my_q = (tid >> 6) * rows_per_wave + lane;          // the row (slot) this lane stores for, if lane < rows_per_wave
     const bool storer = lane < rows_per_wave && my_q < Q;
     uint32_t* out = truth32 + (size_t)e * truth_words;
-    const size_t row_a = ((size_t)(x0 + my_q) * gy) >> 5, row_b = ((size_t)(x0 + Q + my_q) * gy) >> 5;
+    const size_t row_a = ((size_t)(x0 + 2 * my_q) * gy) >> 5, row_b = ((size_t)(x0 + 2 * my_q + 1) * gy) >> 5;
     uint32_t wa = 0, wb = 0;
 #pragma unroll
     for (int k2 = 0; k2 < N2; ++k2) {
@@ -307,12 +308,12 @@ __global__ __launch_bounds__((FourStep<N1, N2, Q>::THREADS)) void k_terrain_fft_
   }
   float lo = INFINITY, hi = -INFINITY;
   if (out_active) {
-    float* dst = field + ((size_t)e * gx + x0 + q_out) * gy + k1;
+    float* dst = field + ((size_t)e * gx + x0 + 2 * q_out) * gy + k1;
 #pragma unroll
     for (int k2 = 0; k2 < N2; ++k2) {
       if (MODE == 0) {
         dst[N1 * k2] = o[k2].x;
-        dst[(size_t)Q * gy + N1 * k2] = o[k2].y;
+        dst[(size_t)gy + N1 * k2] = o[k2].y;
       }
       lo = fminf(lo, fminf(o[k2].x, o[k2].y));
       hi = fmaxf(hi, fmaxf(o[k2].x, o[k2].y));
