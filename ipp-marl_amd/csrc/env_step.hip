@@ -299,6 +299,9 @@ typedef unsigned ippm_k3_u4 __attribute__((ext_vector_type(4)));
 #ifndef IPPM_K3_WAVES      // wavefronts per workgroup of k_sense_tiles (variant builds: 2 / 8)
 #define IPPM_K3_WAVES 4
 #endif
+#ifndef IPPM_K3_CH         // loads in flight per lane of k_sense_tiles (variant builds)
+#define IPPM_K3_CH 3
+#endif
 #ifndef IPPM_K3_LOAD_AUX   // cache policy of the map accesses (bit 1 = non-temporal on gfx950)
 #define IPPM_K3_LOAD_AUX 0
 #endif
@@ -326,7 +329,7 @@ k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int sta
   // dependent scalar round trips.  The first 14 argument words arrive in SGPRs with the wavefront (kernel-argument preload,
   // csrc/Makefile): the address of the agent's sense record (K1: footprint + the measurement constants of its altitude) needs
   // nothing else, and every config scalar the kernel uses is passed by value -- one scalar round trip, then the map loads.
-  constexpr int CH = 3;
+  constexpr int CH = IPPM_K3_CH;
   // grid = (row parts, agents, envs): no index arithmetic to undo
   const int part = blockIdx.x, e = blockIdx.z, i = agent_sel >= 0 ? agent_sel : (int)blockIdx.y;
   const int tile = e * n + (int)blockIdx.y;
@@ -833,7 +836,7 @@ extern "C" int ippm_sense_step(ippm_ctx* ctx, const int64_t* episode, const int3
     if (dense) {
       int need = 1;
       for (int k = 0; k < c.space_z; ++k) {
-        const int wmax = (2 * c.radius_y[k] + 3) / 4 + 1, rpw = 192 / std::max(1, wmax);
+        const int wmax = (2 * c.radius_y[k] + 3) / 4 + 1, rpw = (64 * IPPM_K3_CH) / std::max(1, wmax);
         if (rpw < 2) { dense = false; break; }
         need = std::max(need, (2 * c.radius_x[k] + IPPM_K3_WAVES * rpw - 1) / (IPPM_K3_WAVES * rpw));
       }
