@@ -363,7 +363,7 @@ class Recorder:
         np.random.random_sample = self._rs
 
 
-def run_reference_episode(p, episode, tag, mode="train", snapshots=True):
+def run_reference_episode(p, episode, tag, mode="train", snapshots=True, local_agents=None):
     torch.manual_seed(1234 + episode)
     np.random.seed(4321 + episode)
     wrapper = COMAWrapper(p, None)
@@ -418,6 +418,9 @@ def run_reference_episode(p, episode, tag, mode="train", snapshots=True):
     )
     if snapshots:   # (left out at 493 x 493 to keep the fixture small)
         arrays.update(global_t0=gmaps[0], global_t7=gmaps[7])
+    if local_agents is not None:   # (8 UAVs x 512 x 512: the final local maps of a few agents only)
+        arrays["final_local"] = arrays["final_local"][list(local_agents)]
+        arrays["final_local_agents"] = np.array(list(local_agents), dtype=np.int32)
     save(tag, **arrays)
 
 
@@ -434,6 +437,14 @@ def gen_episode_default_grid():
     """One episode at the reference's own default grid (493 x 493: the only BASELINE-relevant grid whose 11 feature bins are
     not whole cells wide), 2 UAVs as BASELINE config 1: pins the assembled actor / critic planes there."""
     run_reference_episode(make_params("c1"), 2, "episode_default_e2", snapshots=False)
+
+
+def gen_episode_prior_and_c4():
+    """Two more whole episodes of the reference itself: mapping.prior = 0.3 (every fused message shifts every cell of the grid:
+    the explicit slow path of the fusion) and BASELINE config 4's team and grid (8 UAVs, 512 x 512: plans of up to nine ops)."""
+    run_reference_episode(make_params("small", mapping__prior=0.3, experiment__missions__n_agents=3), 4, "episode_small_prior03_e4",
+                          snapshots=False)
+    run_reference_episode(make_params("c4"), 2, "episode_c4_e2", snapshots=False, local_agents=(0, 5))
 
 
 # ------------------------------------------------------------------ 12: TD(lambda)
@@ -587,7 +598,7 @@ def gen_missions():
 
 
 GENERATORS = [gen_derived_and_footprints, gen_start_states, gen_truth, gen_terrain, gen_masks, gen_comm, gen_bayes_measurement,
-              gen_entropy_reward, gen_episodes, gen_episode_default_grid, gen_td_lambda, gen_coma_step, gen_ig_baseline, gen_missions]
+              gen_entropy_reward, gen_episodes, gen_episode_default_grid, gen_episode_prior_and_c4, gen_td_lambda, gen_coma_step, gen_ig_baseline, gen_missions]
 
 if __name__ == "__main__":
     check_schema()

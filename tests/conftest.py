@@ -36,6 +36,12 @@ def golden():
     return load
 
 
+def local_subset(fx, local_maps):
+    """The agents whose final local maps an episode fixture holds (all of them unless it says ``final_local_agents``)."""
+    local_maps = np.asarray(local_maps)
+    return local_maps[fx["final_local_agents"]] if "final_local_agents" in fx else local_maps
+
+
 def unpack_correctness(fx):
     """Episode fixtures store the reference's per-sensing correctness draws bit-packed, in call order."""
     out, off = [], 0
@@ -53,8 +59,11 @@ def unpack_correctness(fx):
 # oracle in exact-float64 mode (tests/test_oracle_golden.py::test_exact_mode_differs_only_by_reference_quantisation): one map
 # cell, (6, 81) of episode_small5_e3, at 2.45e-5 -- in the global map and in the two local maps that received it; every other
 # cell of every recording is within 1e-5.  The 493 x 493 recording (episode_default_e2, added in round 4) has two such cells, at
-# 1.03e-5 .. 1.27e-5.
+# 1.03e-5 .. 1.27e-5; the 8-UAV 512 x 512 recording (episode_c4_e2: twice the fusions per cell) five, the largest at 1.9e-4 --
+# inside the 3e-4 the mechanism allows, which is the cap assert_posteriors holds the listed cells to.
 REFERENCE_QUANTISATION_CELLS = {
+    ("episode_c4_e2", "final_local"): [(0, 251, 99), (0, 256, 57), (0, 396, 75), (1, 178, 50), (1, 247, 142), (1, 251, 99), (1, 256, 57)],
+    ("episode_c4_e2", "final_global"): [(251, 58), (251, 99), (424, 63)],
     ("episode_default_e2", "final_local"): [(1, 487, 373), (1, 490, 367)],
     ("episode_default_e2", "final_global"): [(487, 373)],
     ("episode_small5_e3", "final_local"): [(1, 6, 81), (3, 6, 81)],
@@ -67,7 +76,8 @@ def assert_posteriors(actual, desired, strict, msg="", allow=None):
 
     strict=True  (``desired`` from the oracle in exact float64 mode): every cell within 1e-5 relative.
     strict=False, ``allow`` = list of cell indices (``desired`` recorded from the reference itself): every cell within 1e-5
-      relative except the listed ones (REFERENCE_QUANTISATION_CELLS above), which must be within 5e-5.
+      relative except the listed ones (REFERENCE_QUANTISATION_CELLS above), which must be within 3e-4 (= 2^-25 / 1e-4, what the
+      reference's float32 re-quantisation of a probability next to the 0.9999 clip can do to it).
     """
     actual = np.asarray(actual, dtype=np.float64)
     desired = np.asarray(desired, dtype=np.float64)
@@ -76,7 +86,7 @@ def assert_posteriors(actual, desired, strict, msg="", allow=None):
         return
     with np.errstate(divide="ignore", invalid="ignore"):
         rel = np.where(actual == desired, 0.0, np.abs(actual - desired) / np.abs(desired))   # (cells at exactly 0: noise-free altitudes)
-    assert float(rel.max()) <= 5e-5, f"{msg}: relative deviation {rel.max():.3e} exceeds the reference's own float32 re-quantisation noise"
+    assert float(rel.max()) <= 3e-4, f"{msg}: relative deviation {rel.max():.3e} exceeds the reference's own float32 re-quantisation noise"
     listed = np.zeros(rel.shape, dtype=bool)
     for idx in (allow or []):
         listed[tuple(idx)] = True

@@ -9,7 +9,7 @@ import pytest
 
 import ipp_oracle as O
 from configs import make_params
-from conftest import REFERENCE_QUANTISATION_CELLS as RQ, assert_features_or_ties, assert_posteriors, unpack_correctness
+from conftest import REFERENCE_QUANTISATION_CELLS as RQ, assert_features_or_ties, assert_posteriors, local_subset, unpack_correctness
 from test_oracle_golden import EPISODES
 
 torch = pytest.importorskip("torch")
@@ -60,22 +60,26 @@ def test_golden_episode_replay(golden, tag):
     env.reset([int(fx["episode"])], flips=flips_for(0, fx["positions"][0]))
     assert np.array_equal(env.truth_map[0].numpy(), fx["truth"])
     assert np.array_equal(env.pos[0].cpu().numpy(), fx["positions"][0])
+    # (mapping.prior != 0.5: the reference re-quantises EVERY cell to a float32 probability at every fused message; its own
+    #  recorded rewards and area averages carry that noise -- 1e-6 of S1 / S2, i.e. 2.2e-5 of the reward, and 1e-5 of an average)
+    shifted = d.prior != 0.5
+    fa, ra = (1e-5, 2.5e-5) if shifted else (2e-6, 1e-6)
     for t in range(T):
         obs = env.build_observations(t, comm_draws=torch.from_numpy(comm[t].copy()).to(env.device))
-        np.testing.assert_allclose(obs[0].cpu().numpy(), fx["obs"][t], rtol=RTOL, atol=2e-6, err_msg=f"obs t={t}")
+        np.testing.assert_allclose(obs[0].cpu().numpy(), fx["obs"][t], rtol=RTOL, atol=fa, err_msg=f"obs t={t}")
         acts = torch.from_numpy(fx["actions"][t][None].astype(np.int32))
         reward, done, state = env.steps(t, policy=POLICY_EXPLICIT, actions=acts, flips=flips_for(t + 1, fx["positions"][t + 1]))
         assert np.array_equal(env.mask[0].cpu().numpy(), fx["masks"][t].astype(np.uint8)), t
         assert np.array_equal(env.pos[0].cpu().numpy(), fx["positions"][t + 1]), t
         assert int(env.fault[0]) == 0
-        np.testing.assert_allclose(float(reward[0, 0]), fx["rewards"][t, 0], rtol=RTOL, atol=1e-6, err_msg=f"reward t={t}")
-        np.testing.assert_allclose(state[0].cpu().numpy(), fx["state"][t], rtol=RTOL, atol=2e-6, err_msg=f"state t={t}")
+        np.testing.assert_allclose(float(reward[0, 0]), fx["rewards"][t, 0], rtol=RTOL, atol=ra, err_msg=f"reward t={t}")
+        np.testing.assert_allclose(state[0].cpu().numpy(), fx["state"][t], rtol=RTOL, atol=fa, err_msg=f"state t={t}")
         assert done == bool(fx["done"][t, 0])
         if t == 0 and "global_t0" in fx:
             assert_posteriors(env.posterior_global()[0].cpu().numpy(), fx["global_t0"], strict=False, msg="global t=0", allow=RQ.get((tag, "global_t0"), []))
         if t == 7 and "global_t7" in fx:
             assert_posteriors(env.posterior_global()[0].cpu().numpy(), fx["global_t7"], strict=False, msg="global t=7", allow=RQ.get((tag, "global_t7"), []))
-    assert_posteriors(env.posterior_local()[0].cpu().numpy(), fx["final_local"], strict=False, msg="final local", allow=RQ.get((tag, "final_local"), []))
+    assert_posteriors(local_subset(fx, env.posterior_local()[0].cpu().numpy()), fx["final_local"], strict=False, msg="final local", allow=RQ.get((tag, "final_local"), []))
     assert_posteriors(env.posterior_global()[0].cpu().numpy(), fx["final_global"], strict=False, msg="final global", allow=RQ.get((tag, "final_global"), []))
 
 

@@ -5,7 +5,7 @@ import pytest
 
 import ipp_oracle as O
 from configs import make_params
-from conftest import unpack_correctness
+from conftest import local_subset, unpack_correctness
 
 RTOL = 1e-5  # BASELINE.json north_star: float posteriors/returns within 1e-5 relative; ints bit-exact
 
@@ -137,6 +137,10 @@ EPISODES = {
     "episode_small5_e3": dict(name="small", over=dict(experiment__missions__n_agents=5, experiment__uav__communication_range=15)),
     # the reference's default grid, 493 x 493 (11 feature bins that are not whole cells wide), 2 UAVs = BASELINE config 1's team
     "episode_default_e2": dict(name="c1", over={}),
+    # mapping.prior = 0.3: every fused message shifts every cell of the grid (the fusion's explicit slow path), recorded from the reference
+    "episode_small_prior03_e4": dict(name="small", over=dict(mapping__prior=0.3, experiment__missions__n_agents=3)),
+    # BASELINE config 4's team and grid (8 UAVs, 512 x 512; plans of up to nine ops); final local maps of agents 0 and 5 only
+    "episode_c4_e2": dict(name="c4", over={}),
 }
 
 
@@ -171,7 +175,7 @@ def test_full_episode_replay(golden, tag):
         assert rec["done"] == bool(fx["done"][t, 0])
     np.testing.assert_allclose(sum(r["relative_reward"] for r in log), fx["episode_return"], rtol=RTOL)
     np.testing.assert_allclose(sum(r["absolute_reward"] for r in log), fx["abs_return"], rtol=RTOL)
-    np.testing.assert_allclose(np.array([a["local_map"] for a in ep.agents]), fx["final_local"], rtol=RTOL)
+    np.testing.assert_allclose(local_subset(fx, np.array([a["local_map"] for a in ep.agents])), fx["final_local"], rtol=RTOL)
     np.testing.assert_allclose(ep.global_map, fx["final_global"], rtol=RTOL)
     if "global_t0" in fx:   # (the 493 x 493 fixture keeps only the final maps)
         np.testing.assert_allclose(log[0]["global_map"], fx["global_t0"], rtol=RTOL)
@@ -216,12 +220,15 @@ def test_exact_mode_differs_only_by_reference_quantisation(golden, tag):
                          choose_action=lambda i, t, mask, obs: fx["actions"][t, i],
                          comm_draw=lambda i, j, t: comm[(t * n + i) * n + j], exact=True)
     log = ep.run()
+    # (mapping.prior != 0.5: every fused message shifts EVERY cell of the grid, so the reference's float32 re-quantisation touches
+    #  every cell at every fusion: its S1 / S2 carry 1e-6 of relative noise, 22 times that in the reward, and its area averages 1e-5)
+    shifted = d.prior != 0.5
     for t, rec in enumerate(log):
         assert np.array_equal(rec["next_positions"], fx["positions"][t + 1])
         assert np.array_equal(rec["masks"], fx["masks"][t])
-        np.testing.assert_allclose(rec["relative_reward"], fx["rewards"][t, 0], rtol=RTOL, atol=1e-6)
-        np.testing.assert_allclose(np.array(rec["observations"]), fx["obs"][t], rtol=RTOL, atol=1e-6)
-    assert_posteriors(np.array([a["local_map"] for a in ep.agents]), fx["final_local"], strict=False, msg="final local", allow=RQ.get((tag, "final_local"), []))
+        np.testing.assert_allclose(rec["relative_reward"], fx["rewards"][t, 0], rtol=RTOL, atol=2.5e-5 if shifted else 1e-6)
+        np.testing.assert_allclose(np.array(rec["observations"]), fx["obs"][t], rtol=RTOL, atol=1e-5 if shifted else 1e-6)
+    assert_posteriors(local_subset(fx, np.array([a["local_map"] for a in ep.agents])), fx["final_local"], strict=False, msg="final local", allow=RQ.get((tag, "final_local"), []))
     assert_posteriors(ep.global_map, fx["final_global"], strict=False, msg="final global", allow=RQ.get((tag, "final_global"), []))
 
 
