@@ -212,6 +212,8 @@ def check_philox_episodes(name, over, n_envs, seed=0x1234567ABC, first_episode=1
     ("small", dict(experiment__constraints__min_altitude=15, experiment__constraints__max_altitude=20,
                    experiment__constraints__num_actions=27, experiment__uav__communication_range=10), 2),
     EDGE_85,
+    # 34 x 34 cells: narrower than 44, the one-cell-per-lane instantiations (k_sense_tiles<1>, the row walker's scalar form)
+    ("default", dict(sensor__pixel__number_x=4, sensor__pixel__number_y=4, experiment__missions__n_agents=3), 4),
 ])
 @pytest.mark.parametrize("fused_step", [False, True])
 def test_untracked_env_step_matches_oracle(name, over, n_envs, fused_step):
