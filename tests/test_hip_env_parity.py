@@ -425,7 +425,7 @@ def test_saturation_and_deferred_clamp():
         obs = env.build_observations(t)
         assert_posteriors(env.posterior_local()[0].cpu().numpy(), np.array(log[t]["fused_local"]), strict=True, msg=f"fused local t={t}")
         np.testing.assert_allclose(obs[0].cpu().numpy(), np.array(log[t]["observations"]), rtol=RTOL, atol=2e-6)
-        acts = torch.tensor([log[t]["actions"]], dtype=torch.int32)
+        acts = torch.from_numpy(np.asarray([log[t]["actions"]], dtype=np.int32))
         reward, _, state = env.steps(t, policy=POLICY_EXPLICIT, actions=acts)
         assert_posteriors(env.posterior_global()[0].cpu().numpy(), log[t]["global_map"], strict=True, msg=f"global t={t}")
         np.testing.assert_allclose(float(reward[0, 0]), log[t]["relative_reward"], rtol=RTOL, atol=1e-6)
