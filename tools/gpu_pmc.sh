@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 i=0
 for set in "$@"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace -d $OUT/pmc$i -o p -- python bench.py --steps 30 --warmup 10 --no-cpu-baseline --train-rounds 0 --roofline-steps 0 ${BENCH_ARGS} > $OUT/pmc$i.log 2>&1
+  timeout -k 10 ${PROF_TIMEOUT:-300} rocprofv3 --pmc $set --kernel-trace -d $OUT/pmc$i -o p -- python bench.py --steps 30 --warmup 10 --no-cpu-baseline --train-rounds 0 --roofline-steps 0 ${BENCH_ARGS} > $OUT/pmc$i.log 2>&1
   python tools/pmc_db_summary.py $(find $OUT/pmc$i -name "*.db") ; python - <<PY
 import pandas as pd, glob
 f=glob.glob("$OUT/pmc$i/**/p_counter_collection.csv", recursive=True)

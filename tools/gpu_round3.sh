@@ -19,7 +19,7 @@ if [ -n "$TWO_RANKS" ]; then
   python tools/bench_brief.py $OUT/bench2.json
 fi
 if [ -n "$TRACE" ]; then
-  rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python bench.py --steps 60 --warmup 15 --no-cpu-baseline --train-rounds 0 > $OUT/bench_traced.json 2> $OUT/trace.err
+  timeout -k 10 ${PROF_TIMEOUT:-300} rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python bench.py --steps 60 --warmup 15 --no-cpu-baseline --train-rounds 0 > $OUT/bench_traced.json 2> $OUT/trace.err
   python tools/bench_brief.py $OUT/bench_traced.json
   f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -12 "$f" && cp "$f" $OUT/kernel_stats.csv
 fi
