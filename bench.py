@@ -141,14 +141,16 @@ def ipc_env_setting(env, mode: str) -> str:
     return mode
 
 
-def newest_pmc_summary():
-    """profiles/rNN/pmc_summary.json of the newest round that has one (written by tools/pmc_summary.py from separate
-    rocprofv3 --pmc passes of this command)."""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]", "pmc_summary.json")))
-    if not files:
-        return None, None
-    with open(files[-1]) as f:
-        return json.load(f), os.path.relpath(files[-1], ROOT)
+def newest_pmc_summary(n_envs, n_agents, grid):
+    """profiles/rNN/pmc_summary*.json of the newest round that has one FOR THIS SHAPE (written by tools/pmc_summary.py from
+    separate rocprofv3 --pmc passes of this command: pmc_summary.json = config 2, pmc_summary_c4.json / _c5.json = the shapes of
+    BASELINE configs 4 and 5)."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]", "pmc_summary*.json")), reverse=True):
+        with open(path) as f:
+            rec = json.load(f)
+        if (rec.get("envs_per_gpu"), rec.get("n_agents"), rec.get("grid")) == (n_envs, n_agents, grid):
+            return rec, os.path.relpath(path, ROOT)
+    return None, None
 
 
 def main():
@@ -334,8 +336,8 @@ def main():
     torch.cuda.synchronize()
     copy_gbs = 3 * 2 * env.local.numel() * 4 / (ca.elapsed_time(cb) * 1e-3) / 1e9
     del scratch
-    pmc, pmc_path = newest_pmc_summary()
-    pmc_ok = bool(pmc) and pmc.get("envs_per_gpu") == E and pmc.get("n_agents") == N and pmc.get("grid") == grid[0]
+    pmc, pmc_path = newest_pmc_summary(E, N, grid[0])
+    pmc_ok = bool(pmc)
 
     TIMING = ("HIP start/stop events bound to each dispatch (hipExtLaunchKernelGGL): the kernel's own begin-to-end duration, as "
               "rocprofv3's kernel trace reports it; no bracket overhead to subtract, so frac_raw == frac")

@@ -403,7 +403,7 @@ k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int sta
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int sub = lane >> shift, gl = lane & (lpr - 1);
   const size_t TB = ippm_tile_bytes(S, VEC);
-  const __amdgpu_buffer_rsrc_t rmap = IPPM_K3_RSRC(local + (size_t)(e * n + i) * gx * gy, (size_t)gx * gy * 4);
+  const __amdgpu_buffer_rsrc_t rmap = IPPM_K3_RSRC(local + (size_t)(e * n + i) * IPPM_MAP_PITCH(gx, gy), (size_t)gx * gy * 4);
   const __amdgpu_buffer_rsrc_t rtruth = IPPM_K3_RSRC(truth + (size_t)e * ippm_truth_bytes(gx, gy), ippm_truth_bytes(gx, gy));
   const __amdgpu_buffer_rsrc_t rcode = IPPM_K3_RSRC(code + (size_t)(e * n + i) * TB, TB);
   const __amdgpu_buffer_rsrc_t rflip = IPPM_K3_RSRC(FLIPS ? flips + (size_t)(e * n + i) * TB : code, FLIPS ? TB : 0);
@@ -567,7 +567,7 @@ k_reset_maps(const ippm_config* __restrict__ c, const int64_t* __restrict__ epis
     if (xr <= xl || yd <= yu) { yu = yd = xl = xr = 0; }
   }
   const float lp = c->logit_prior;
-  float* map = is_global ? global + (size_t)e * gx * gy : local + (size_t)(e * n + m) * gx * gy;
+  float* map = is_global ? global + (size_t)e * IPPM_MAP_PITCH(gx, gy) : local + (size_t)(e * n + m) * IPPM_MAP_PITCH(gx, gy);
   const __amdgpu_buffer_rsrc_t rmap = IPPM_K3_RSRC(map, (size_t)gx * gy * 4);
   const bool mis = (gy & 3) != 0;
   const int fg0 = yu >> 2, fg1 = (yd + 3) >> 2;   // groups that meet the footprint's columns

@@ -104,7 +104,8 @@ __device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e,
   const int32_t* plan = w.plan + (size_t)map_abs * IPPM_WS_WORDS;
   const int last_op = plan[WS_PLAN + PL_LAST];
   const __amdgpu_buffer_rsrc_t rmap =
-      IPPM_T_RSRC(is_global ? w.global + (size_t)e * w.gx * w.gy : w.local + (size_t)(e * w.n + slot) * w.gx * w.gy, (size_t)w.gx * w.gy * 4);
+      IPPM_T_RSRC(is_global ? w.global + (size_t)e * IPPM_MAP_PITCH(w.gx, w.gy) : w.local + (size_t)(e * w.n + slot) * IPPM_MAP_PITCH(w.gx, w.gy),
+                  (size_t)w.gx * w.gy * 4);
   const __amdgpu_buffer_rsrc_t rcode = IPPM_T_RSRC(w.code, (size_t)w.n_envs * w.n * w.TB);
   // ---- trip 2a: the op records of the mask.  Spare slots come FIRST: an empty slot still clips, like every op of the reference
   // -- a no-op ahead of the first real op, but behind the last it would clip that op's unclamped outputs.

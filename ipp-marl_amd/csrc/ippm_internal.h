@@ -38,6 +38,12 @@
 #define OP_XR 6
 #define OP_LM1 7
 #define IPPM_MAX_OPS (IPPM_MAX_AGENTS + 2)
+// Variant builds only (make VARIANT=skewN EXTRA=-DIPPM_MAP_SKEW=N; tools/alloc_skew_sample.py): N floats of padding behind every map, honoured
+// by K3's tile form, the tile fusion and k_reset_maps -- the env-only step -- and by nothing else.  0 in the product library.
+#ifndef IPPM_MAP_SKEW
+#define IPPM_MAP_SKEW 0
+#endif
+#define IPPM_MAP_PITCH(gx, gy) ((size_t)(gx) * (size_t)(gy) + IPPM_MAP_SKEW)
 #define IPPM_COUNTER_SLOTS 64  // work counters are spread over 64 slots to keep atomics off one address
 
 // sums layout: double [E, 8]

@@ -48,11 +48,16 @@ def main():
         "kernel": "k_stream_copy of the local maps (ippm_stream_copy, 16 B per lane)", "bytes_each_way": copy_bytes,
         "FETCH_SIZE_reported_KiB": float(cal_f["mean"]), "WRITE_SIZE_reported_KiB": float(cal_w["mean"]),
         "fetch_correction": f_scale, "write_correction": w_scale}}
-    for key, pat in (("k_sense_update", "k_sense_tiles<4, false, false, true"), ("k_fuse_tiles", "k_fuse_tiles<6, false"), ("k_fuse_rows", "k_fuse_rows<4, false, 6, false>"),
+    # (prefixes: the most frequent instantiation of each kernel is the step's -- <6, ..> at 4 UAVs, <10, ..> at 8, <18, ..> at 16)
+    for key, pat in (("k_sense_update", "k_sense_tiles<"), ("k_fuse_tiles", "k_fuse_tiles<"), ("k_fuse_rows", "k_fuse_rows<"),
                      ("k_plan_step", "k_plan_step"), ("k_reset_maps", "k_reset_maps"), ("k_stream_copy", "k_stream_copy")):
         f, w = pick(fetch, pat), pick(write, pat)
+        if f is None or w is None:
+            continue
+        pat = f.name            # the instantiation's full name
+        w = pick(write, pat)
         t = trace[trace["kernel"].str.contains(pat, regex=False)]["us"]
-        if f is None or w is None or not len(t):
+        if w is None or not len(t):
             continue
         rd = float(f["mean"]) * 1024.0 * f_scale
         wr = float(w["mean"]) * 1024.0 * w_scale
