@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define IPPM_VERSION 301
+#define IPPM_VERSION 500
 #define IPPM_MAX_AGENTS 16
 #define IPPM_MAX_LATTICE 64 /* lattice points per horizontal axis */
 #define IPPM_MAX_Z 8        /* altitude levels */
@@ -67,7 +67,7 @@ extern "C" {
 #define IPPM_STEP_COMM 1   /* comm matrix + local-fusion plans */
 #define IPPM_STEP_GLOBAL 2 /* global-fusion plan */
 #define IPPM_STEP_MOVE 4   /* K1 mask/act/move (+ footprints of the new positions) */
-#define IPPM_STEP_TILES 8  /* write the work list as one-trip tile items (ippm_fuse_step on a context that has the tile form) */
+#define IPPM_STEP_TILES 8  /* accepted, implied: the work list's form follows the context (ippm_tile_form), see ippm_plan_step */
 #define IPPM_SENSE_REC_WORDS 8  /* words per agent of ippm_plan_step's rect_next / ippm_sense_step's rect_in */
 
 /* Derived constants, computed on the host in float64 with the reference's expression order
@@ -244,11 +244,13 @@ int ippm_fuse_global_reward(ippm_ctx* ctx, float* global, const uint8_t* code, c
  *                     with COMM/GLOBAL; a learned policy calls MOVE separately after the actor.
  *   work (optional, int32 [ippm_work_words()]): with COMM | GLOBAL the kernel also lists the non-empty work items of the
  *   step's fusion for ippm_fuse_step, every env into its own slice (count + items: written, never accumulated, so there is
- *   nothing to clear between steps).  Two forms: runs of rows of a plan's hull (map, run) -- consumed by ippm_fuse_step WITH
- *   area sums -- and, with IPPM_STEP_TILES, self-contained one-trip tile items (rows x column interval x op mask, each at most
- *   1024 cells) -- consumed by ippm_fuse_step WITHOUT area sums (the env-only step).  The flag must match the ippm_fuse_step
- *   call that follows; a mismatch fuses nothing and is counted in ippm_counters.reserved[0].  Configs without the tile form
- *   (grids not a multiple of 4 wide, mapping.prior != 0.5) ignore the flag on both sides.
+ *   nothing to clear between steps).  The list has one of two forms, chosen by the CONTEXT (ippm_tile_form()), not by the
+ *   caller: self-contained one-trip tile items (rows x column interval x op mask, each at most 1024 cells) on contexts that have
+ *   the tile form -- 16-byte lane groups (grid_y >= 44) and mapping.prior == 0.5 --, runs of rows of a plan's hull (map, run)
+ *   on all others.  ippm_fuse_step of the same context consumes whichever form ippm_plan_step wrote, with or without area
+ *   sums.  IPPM_STEP_TILES is accepted for source compatibility and changes nothing (it is implied where the tile form exists
+ *   and ignored where it does not).  A list that a kernel cannot read (written by another context's plan step, or overflowed)
+ *   fuses nothing and is counted in ippm_counters.reserved[0].
  * ippm_fuse_step: K4 for all local maps and K5 for all global maps from the plans above, in one launch; keeps `area`
  *   (optional) up to date; leaves the reward sums open (ippm_sense_step or ippm_reward_finalize completes them).  With the
  *   `work` list of the same step's ippm_plan_step a fixed number of resident wavefronts strides over exactly the non-empty

@@ -54,12 +54,15 @@ struct TileCtx {
 // The item's contribution to the area sums of its map: per lane-load the weighted sigmoid differences of its four cells into
 // the (at most) 2 x 2 bins the group meets.  `old4` / `new4`: the cells as loaded and as stored (a lane-load past the item's
 // end loaded zeros and stores nothing: zero difference).
+// MIS (rows not a multiple of 4 wide): the cells of a row's last group that hang over into the next row were loaded and run through
+// the chain but are never stored (another lane owns them): they contribute nothing here either.
+template <bool MIS>
 __device__ __forceinline__ void tile_area_slot(const TileCtx& w, int x, int y, const float* old4, const float* new4) {
   float d[4], sd = 0.f, cA = 0.f;
   const AreaCols<4> ac = area_cols<4>(y, w.gy, w.inv_gy);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    d[j] = sigmoid_diff(new4[j], old4[j]);
+    d[j] = (MIS && y + j >= w.gy) ? 0.f : sigmoid_diff(new4[j], old4[j]);
     sd += d[j];
     cA += ac.wA[j] * d[j];
   }
@@ -97,8 +100,10 @@ struct TileAcc {   // per wavefront, over all its items (all of one env)
 };
 
 // One item with at most NA ops (spare slots first) and SLOTS loads in flight per lane.
+// The item is a RUN of `cnt` lane-loads of its region (rows from x0 on, groups [g0, g0 + W)) in row-major order, starting at group
+// `gs` of row x0: lane-load t = q * 64 + lane (t < cnt) is element gs + t of that order.
 template <int NA, int SLOTS, bool MIS, bool TRACK>
-__device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e, int slot, int x0, int nr, int g0, int W, unsigned active) {
+__device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e, int slot, int x0, int cnt, int gs, int g0, int W, unsigned active) {
   const int map_abs = e * (w.n + 1) + slot;
   const bool is_global = slot == w.n;
   const int32_t* plan = w.plan + (size_t)map_abs * IPPM_WS_WORDS;
@@ -141,17 +146,17 @@ __device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e,
     va = *reinterpret_cast<const int4*>(plan + WS_OPS + o * OP_WORDS);
     vb = *reinterpret_cast<const int4*>(plan + WS_OPS + o * OP_WORDS + 4);
   }
-  // ---- trip 2b: every map cell of the item.  Lane-load t = q * 64 + lane -> (row t / W, group t % W); t < 256, W <= 256:
-  // floor(t / W) = (t * (floor(65536 / W) + 1)) >> 16 exactly.
-  const unsigned inv = (unsigned)(65536.0f * __builtin_amdgcn_rcpf((float)W)) + 1u;
+  // ---- trip 2b: every map cell of the item.  Lane-load t = q * 64 + lane -> element tt = gs + t of the region's row-major order
+  // -> (row tt / W, group tt % W); tt < 512, W <= 256: floor(tt / W) = (int)((tt + 0.5) * (1 / W)) exactly (ippm_div_small).
+  const float inv_w = __builtin_amdgcn_rcpf((float)W);
   CellVec<4> mv[SLOTS];
   int off[SLOTS], coff[SLOTS], ycol[SLOTS];
 #pragma unroll
   for (int q = 0; q < SLOTS; ++q) {
-    const unsigned t = (unsigned)(q * 64 + w.lane);
-    const int r = (int)((t * inv) >> 16);
-    const int gi = (int)t - r * W;
-    const bool valid = r < nr;
+    const int t = q * 64 + w.lane;
+    const int r = ippm_div_small(gs + t, inv_w);
+    const int gi = gs + t - r * W;
+    const bool valid = t < cnt;
     const int row = x0 + r, g = g0 + gi;
     off[q] = valid ? (row * w.gy + g * 4) * 4 : IPPM_T_OOB;
     coff[q] = row * w.row_bytes + g;
@@ -246,7 +251,7 @@ __device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e,
         __builtin_amdgcn_raw_buffer_store_b128(v, rmap, off[q], 0, IPPM_T_STORE_AUX);
       }
     }
-    if (TRACK) tile_area_slot(w, x0 + (int)(((unsigned)(q * 64 + w.lane) * inv) >> 16), ycol[q] == IPPM_T_FAR ? 0 : ycol[q], mv[q].v, out);
+    if (TRACK) tile_area_slot<MIS>(w, x0 + ippm_div_small(gs + q * 64 + w.lane, inv_w), ycol[q] == IPPM_T_FAR ? 0 : ycol[q], mv[q].v, out);
     if (is_global) {
       // information-gain terms (utils/reward.py:68-82) of the cells the step changed; an untouched cell contributes exact zeros
       // (same weight, same entropy).  Slots whose touched cells all have weight 0 before and after (believed free, still
@@ -328,18 +333,18 @@ k_fuse_tiles(const int32_t* __restrict__ work, int n_envs, int env_cap, int n, i
   acc.cells_l = acc.ops_l = acc.cells_g = acc.ops_g = 0;
   for (int i = first; i < count; i += step) {
     const int4 nx = items[min(i + step, env_cap - 1)];  // the next item travels while this one is worked on
-    const int slot = (unsigned)it.w >> 24, x0 = it.y & 0xFFFF, nr = it.y >> 16, g0 = it.z & 0xFFFF, W = it.z >> 16;
+    const int slot = (unsigned)it.w >> 24, gs = it.x & 0xFFFF, cnt = (unsigned)it.x >> 16, x0 = it.y, g0 = it.z & 0xFFFF, W = (unsigned)it.z >> 16;
     const unsigned active = (unsigned)it.w & 0x00FFFFFFu;
     const int na = __popc(active);
-    if (na == 1) tile_item<1, 4, MIS, TRACK>(w, acc, env, slot, x0, nr, g0, W, active);
-    else if (na == 2) tile_item<2, 4, MIS, TRACK>(w, acc, env, slot, x0, nr, g0, W, active);
-    else if (na == 3) tile_item<3, 4, MIS, TRACK>(w, acc, env, slot, x0, nr, g0, W, active);
-    else if (na == 4) tile_item<4, 4, MIS, TRACK>(w, acc, env, slot, x0, nr, g0, W, active);
-    else if (NAMAX <= 6 || na <= 6) tile_item<(NAMAX < 6 ? NAMAX : 6), IPPM_TILE_SLOTS_MID, MIS, TRACK>(w, acc, env, slot, x0, nr, g0, W, active);
-    else if (na <= 8) tile_item<8, IPPM_TILE_SLOTS_MID, MIS, TRACK>(w, acc, env, slot, x0, nr, g0, W, active);
-    else if (NAMAX <= 10 || na <= 10) tile_item<10, 2, MIS, TRACK>(w, acc, env, slot, x0, nr, g0, W, active);
-    else if (na <= 14) tile_item<14, 1, MIS, TRACK>(w, acc, env, slot, x0, nr, g0, W, active);
-    else tile_item<18, 1, MIS, TRACK>(w, acc, env, slot, x0, nr, g0, W, active);
+    if (na == 1) tile_item<1, 4, MIS, TRACK>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
+    else if (na == 2) tile_item<2, 4, MIS, TRACK>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
+    else if (na == 3) tile_item<3, 4, MIS, TRACK>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
+    else if (na == 4) tile_item<4, 4, MIS, TRACK>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
+    else if (NAMAX <= 6 || na <= 6) tile_item<(NAMAX < 6 ? NAMAX : 6), IPPM_TILE_SLOTS_MID, MIS, TRACK>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
+    else if (na <= 8) tile_item<8, IPPM_TILE_SLOTS_MID, MIS, TRACK>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
+    else if (NAMAX <= 10 || na <= 10) tile_item<10, 2, MIS, TRACK>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
+    else if (na <= 14) tile_item<14, 1, MIS, TRACK>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
+    else tile_item<18, 1, MIS, TRACK>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
     it = nx;
   }
   // the wavefront's reward terms and work counters: one atomic per quantity

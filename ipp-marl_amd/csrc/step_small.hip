@@ -239,34 +239,40 @@ __global__ void k_plan(const ippm_config* __restrict__ c, const int32_t* __restr
 // ======================================================================================================
 __device__ __forceinline__ int tb_lane_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
-// items of rows [xa, xb) x groups [g0, g1) with the ops of `mask`: their slots in the env's list are reserved with one LDS atomic
-// (the env's running item count), then written
-__device__ __forceinline__ void tile_items_of_interval(int4* items, int env_cap, int32_t* s_items, int env, int slot, int xa, int xb, int g0,
-                                                       int g1, unsigned mask) {
-  const int W = g1 - g0, rows = xb - xa;
+// The items of one REGION = rows [xa, xb) x groups [g0, g1) of a (slab, interval), met by the ops of `mask` (all arguments
+// wave-uniform; every lane takes part).  The region's lane-loads in row-major order, t = (row - xa) * W + (group - g0), are cut
+// into runs of 64 * slots: item i is the run [i * cap, i * cap + count) -- it starts wherever in a row the previous one ended, so
+// every item but a region's last is full whatever the width (round 4 cut regions into blocks of WHOLE rows, floor(cap / W) of
+// them: a 150-group interval filled 150 of 256 lane-loads, and at config 5's shape the list as a whole 77 %).  One LDS atomic
+// reserves the region's slots in the env's list, then lane l writes items l, l + 64, ...
+__device__ __forceinline__ void tile_emit_region(int4* items, int env_cap, int32_t* s_items, int slot, int xa, int xb, int g0, int g1,
+                                                 unsigned mask, int lane) {
+  const int W = g1 - g0, total = (xb - xa) * W;
   const int sl = ippm_tile_slots(__popc(mask));          // 4, 2 or 1
-  const int cap = 64 * sl;
-  const int nch = (W + cap - 1) / cap;                   // column chunks (1 unless the interval is wider than an item)
-  const int Wc = nch == 1 ? W : (W + nch - 1) / nch;
-  // exact floor(cap / Wc) and ceil(rows / rpi) through one float reciprocal each (operands < 2^12: never within 1e-4 of an integer
-  // boundary after the +0.5)
-  const int rpi = max(1, (int)(((float)cap + 0.5f) * __builtin_amdgcn_rcpf((float)Wc)));
-  const int nrb = (int)(((float)(rows + rpi - 1) + 0.5f) * __builtin_amdgcn_rcpf((float)rpi));
-  int k = atomicAdd(s_items, nch * nrb);
-  for (int rb = 0; rb < nrb; ++rb) {
-    const int x0 = xa + rb * rpi, nr = min(rpi, xb - x0);
-    for (int ch = 0; ch < nch; ++ch, ++k) {
-      const int g = g0 + ch * Wc, w = min(Wc, g1 - g);
-      if (k < env_cap) items[k] = make_int4(env, x0 | (nr << 16), g | (w << 16), (int)(mask | ((unsigned)slot << 24)));
-    }
+  const int sh = sl == 4 ? 8 : (sl == 2 ? 7 : 6);        // cap = 64 * slots = 1 << sh
+  const int n = (total + (1 << sh) - 1) >> sh;
+  int k0 = 0;
+  if (lane == 0) k0 = atomicAdd(s_items, n);
+  k0 = __builtin_amdgcn_readfirstlane(k0);
+  const float inv_w = __builtin_amdgcn_rcpf((float)W);
+  for (int i = lane; i < n; i += 64) {
+    const int t0 = i << sh;
+    int r = (int)((float)t0 * inv_w);                     // floor(t0 / W) to within one (t0 < 2^24), then exact
+    int gs = t0 - r * W;
+    if (gs < 0) { --r; gs += W; }
+    else if (gs >= W) { ++r; gs -= W; }
+    const int cnt = min(1 << sh, total - t0);
+    if (k0 + i < env_cap) items[k0 + i] = make_int4(gs | (cnt << 16), xa + r, g0 | (W << 16), (int)(mask | ((unsigned)slot << 24)));
   }
 }
 
 // All items of one map's plan (nops > 0, uniform) into the env's list.  s_ops: the plan's rectangles in LDS.
 // Lane l ranks edge l among the plan's 2 nops row edges; lane s then owns slab s and walks the plan's ops in ascending first
-// column (a second rank sort), merging their group ranges into intervals; every finished interval goes out at once (ONE pass: a
-// counting pass + prefix sum + second walk made the builder the plan kernel's critical path).  The order of an env's items in its
-// list is whatever the atomics make it; no result depends on it.
+// column (a second rank sort), merging their group ranges into intervals.  Whenever lanes have finished an interval the wave
+// stops walking and emits those regions one after the other, ALL lanes writing each region's items (tile_emit_region): with
+// every lane writing its own slab's items one by one the wave ran as long as its longest slab at every step of the walk -- at
+// config 5's shape (17 plans of up to 17 rectangles on 1024^2, thousands of items per map) that was most of the plan kernel's
+// 144 us.  The order of an env's items in its list is whatever the atomics make it; no result depends on it.
 __device__ __forceinline__ void tile_build_map(const int4* s_ops, int nops, int env, int slot, int4* items, int env_cap, int32_t* s_items,
                                                int lane) {
   const int n_edges = 2 * nops;
@@ -297,22 +303,28 @@ __device__ __forceinline__ void tile_build_map(const int4* s_ops, int nops, int 
   if (!slab_on) xb = xa;
   int g0 = 0, g1 = -1;
   unsigned mask = 0;
-  for (int r = 0; r < nops; ++r) {
-    const int o = tb_lane_i(order, r);  // op with the r-th smallest first column
-    const int yu = tb_lane_i(r_yu, o), yd = tb_lane_i(r_yd, o), xl = tb_lane_i(r_xl, o), xr = tb_lane_i(r_xr, o);
-    const bool in = slab_on && xl <= xa && xa < xr;
-    const int lo = yu >> 2, hi = (yd + 3) >> 2;
+  for (int r = 0; r <= nops; ++r) {      // r == nops: the intervals still open
+    bool in = false, done = mask != 0;
+    int lo = 0, hi = 0, o = 0;
+    if (r < nops) {
+      o = tb_lane_i(order, r);  // op with the r-th smallest first column
+      const int yu = tb_lane_i(r_yu, o), yd = tb_lane_i(r_yd, o), xl = tb_lane_i(r_xl, o), xr = tb_lane_i(r_xr, o);
+      in = slab_on && xl <= xa && xa < xr;
+      lo = yu >> 2; hi = (yd + 3) >> 2;
+      done = in && mask != 0 && lo > g1;  // a gap of at least one group: the interval so far is complete
+    }
+    for (unsigned long long pend = __ballot(done); pend != 0; pend &= pend - 1) {
+      const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)pend) - 1);
+      tile_emit_region(items, env_cap, s_items, slot, tb_lane_i(xa, src), tb_lane_i(xb, src), tb_lane_i(g0, src), tb_lane_i(g1, src),
+                       (unsigned)tb_lane_i((int)mask, src), lane);
+    }
+    if (done) mask = 0;
     if (in) {
-      if (mask != 0 && lo > g1) {  // a gap of at least one group: the interval so far is complete
-        tile_items_of_interval(items, env_cap, s_items, env, slot, xa, xb, g0, g1, mask);
-        mask = 0;
-      }
       if (mask == 0) { g0 = lo; g1 = hi; }
       else g1 = max(g1, hi);
       mask |= 1u << o;
     }
   }
-  if (mask != 0) tile_items_of_interval(items, env_cap, s_items, env, slot, xa, xb, g0, g1, mask);
 }
 
 // ======================================================================================================
@@ -601,7 +613,13 @@ extern "C" int ippm_plan_step(ippm_ctx* ctx, const int64_t* episode, int32_t* po
                               int32_t* rect_next, int32_t* work, int32_t n_envs, void* stream) {
   if (!ctx || !pos) { ippm_set_error("ippm_plan_step: null argument"); return -1; }
   if ((flags & (IPPM_STEP_COMM | IPPM_STEP_GLOBAL | IPPM_STEP_MOVE)) == 0 || (flags & ~15)) { ippm_set_error("ippm_plan_step: bad flags"); return -1; }
-  if ((flags & IPPM_STEP_TILES) && !ctx->tiles) flags &= ~IPPM_STEP_TILES;   // configs without the tile form keep the row-run list
+  // The form of the work list follows the CONTEXT, not the caller: ippm_fuse_step hands a list to the tile fusion exactly when
+  // the context has the tile form (and no measurement knob routes it to the row walker), so that is the form built here --
+  // IPPM_STEP_TILES is implied there and ignored elsewhere.  (Until round 5 the flag decided, and a caller who followed the
+  // header -- plan without the flag, fuse with area sums -- got a list the tile fusion skipped: no fusion, rc 0.)
+  const bool tile_ctx = ctx->tiles && !ctx->knob_nowork && !ctx->knob_split;
+  if (tile_ctx && work && (flags & (IPPM_STEP_COMM | IPPM_STEP_GLOBAL))) flags |= IPPM_STEP_TILES;
+  else flags &= ~IPPM_STEP_TILES;
   if ((flags & IPPM_STEP_COMM) && (!comm || !rect || !ws)) { ippm_set_error("ippm_plan_step: comm/plan needs comm, rect, ws"); return -1; }
   if ((flags & IPPM_STEP_COMM) && !draws && !episode) { ippm_set_error("ippm_plan_step: Philox draws need the episode ids"); return -1; }
   if ((flags & IPPM_STEP_GLOBAL) && (!rect || !ws)) { ippm_set_error("ippm_plan_step: global plan needs rect, ws"); return -1; }

@@ -567,6 +567,32 @@ def test_graph_replay_matches_eager():
         b.reset(eps + 100)
 
 
+def test_work_list_form_follows_the_context():
+    """A C caller that plans WITHOUT IPPM_STEP_TILES and fuses with (or without) area sums gets the same maps as one that passes
+    the flag: the form of the work list is the context's (include/ippmarl.h), so plan and fusion cannot disagree.  (ADVICE r04:
+    until round 5 such a caller's list was skipped by the tile fusion -- no fusion, no area update, rc 0.)"""
+    from ippmarl.vec_env import POLICY_UNIFORM
+    params = make_params("small")
+    for track in (True, False):
+        a, b = _env(params, 8, track_area=track), _env(params, 8, track_area=track)
+        assert a._tile_form
+        b._tile_form = False          # VecEnv then never sets the flag; the library must build the tile form all the same
+        eps = np.arange(5, 13)
+        a.reset(eps)
+        b.reset(eps)
+        for t in range(a.d.budget + 1):
+            a.build_observations(t, features=False)
+            b.build_observations(t, features=False)
+            a.steps(t, policy=POLICY_UNIFORM, features=False)
+            b.steps(t, policy=POLICY_UNIFORM, features=False)
+            assert torch.equal(a.local, b.local) and torch.equal(a.glob, b.glob) and torch.equal(a.pos, b.pos), (track, t)
+            assert int(b.work[0]) & 0x40000000, "the list was not written in the tile form"
+        assert float((a.glob != 0).float().mean()) > 0.2     # the global maps were fused at all
+        if track:
+            np.testing.assert_allclose(a.area.cpu().numpy(), b.area.cpu().numpy(), rtol=1e-12)
+        assert a.counters()["work_list_rejects"] == 0 and b.counters()["work_list_rejects"] == 0
+
+
 def test_fused_comm_and_plan_equals_separate_calls():
     """ippm_comm_fuse_local == ippm_comm_matrix + ippm_fuse_local (bitwise), incl. link failures and per-episode ranges."""
     from ippmarl.vec_env import POLICY_UNIFORM
