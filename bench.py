@@ -58,6 +58,8 @@ def bench_params(args):
         over["experiment__constraints__num_actions"] = args.actions
     if getattr(args, "episode_comm_range", False):
         over["experiment__uav__fix_range"] = False
+    if getattr(args, "comm_range", None) is not None:
+        over["experiment__uav__communication_range"] = args.comm_range
     return grid256_params(**over)
 
 
@@ -164,6 +166,7 @@ def main():
     ap.add_argument("--actions", type=int, default=None, choices=[4, 6, 9, 27], help="action set (default: params.yaml's 6)")
     ap.add_argument("--episode-comm-range", action="store_true", help="per-episode comm range from {0, 15, 25, 100} m "
                     "(experiment.uav.fix_range: False, BASELINE config 5's comm-range masking)")
+    ap.add_argument("--comm-range", type=float, default=None, help="experiment.uav.communication_range in metres (default: params.yaml's 25)")
     ap.add_argument("--terrain", default="random_field", choices=["random_field", "split"],
                     help="ground truth: the power-law random field of ground_truths.py:25-40 generated on the device, or "
                          "the half-plane split the reference flies over")

@@ -98,6 +98,18 @@ extern "C" int ippm_ctx_create(const ippm_config* cfg, ippm_ctx** out) {
   ctx->knob_split = knob("IPPM_FUSE_SPLIT", 0);
   ctx->knob_tile_waves = knob("IPPM_TILE_WAVES", 0);
   ctx->knob_plan_builders = knob("IPPM_PLAN_BUILDERS", 0);
+  // Workgroup shape of the env-only step's K3 (wavefronts per workgroup x loads in flight per lane), by the width of the widest
+  // footprint row in 4-cell groups.  Measured on one allocation per grid, alternating episodes (tools/ab_knobs.py,
+  // profiles/r05/k3_workgroup_shapes.txt): 256^2 (W = 23): (4,3) 35.2 us, (2,2) 34.4; 512^2 (W = 46): (4,3) 67.6, (2,2) 64.2, (1,3)
+  // 69.9; 1024^2 (W = 91): (4,3) 94.5, (2,3) 93.8, (2,2) 100.4, (4,4) 162.7.  Short rows: many small workgroups with two loads in
+  // flight; long rows (a load instruction no longer spans a row segment): fewer, with three.
+  {
+    int wmax = 1;
+    for (int k = 0; k < c.space_z; ++k) wmax = std::max(wmax, (2 * c.radius_y[k] + 3) / 4 + 1);
+    const bool narrow = wmax <= 64;
+    ctx->k3_wpg = knob("IPPM_K3_WPG", narrow ? 2 : 4);
+    ctx->k3_chn = knob("IPPM_K3_CHN", narrow ? 2 : 3);
+  }
   ctx->knob_k3_dense = knob("IPPM_K3_DENSE", 1);   // 0: the power-of-two lane layout of round 3 (A/B: tools/ab_knobs.py)
   ctx->tiles = (ctx->vec == 4 && c.logit_prior == 0.f && c.grid_x < 32768 && c.grid_y <= 1024 && !knob("IPPM_NO_TILES", 0)) ? 1 : 0;
   int rc = ippm_check_hip(hipMalloc(&ctx->dcfg, sizeof(ippm_config)), "hipMalloc(cfg)");
@@ -192,6 +204,7 @@ extern "C" int ippm_read_kernel_times(ippm_ctx* ctx, int32_t cls, int32_t reset,
     // "(k_fuse_rows<4, false, 6, false>)" as written at the launch site -> without the macro's parentheses
     std::string s = ctx->ev_name[cls] ? ctx->ev_name[cls] : "";
     if (s.size() >= 2 && s.front() == '(' && s.back() == ')') s = s.substr(1, s.size() - 2);
+    for (size_t at; (at = s.find(" >")) != std::string::npos;) s.erase(at, 1);   // (an empty variadic tail of the launch macro leaves "false >")
     std::strncpy(name, s.c_str(), (size_t)name_len - 1);
     name[name_len - 1] = 0;
   }

@@ -315,8 +315,9 @@ typedef unsigned ippm_k3_u4 __attribute__((ext_vector_type(4)));
 // are compile-time so that the production instantiation <4, false, false> carries neither the second Philox call and the
 // cell-by-cell tail stores nor the flips resource (the kernel sits at the SGPR limit: every uniform it holds less is a
 // v_writelane / v_readlane pair less in its instruction stream).
-template <int VEC, bool MIS, bool FLIPS, bool REC, bool DENSE, bool TRACK>
-__global__ void __launch_bounds__(64 * IPPM_K3_WAVES)
+// WPG x CH: wavefronts per workgroup and loads in flight per lane (the production shape is chosen per grid width, ippm_sense_step)
+template <int VEC, bool MIS, bool FLIPS, bool REC, bool DENSE, bool TRACK, int WPG = IPPM_K3_WAVES, int CHN = IPPM_K3_CH>
+__global__ void __launch_bounds__(64 * WPG)
 k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int stage, int rows_per_part, int gy, int gx,
               float* __restrict__ local, const uint8_t* __restrict__ truth, const int64_t* __restrict__ episode,
               uint8_t* __restrict__ code, int S_arg, float lc_arg, uint32_t k0_arg, uint32_t k1_arg,
@@ -329,10 +330,17 @@ k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int sta
   // dependent scalar round trips.  The first 14 argument words arrive in SGPRs with the wavefront (kernel-argument preload,
   // csrc/Makefile): the address of the agent's sense record (K1: footprint + the measurement constants of its altitude) needs
   // nothing else, and every config scalar the kernel uses is passed by value -- one scalar round trip, then the map loads.
-  constexpr int CH = IPPM_K3_CH;
+  constexpr int CH = CHN;
   // grid = (row parts, agents, envs): no index arithmetic to undo
+#ifdef IPPM_K3_GRID_SWAP   // experiment: consecutive workgroups = the agents of an env, a map's parts n workgroups apart
+  const int part = blockIdx.y, e = blockIdx.z, i = agent_sel >= 0 ? agent_sel : (int)blockIdx.x;
+  const int tile = e * n + (int)blockIdx.x;
+  const int agent_blk = blockIdx.x;
+#else
   const int part = blockIdx.x, e = blockIdx.z, i = agent_sel >= 0 ? agent_sel : (int)blockIdx.y;
   const int tile = e * n + (int)blockIdx.y;
+  const int agent_blk = blockIdx.y;
+#endif
   int r[4];
   float lm0, lm1;
   uint32_t thr;
@@ -368,22 +376,25 @@ k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int sta
   const int h = xr - xl, w = yd - yu;
   const int y0 = yu & ~(VEC - 1), tile_y0 = yu & ~3;
   const int groups = (yd - y0 + VEC - 1) / VEC;
-  // DENSE: the three loads of a lane are lane-loads t = q * 64 + lane of the wavefront's rows in row-major order, (row t / W,
-  // group t % W) with W = groups -- a load instruction then covers 64 consecutive groups (2.7 whole 368-byte row segments of a
-  // 15 m footprint) instead of eight 128-byte pieces of eight rows; a wavefront takes floor(192 / W) rows, a part four times that
-  int dense_rpw = 0;
-  unsigned dense_inv = 0;
+  // DENSE: the footprint's 4-cell groups in ROW-MAJOR order, T = row * W + group (W = groups per row), are dealt out in runs: a
+  // wavefront takes CH * 64 consecutive ones, its lane's loads are T = base + q * 64 + lane -- a load instruction covers 64
+  // consecutive groups (2.7 whole 368-byte row segments of a 15 m footprint at 256^2) and every wavefront but a footprint's last
+  // is full whatever the width.  (Round 4 gave a wavefront floor(CH * 64 / W) whole rows: 184 of 192 lane-loads at 256^2 and 512^2,
+  // and no shape with fewer than two rows per wavefront -- 1024^2 could not run with two loads in flight.)
+  float dense_invw = 0.f;
+  int dense_base = 0, dense_total = 0;
   int part_rows = rows_per_part;
   if (DENSE) {
-    dense_inv = (unsigned)(65536.0f * __builtin_amdgcn_rcpf((float)max(groups, 1))) + 1u;   // floor(t / W) = (t * inv) >> 16 for t <= 192, W <= 192
-    dense_rpw = (int)(((unsigned)(CH * 64) * dense_inv) >> 16);
-    part_rows = IPPM_K3_WAVES * dense_rpw;
+    dense_invw = __builtin_amdgcn_rcpf((float)max(groups, 1));   // floor(T / W) = (int)((T + 0.5) / W) exactly for T < 2^20 (ippm_div_small)
+    dense_total = h * groups;
+    dense_base = (part * WPG + (int)(threadIdx.x >> 6)) * (CH * 64);
+    part_rows = h;      // (r0, r1 below only decide whether the workgroup has work: part * WPG * CH * 64 < total)
   }
-  const int r0 = part * part_rows, r1 = min(h, r0 + part_rows);
+  const int r0 = DENSE ? (part * WPG * CH * 64 < dense_total ? 0 : h) : part * part_rows, r1 = min(h, r0 + part_rows);
   // the reward of the step whose global fusion ran in the launch before this one: any one thread per env completes it (last:
   // nothing of this launch waits for it)
   if (w <= 0 || r0 >= r1) {
-    if (sums && part == 0 && blockIdx.y == 0 && threadIdx.x == 0) ippm_reward_finalize_env(c, sums, reward, e);
+    if (sums && part == 0 && agent_blk == 0 && threadIdx.x == 0) ippm_reward_finalize_env(c, sums, reward, e);
     return;
   }
   // TRACK: the map's 11 x 11 area sums (K6's view of it, ippm_tiles.h) follow the cells this workgroup changes: weighted sigmoid
@@ -410,7 +421,7 @@ k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int sta
   const uint32_t sw = ippm_stream_word((uint32_t)i, (uint32_t)stage, IPPM_DOMAIN_FLIP);
   float amax = 0.f;
   for (int gbase = 0; gbase < (DENSE ? 1 : groups); gbase += CH * lpr) {     // one trip unless the footprint is wider than 3 x 64 groups
-    for (int row0 = r0 + wv * (DENSE ? dense_rpw : rpw) + (DENSE ? 0 : sub); row0 < r1; row0 += IPPM_K3_WAVES * rpw) {  // one trip for the common footprints
+    for (int row0 = r0 + (DENSE ? 0 : wv * rpw + sub); row0 < r1; row0 += WPG * rpw) {  // one trip for the common footprints
       CellVec<VEC> m[CH];
       uint32_t tw[CH], fw[CH];
       int cellv[CH], rowv[CH], yv[CH];
@@ -419,11 +430,11 @@ k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int sta
       for (int q = 0; q < CH; ++q) {
         int row, y;
         if (DENSE) {
-          const unsigned t = (unsigned)(q * 64 + lane);
-          const int rr = (int)((t * dense_inv) >> 16);
-          const int gi = (int)t - rr * groups;
-          row = row0 + rr;
-          on[q] = rr < dense_rpw && row < r1;
+          const int T = dense_base + q * 64 + lane;
+          const int rr = ippm_div_small(T, dense_invw);
+          const int gi = T - rr * groups;
+          row = rr;
+          on[q] = T < dense_total;
           y = y0 + gi * VEC;
         } else {
           const int gidx = gbase + gl + q * lpr;
@@ -450,7 +461,7 @@ k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int sta
 #pragma unroll
       for (int q = 0; q < CH; ++q) {
         // wave-uniform: narrow footprints use one or two of the three passes
-        if (DENSE ? (q * 64 >= dense_rpw * groups) : (gbase + q * lpr >= groups)) continue;
+        if (DENSE ? (dense_base + q * 64 >= dense_total) : (gbase + q * lpr >= groups)) continue;
         int y = yv[q];
         // (the column masks below do not depend on the row: left alone they are hoisted in front of the loads, ~60 instructions
         // between the wavefront's start and its first memory request)
@@ -523,7 +534,7 @@ k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int sta
   if (ws && __any(amax > lc) && lane == 0) ws[(size_t)(e * (n + 1) + i) * IPPM_WS_WORDS + WS_FLAG_S] = 1;
   if (counters && part == 0 && threadIdx.x == 0)
     atomicAdd(&counters[(tile & (IPPM_COUNTER_SLOTS - 1)) * 8 + 0], (unsigned long long)h * w);
-  if (sums && part == 0 && blockIdx.y == 0 && threadIdx.x == 0) ippm_reward_finalize_env(c, sums, reward, e);
+  if (sums && part == 0 && agent_blk == 0 && threadIdx.x == 0) ippm_reward_finalize_env(c, sums, reward, e);
   if (TRACK) {
     __syncthreads();
     area_lds_commit(s_area, area + (size_t)(e * (n + 1) + i) * IPPM_FEAT * IPPM_FEAT);
@@ -827,31 +838,46 @@ extern "C" int ippm_sense_step(ippm_ctx* ctx, const int64_t* episode, const int3
     const ippm_config& c = ctx->cfg;
     int h_max = 1;
     for (int k = 0; k < c.space_z; ++k) h_max = std::max(h_max, 2 * c.radius_x[k]);
-    const int rows_per_part = std::max(4, env_int("IPPM_K3_ROWS", 8 * IPPM_K3_WAVES));
-    block = dim3(64 * IPPM_K3_WAVES);
+    // workgroup shape: wavefronts per workgroup x loads in flight per lane.  (4, 3) unless the production combination below runs
+    // with another one (knobs IPPM_K3_WPG / IPPM_K3_CHN, or the per-grid-width choice of ippm_ctx_create)
+    int wpg = IPPM_K3_WAVES, chn = IPPM_K3_CH;
+    const bool shaped = ctx->vec == 4 && !flips && rect_in && !area && (c.grid_y & 3) == 0 && ctx->knob_k3_dense != 0;
+    if (shaped) { wpg = ctx->k3_wpg; chn = ctx->k3_chn; }
+    const int rows_per_part = std::max(4, env_int("IPPM_K3_ROWS", 8 * wpg));
+    block = dim3(64 * wpg);
     int parts = (h_max + rows_per_part - 1) / rows_per_part;
-    // dense lane mapping (k_sense_tiles<..., DENSE>): a part is 4 * floor(192 / W) rows, W = the footprint's 4-cell groups (one
-    // more than its width needs when it starts off a group boundary); every altitude must get at least two rows per wavefront
-    bool dense = ctx->vec == 4 && ctx->knob_k3_dense != 0;
+    // dense lane mapping (k_sense_tiles<..., DENSE>): a part is a run of wpg * chn * 64 of the footprint's row-major 4-cell groups
+    // (W per row: one more than its width needs when it starts off a group boundary)
+    const bool dense = ctx->vec == 4 && ctx->knob_k3_dense != 0;
     if (dense) {
       int need = 1;
       for (int k = 0; k < c.space_z; ++k) {
-        const int wmax = (2 * c.radius_y[k] + 3) / 4 + 1, rpw = (64 * IPPM_K3_CH) / std::max(1, wmax);
-        if (rpw < 2) { dense = false; break; }
-        need = std::max(need, (2 * c.radius_x[k] + IPPM_K3_WAVES * rpw - 1) / (IPPM_K3_WAVES * rpw));
+        const int wmax = (2 * c.radius_y[k] + 3) / 4 + 1;
+        need = std::max(need, (2 * c.radius_x[k] * wmax + wpg * chn * 64 - 1) / (wpg * chn * 64));
       }
-      if (dense) parts = need;
+      parts = need;
     }
     if (n_envs > 65535) { ippm_set_error("ippm_sense_step: more than 65535 envs per launch"); return -1; }
+#ifdef IPPM_K3_GRID_SWAP
+    dim3 grid((unsigned)(agent_sel >= 0 ? 1 : c.n_agents), (unsigned)parts, (unsigned)n_envs);
+#else
     dim3 grid((unsigned)parts, (unsigned)(agent_sel >= 0 ? 1 : c.n_agents), (unsigned)n_envs);
+#endif
     int32_t* rect_out = rect_in == rect ? nullptr : rect;
-#define IPPM_K3T___(V, M, F, R, D, T)                                                                                       \
-  IPPM_LAUNCH(ctx, IPPM_T_SENSE, (k_sense_tiles<V, M, F, R, D, T>), grid, block, S_(stream), rect_in, c.n_agents, agent_sel, stage, rows_per_part, \
+#define IPPM_K3T___(V, M, F, R, D, T, ...)                                                                                       \
+  IPPM_LAUNCH(ctx, IPPM_T_SENSE, (k_sense_tiles<V, M, F, R, D, T __VA_OPT__(,) __VA_ARGS__>), grid, block, S_(stream), rect_in, c.n_agents, agent_sel, stage, rows_per_part, \
               c.grid_y, c.grid_x, local, truth, episode, code, c.tile_stride, c.logit_clip, (uint32_t)c.philox_seed,                 \
               (uint32_t)(c.philox_seed >> 32), ctx->dcfg, pos, flips, rect_out, ws, sums, reward, ctx->dcounters, area)
 #define IPPM_K3T__(V, M, F, R, D) do { if (area) IPPM_K3T___(V, M, F, R, D, true); else IPPM_K3T___(V, M, F, R, D, false); } while (0)
 #define IPPM_K3T_(V, M, F, R) do { if (dense) IPPM_K3T__(V, M, F, R, true); else IPPM_K3T__(V, M, F, R, false); } while (0)
 #define IPPM_K3T(V, M, F) do { if (rect_in) IPPM_K3T_(V, M, F, true); else IPPM_K3T_(V, M, F, false); } while (0)
+    if (shaped && !(wpg == IPPM_K3_WAVES && chn == IPPM_K3_CH)) {   // the closing K3 of the env-only step in another workgroup shape
+#define IPPM_K3S(W_, C_) if (wpg == W_ && chn == C_) { IPPM_K3T___(4, false, false, true, true, false, W_, C_); IPPM_LAUNCH_CHECK("sense_tiles"); return 0; }
+      IPPM_K3S(1, 3) IPPM_K3S(2, 3) IPPM_K3S(2, 2) IPPM_K3S(1, 4) IPPM_K3S(2, 4) IPPM_K3S(4, 4) IPPM_K3S(4, 2)
+#undef IPPM_K3S
+      ippm_set_error("ippm_sense_step: no instantiation for this K3 shape (IPPM_K3_WPG x IPPM_K3_CHN)");
+      return -1;
+    }
     const bool mis = (c.grid_y & 3) != 0;
     if (ctx->vec == 4) {
       if (flips) { if (mis) IPPM_K3T(4, true, true); else IPPM_K3T(4, false, true); }

@@ -114,16 +114,13 @@ __device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e,
   const __amdgpu_buffer_rsrc_t rcode = IPPM_T_RSRC(w.code, (size_t)w.n_envs * w.n * w.TB);
   // ---- trip 2a: the op records of the mask.  Spare slots come FIRST: an empty slot still clips, like every op of the reference
   // -- a no-op ahead of the first real op, but behind the last it would clip that op's unclamped outputs.
-  // Small plans: uniform addresses, scalar loads, the fields stay in SGPRs.  Larger ones: lane o fetches op o, fields by readlane.
-  constexpr bool SCALAR_OPS = NA <= 6;
+  // Uniform addresses, scalar loads: the fields stay in SGPRs (NA <= 6; items met by more ops: tile_item_long).
+  static_assert(NA <= 6, "straight-line chains are compiled for up to six ops");
   const int pad = NA - __popc(active);
-  int s_yu[SCALAR_OPS ? NA : 1], s_yd[SCALAR_OPS ? NA : 1], cs[NA];
-  float s_lm0[SCALAR_OPS ? NA : 1], s_lm1[SCALAR_OPS ? NA : 1];
-  int v_yu = 0, v_yd = 0, v_cs = 0;
-  float v_lm0 = 0.f, v_lm1 = 0.f;
+  int s_yu[NA], s_yd[NA], cs[NA];
+  float s_lm0[NA], s_lm1[NA];
   int keep_slot = -1;
-  int4 va = make_int4(0, 0, 0, 0), vb = make_int4(0, 0, 0, 0);
-  if constexpr (SCALAR_OPS) {
+  {
     unsigned rem = active;
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
@@ -141,10 +138,6 @@ __device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e,
       cs[k] = isf ? (e * w.n + a.y) * w.TB - b.y * w.row_bytes - (a.w >> 2) : 0;
       keep_slot = idx == last_op ? k : keep_slot;
     }
-  } else {
-    const int o = min(w.lane, IPPM_MAX_OPS - 1);
-    va = *reinterpret_cast<const int4*>(plan + WS_OPS + o * OP_WORDS);
-    vb = *reinterpret_cast<const int4*>(plan + WS_OPS + o * OP_WORDS + 4);
   }
   // ---- trip 2b: every map cell of the item.  Lane-load t = q * 64 + lane -> element tt = gs + t of the region's row-major order
   // -> (row tt / W, group tt % W); tt < 512, W <= 256: floor(tt / W) = (int)((tt + 0.5) * (1 / W)) exactly (ippm_div_small).
@@ -164,23 +157,6 @@ __device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e,
     const ippm_t_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rmap, off[q], 0, IPPM_T_LOAD_AUX);
     mv[q].v[0] = __uint_as_float(v.x); mv[q].v[1] = __uint_as_float(v.y); mv[q].v[2] = __uint_as_float(v.z); mv[q].v[3] = __uint_as_float(v.w);
   }
-  if constexpr (!SCALAR_OPS) {
-    const bool on = w.lane < IPPM_MAX_OPS && ((active >> w.lane) & 1u);
-    const bool isf = on && va.x != 0;
-    v_yu = on ? va.w : 0; v_yd = on ? vb.x : 0;
-    v_lm0 = isf ? __int_as_float(va.z) : 0.f;
-    v_lm1 = isf ? __int_as_float(vb.w) : 0.f;
-    v_cs = isf ? (e * w.n + va.y) * w.TB - vb.y * w.row_bytes - (va.w >> 2) : 0;
-    unsigned rem = active;
-#pragma unroll
-    for (int k = 0; k < NA; ++k) {
-      if (k < pad) { cs[k] = 0; continue; }
-      const int idx = __ffs(rem) - 1;
-      rem &= rem - 1u;
-      cs[k] = t_lane_i(v_cs, idx);
-      keep_slot = idx == last_op ? k : keep_slot;
-    }
-  }
   // ---- trip 3: one measurement-code byte per (slot, op)
   uint32_t cw[SLOTS][NA];
 #pragma unroll
@@ -198,20 +174,10 @@ __device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e,
 #pragma unroll
     for (int j = 0; j < 4; ++j) L[j] = mv[q].v[j];
     unsigned touched = 0, keepm = 0;
-    unsigned rem = active;
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
-      int yu, yd;
-      float lm0, lm1;
-      if constexpr (SCALAR_OPS) { yu = s_yu[k]; yd = s_yd[k]; lm0 = s_lm0[k]; lm1 = s_lm1[k]; }
-      else {
-        if (k < pad) { yu = 0; yd = 0; lm0 = 0.f; lm1 = 0.f; }
-        else {
-          const int idx = __ffs(rem) - 1;
-          rem &= rem - 1u;
-          yu = t_lane_i(v_yu, idx); yd = t_lane_i(v_yd, idx); lm0 = t_lane_f(v_lm0, idx); lm1 = t_lane_f(v_lm1, idx);
-        }
-      }
+      const int yu = s_yu[k], yd = s_yd[k];
+      const float lm0 = s_lm0[k], lm1 = s_lm1[k];
       // cells y .. y+3 of my group inside [yu, yd): bits [lo, hi)
       const int lo = min(max(yu - ycol[q], 0), 4), hi = min(max(yd - ycol[q], 0), 4);
       const unsigned cm = ((1u << (hi - lo)) - 1u) << lo;
@@ -283,14 +249,146 @@ __device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e,
   else { acc.cells_l += cells; acc.ops_l += opcells; }
 }
 
+// An item met by MORE than six ops (4 % of the lane-loads at config 5's shape, 0.1 % at config 4's): the same run of lane-loads,
+// two in flight per lane, but the chain runs one op per iteration of a run-time loop -- the next op's record (scalar) and code
+// bytes are requested before the current op's clip-and-add -- with the cells in registers throughout.  The kernel therefore needs
+// the registers of a six-op item whatever the team size; round 4 compiled straight-line chains of 8 / 10 / 14 / 18 ops into the
+// kernels of larger teams: 94 VGPRs, five wavefronts per SIMD, for every item of config 4 because one item in a thousand meets
+// seven ops.  Same arithmetic: the spare slots of a straight-line chain are clips ahead of a real op's own clip.
+template <bool MIS, bool TRACK>
+__device__ __forceinline__ void tile_item_long(const TileCtx& w, TileAcc& acc, int e, int slot, int x0, int cnt, int gs, int g0, int W, unsigned active) {
+  constexpr int SLOTS = 2;
+  const int map_abs = e * (w.n + 1) + slot;
+  const bool is_global = slot == w.n;
+  const int32_t* plan = w.plan + (size_t)map_abs * IPPM_WS_WORDS;
+  const int last_op = plan[WS_PLAN + PL_LAST];
+  const __amdgpu_buffer_rsrc_t rmap =
+      IPPM_T_RSRC(is_global ? w.global + (size_t)e * IPPM_MAP_PITCH(w.gx, w.gy) : w.local + (size_t)(e * w.n + slot) * IPPM_MAP_PITCH(w.gx, w.gy),
+                  (size_t)w.gx * w.gy * 4);
+  const __amdgpu_buffer_rsrc_t rcode = IPPM_T_RSRC(w.code, (size_t)w.n_envs * w.n * w.TB);
+  const float inv_w = __builtin_amdgcn_rcpf((float)W);
+  CellVec<4> mv[SLOTS];
+  float L[SLOTS][4];
+  int off[SLOTS], coff[SLOTS], ycol[SLOTS];
+  unsigned touched[SLOTS], keepm[SLOTS];
+#pragma unroll
+  for (int q = 0; q < SLOTS; ++q) {
+    const int t = q * 64 + w.lane;
+    const int r = ippm_div_small(gs + t, inv_w);
+    const int gi = gs + t - r * W;
+    const bool valid = t < cnt;
+    const int row = x0 + r, g = g0 + gi;
+    off[q] = valid ? (row * w.gy + g * 4) * 4 : IPPM_T_OOB;
+    coff[q] = row * w.row_bytes + g;
+    ycol[q] = valid ? g * 4 : IPPM_T_FAR;
+    touched[q] = 0; keepm[q] = 0;
+    const ippm_t_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rmap, off[q], 0, IPPM_T_LOAD_AUX);
+    mv[q].v[0] = __uint_as_float(v.x); mv[q].v[1] = __uint_as_float(v.y); mv[q].v[2] = __uint_as_float(v.z); mv[q].v[3] = __uint_as_float(v.w);
+  }
+  // one op: its record (two 16-byte scalar loads) and its code byte per slot
+  struct OpIn { int idx, yu, yd; float lm0, lm1; uint32_t cw[SLOTS]; };
+  unsigned rem = active;
+  auto fetch = [&](OpIn& o) __attribute__((always_inline)) {
+    o.idx = __ffs(rem) - 1;
+    rem &= rem - 1u;
+    const int4 a = *reinterpret_cast<const int4*>(plan + WS_OPS + o.idx * OP_WORDS);       // {type, src, lm0, yu}
+    const int4 b = *reinterpret_cast<const int4*>(plan + WS_OPS + o.idx * OP_WORDS + 4);   // {yd, xl, xr, lm1}
+    const bool isf = a.x != 0;
+    o.yu = a.w; o.yd = b.x;
+    o.lm0 = isf ? __int_as_float(a.z) : 0.f;
+    o.lm1 = isf ? __int_as_float(b.w) : 0.f;
+    const int cs = isf ? (e * w.n + a.y) * w.TB - b.y * w.row_bytes - (a.w >> 2) : 0;
+#pragma unroll
+    for (int q = 0; q < SLOTS; ++q) o.cw[q] = __builtin_amdgcn_raw_buffer_load_b8(rcode, coff[q] + cs, 0, 0);
+  };
+  OpIn cur, nxt;
+  fetch(cur);
+#pragma unroll
+  for (int q = 0; q < SLOTS; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) L[q][j] = mv[q].v[j];
+  unsigned cells = 0, opcells = 0;
+  bool keeps = false;
+  for (;;) {
+    const bool more = rem != 0;
+    if (more) fetch(nxt);
+    const bool is_last = cur.idx == last_op;   // (the plan's last op has the highest index: if the item meets it, it ends the chain)
+    keeps = keeps || is_last;
+#pragma unroll
+    for (int q = 0; q < SLOTS; ++q) {
+      const int lo = min(max(cur.yu - ycol[q], 0), 4), hi = min(max(cur.yd - ycol[q], 0), 4);
+      const unsigned cm = ((1u << (hi - lo)) - 1u) << lo;
+      touched[q] |= cm;
+      keepm[q] = is_last ? cm : keepm[q];
+      opcells += (cur.lm0 != 0.f || cur.lm1 != 0.f) ? __popc(cm) : 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float lm = ippm_masked(ippm_bitmask(cm, j), ippm_blend(ippm_bitmask(cur.cw[q], j), cur.lm1, cur.lm0));
+        L[q][j] = ippm_clampl(L[q][j], w.lc) + lm;
+      }
+    }
+    if (!more) break;
+    cur = nxt;
+  }
+  float amax = 0.f;
+#pragma unroll
+  for (int q = 0; q < SLOTS; ++q) {
+    cells += __popc(touched[q]);
+    float out[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[j] = ippm_blend(ippm_bitmask(keeps ? keepm[q] : 0u, j), L[q][j], ippm_clampl(L[q][j], w.lc));
+    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(out[0]), fabsf(out[1])), fmaxf(fabsf(out[2]), fabsf(out[3]))));
+    {
+      ippm_t_u4 v;
+      v.x = __float_as_uint(out[0]); v.y = __float_as_uint(out[1]); v.z = __float_as_uint(out[2]); v.w = __float_as_uint(out[3]);
+      if (MIS) {
+        const bool tail = ycol[q] + 4 > w.gy;
+        __builtin_amdgcn_raw_buffer_store_b128(v, rmap, tail ? IPPM_T_OOB : off[q], 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(v.x, rmap, tail ? off[q] : IPPM_T_OOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(v.y, rmap, tail && ycol[q] + 1 < w.gy ? off[q] + 4 : IPPM_T_OOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(v.z, rmap, tail && ycol[q] + 2 < w.gy ? off[q] + 8 : IPPM_T_OOB, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b128(v, rmap, off[q], 0, IPPM_T_STORE_AUX);
+      }
+    }
+    if (TRACK) tile_area_slot<MIS>(w, x0 + ippm_div_small(gs + q * 64 + w.lane, inv_w), ycol[q] == IPPM_T_FAR ? 0 : ycol[q], mv[q].v, out);
+    if (is_global) {   // the reward terms, as in tile_item
+      float wa[4], wb[4], wsum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t tm = ippm_bitmask(touched[q], j);
+        wa[j] = ippm_masked(tm, ippm_weight_l(out[j], w.wt));
+        wb[j] = ippm_masked(tm, ippm_weight_l(mv[q].v[j], w.wt));
+        wsum += wa[j] + wb[j];
+      }
+      if (__any(wsum != 0.f)) {
+        float s1 = 0.f, sD = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float hb = ippm_entropy_l(mv[q].v[j], w.lc), ha = ippm_entropy_l(out[j], w.lc);
+          s1 += wa[j] * (hb - ha);
+          sD += (wa[j] - wb[j]) * hb;
+        }
+        acc.a1 += (double)s1;
+        acc.aD += (double)sD;
+      }
+    }
+  }
+  if (__any(amax > w.lc) && w.lane == 0) w.ws[(size_t)map_abs * IPPM_WS_WORDS + WS_FLAG_A] = 1;
+  if (TRACK) tile_area_flush(w, map_abs);
+  if (is_global) { acc.cells_g += cells; acc.ops_g += opcells; }
+  else { acc.cells_l += cells; acc.ops_l += opcells; }
+}
+
 // Workgroup = one wavefront; gridDim.x is a multiple of the env count: wavefront b serves env b % E and takes every
 // (gridDim.x / E)-th item of the env's list.
-// (wavefronts per SIMD: 5 in general; the production instantiation <6, false> fits in 80 VGPRs without scratch and takes 6: +1 %)
+// (wavefronts per SIMD: the untracked instantiation fits in 80 VGPRs without scratch and takes 6 -- for every team size since
+// round 5, items met by more than six ops run the chain in chunks)
 #ifndef IPPM_TILE_WAVES_PER_EU
 #define IPPM_TILE_WAVES_PER_EU 5
 #endif
-template <int NAMAX, bool MIS, bool TRACK>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NAMAX <= 6 && !MIS && !TRACK ? 6 : (TRACK ? 4 : IPPM_TILE_WAVES_PER_EU), 8)))
+template <bool MIS, bool TRACK>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(!MIS && !TRACK ? 6 : (TRACK ? 4 : IPPM_TILE_WAVES_PER_EU), 8)))
 k_fuse_tiles(const int32_t* __restrict__ work, int n_envs, int env_cap, int n, int gx, int gy, int row_bytes, int TB, float lc, float wt,
              const int32_t* __restrict__ plan_ro, float* __restrict__ local, float* __restrict__ global,
              const uint8_t* __restrict__ code, int32_t* __restrict__ ws, double* __restrict__ sums,
@@ -340,11 +438,8 @@ k_fuse_tiles(const int32_t* __restrict__ work, int n_envs, int env_cap, int n, i
     else if (na == 2) tile_item<2, 4, MIS, TRACK>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
     else if (na == 3) tile_item<3, 4, MIS, TRACK>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
     else if (na == 4) tile_item<4, 4, MIS, TRACK>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
-    else if (NAMAX <= 6 || na <= 6) tile_item<(NAMAX < 6 ? NAMAX : 6), IPPM_TILE_SLOTS_MID, MIS, TRACK>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
-    else if (na <= 8) tile_item<8, IPPM_TILE_SLOTS_MID, MIS, TRACK>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
-    else if (NAMAX <= 10 || na <= 10) tile_item<10, 2, MIS, TRACK>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
-    else if (na <= 14) tile_item<14, 1, MIS, TRACK>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
-    else tile_item<18, 1, MIS, TRACK>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
+    else if (na <= 6) tile_item<6, 2, MIS, TRACK>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
+    else tile_item_long<MIS, TRACK>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
     it = nx;
   }
   // the wavefront's reward terms and work counters: one atomic per quantity
@@ -373,21 +468,27 @@ int ippm_launch_fuse_tiles(ippm_ctx* ctx, float* local, float* global, const uin
   const int max_ops = c.n_agents + 1;
   const int env_cap = ippm_tile_env_cap(ctx);
   // wavefronts per env: about three items each.  An item is <= 256 lane-loads (1024 cells); a step touches roughly half of the
-  // maps over a third of their cells.
+  // maps over a third of their cells.  Up to 1024 per env: with per-episode comm ranges (config 5) the envs' lists differ fifty-fold
+  // in length (484 .. 21 611 items at 64 envs x 16 UAVs x 1024^2) and the wavefronts of a long list are the launch's tail --
+  // 256 / 1024 / 2048 per env: 962 / 853 / 850 us there; a wavefront whose env has nothing left for it costs a scalar load.
+  // (Dealing the wavefronts out in proportion to the lists -- ceil(count / 8 .. 64) per env from a taller grid -- was 6 - 15 % SLOWER
+  // than 1024 for everybody: the launch is throughput-bound at ~600 items per microsecond, like configs 2 and 4, not held up by
+  // its longest chains; profiles/r05/c5_wave_distribution.txt)
   const double est_items = 0.5 * (c.n_agents + 1) * (double)c.grid_x * c.grid_y / 3.0 / (256.0 * ippm_tile_slots(max_ops));
-  int per_env = ctx->knob_tile_waves > 0 ? ctx->knob_tile_waves : (int)std::max(4.0, std::min(256.0, est_items / 3.0));
+  int per_env = ctx->knob_tile_waves > 0 ? ctx->knob_tile_waves : (int)std::max(4.0, std::min(1024.0, est_items / 3.0));
   per_env = std::max(1, std::min(per_env, env_cap));
   // a launch smaller than the chip's wave slots leaves CUs idle: small batches take more wavefronts per env
   while ((long long)per_env * n_envs < 16384 && per_env * 2 <= env_cap && per_env < 256) per_env *= 2;
+  // Per-episode comm ranges (experiment.uav.fix_range: False, config 5): an env that hears nobody fuses its global map only, one
+  // whose range is 100 m fuses sixteen local maps as well -- 484 .. 21 611 items per env at 64 envs x 16 UAVs x 1024^2.  There the
+  // wavefronts are dealt out in proportion to the lists (eight items each), from a grid tall enough for the longest.
   dim3 grid((unsigned)n_envs, (unsigned)per_env), block(64);
-#define IPPM_FT_(NA, M, T) \
-  IPPM_LAUNCH(ctx, IPPM_T_FUSE, (k_fuse_tiles<NA, M, T>), grid, block, st, work, n_envs, env_cap, c.n_agents, c.grid_x, c.grid_y, c.tile_stride >> 2, \
+#define IPPM_FT_(M, T) \
+  IPPM_LAUNCH(ctx, IPPM_T_FUSE, (k_fuse_tiles<M, T>), grid, block, st, work, n_envs, env_cap, c.n_agents, c.grid_x, c.grid_y, c.tile_stride >> 2, \
               (int)ippm_tile_bytes(c.tile_stride, 4), c.logit_clip, c.logit_weight_thr, ws, local, global, code, ws, sums, ctx->dcounters, area)
-#define IPPM_FT(NA, M) do { if (area) IPPM_FT_(NA, M, true); else IPPM_FT_(NA, M, false); } while (0)
-  const bool mis = (c.grid_y & 3) != 0;   // rows only 4-byte aligned: the instantiation with the cell-by-cell row-tail stores
-  if (max_ops <= 6) { if (mis) IPPM_FT(6, true); else IPPM_FT(6, false); }
-  else if (max_ops <= 10) { if (mis) IPPM_FT(10, true); else IPPM_FT(10, false); }
-  else { if (mis) IPPM_FT(18, true); else IPPM_FT(18, false); }
+#define IPPM_FT(M) do { if (area) IPPM_FT_(M, true); else IPPM_FT_(M, false); } while (0)
+  // rows only 4-byte aligned (grid_y not a multiple of 4): the instantiation with the cell-by-cell row-tail stores
+  if ((c.grid_y & 3) != 0) IPPM_FT(true); else IPPM_FT(false);
 #undef IPPM_FT
 #undef IPPM_FT_
   IPPM_LAUNCH_CHECK("fuse_tiles");

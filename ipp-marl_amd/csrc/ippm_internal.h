@@ -63,6 +63,7 @@ struct ippm_ctx {
   // tuning knobs, resolved ONCE at ippm_ctx_create (the work buffer's size, the plan kernel's item layout and the fusion launch
   // all derive from them and must agree for the context's lifetime)
   int knob_wave_rows, knob_persist, knob_nowork, knob_split, knob_tile_waves, knob_plan_builders, knob_k3_dense;
+  int k3_wpg, k3_chn;        // workgroup shape of the env-only step's K3 (wavefronts per workgroup, loads in flight per lane)
   float2* d_roots;           // e^{2 pi i k / 1024}, k = 0..1023: the twiddle table of the terrain transforms (terrain.hip)
   int tiles;                 // the config can take the one-trip tile form of the fusion (16-byte lane groups, prior 0.5)
   // kernel timing (ippm_kernel_timing): per kernel class a pool of event pairs attached to the dispatches themselves
@@ -100,10 +101,8 @@ int ippm_launch_fuse_tiles(ippm_ctx* ctx, float* local, float* global, const uin
 #define IPPM_WORK_OVERFLOW 0x20000000  // the env's items did not fit (never, by the bound of ippm_tile_env_cap)
 #define IPPM_WORK_COUNT 0x0FFFFFFF
 // loads in flight per lane of a tile item, by the number of ops that meet it (the code bytes of every op are in flight too)
-#ifndef IPPM_TILE_SLOTS_MID   // loads in flight per lane for items of 5..8 ops (variant builds try 4)
-#define IPPM_TILE_SLOTS_MID 2
-#endif
-__host__ __device__ inline int ippm_tile_slots(int na) { return na <= 4 ? 4 : (na <= 8 ? IPPM_TILE_SLOTS_MID : (na <= 10 ? 2 : 1)); }
+// (4 for up to four ops, 2 beyond: items of more than six ops run their chain six ops at a time, fuse_tiles.hip)
+__host__ __device__ inline int ippm_tile_slots(int na) { return na <= 4 ? 4 : 2; }
 int ippm_launch_plan(ippm_ctx* ctx, const int32_t* rect, const int32_t* pos, const uint8_t* comm, int32_t* ws, int global_maps,
                      int n_envs, int agent_sel, hipStream_t st);
 int ippm_check_hip(hipError_t err, const char* what);

@@ -245,17 +245,19 @@ __device__ __forceinline__ int tb_lane_i(int v, int lane) { return __builtin_amd
 // every item but a region's last is full whatever the width (round 4 cut regions into blocks of WHOLE rows, floor(cap / W) of
 // them: a 150-group interval filled 150 of 256 lane-loads, and at config 5's shape the list as a whole 77 %).  One LDS atomic
 // reserves the region's slots in the env's list, then lane l writes items l, l + 64, ...
-__device__ __forceinline__ void tile_emit_region(int4* items, int env_cap, int32_t* s_items, int slot, int xa, int xb, int g0, int g1,
-                                                 unsigned mask, int lane) {
+#ifndef IPPM_TILE_COOP_ITEMS   // regions of more items than this are written by the whole builder wavefront
+#define IPPM_TILE_COOP_ITEMS 6
+#endif
+__device__ __forceinline__ int tile_region_items(int rows, int W, unsigned mask, int& sh) {
+  sh = ippm_tile_slots(__popc(mask)) == 4 ? 8 : 7;   // cap = 64 * slots = 1 << sh
+  return (rows * W + (1 << sh) - 1) >> sh;
+}
+// items first, first + stride, ... of the region's n, into list slots k0 + i
+__device__ __forceinline__ void tile_write_items(int4* items, int env_cap, int k0, int first, int stride, int n, int sh, int slot, int xa, int xb,
+                                                 int g0, int g1, unsigned mask) {
   const int W = g1 - g0, total = (xb - xa) * W;
-  const int sl = ippm_tile_slots(__popc(mask));          // 4, 2 or 1
-  const int sh = sl == 4 ? 8 : (sl == 2 ? 7 : 6);        // cap = 64 * slots = 1 << sh
-  const int n = (total + (1 << sh) - 1) >> sh;
-  int k0 = 0;
-  if (lane == 0) k0 = atomicAdd(s_items, n);
-  k0 = __builtin_amdgcn_readfirstlane(k0);
   const float inv_w = __builtin_amdgcn_rcpf((float)W);
-  for (int i = lane; i < n; i += 64) {
+  for (int i = first; i < n; i += stride) {
     const int t0 = i << sh;
     int r = (int)((float)t0 * inv_w);                     // floor(t0 / W) to within one (t0 < 2^24), then exact
     int gs = t0 - r * W;
@@ -264,6 +266,16 @@ __device__ __forceinline__ void tile_emit_region(int4* items, int env_cap, int32
     const int cnt = min(1 << sh, total - t0);
     if (k0 + i < env_cap) items[k0 + i] = make_int4(gs | (cnt << 16), xa + r, g0 | (W << 16), (int)(mask | ((unsigned)slot << 24)));
   }
+}
+// a LARGE region (all arguments wave-uniform; every lane takes part): lane l writes items l, l + 64, ...
+__device__ __forceinline__ void tile_emit_region(int4* items, int env_cap, int32_t* s_items, int slot, int xa, int xb, int g0, int g1,
+                                                 unsigned mask, int lane) {
+  int sh;
+  const int n = tile_region_items(xb - xa, g1 - g0, mask, sh);
+  int k0 = 0;
+  if (lane == 0) k0 = atomicAdd(s_items, n);
+  k0 = __builtin_amdgcn_readfirstlane(k0);
+  tile_write_items(items, env_cap, k0, lane, 64, n, sh, slot, xa, xb, g0, g1, mask);
 }
 
 // All items of one map's plan (nops > 0, uniform) into the env's list.  s_ops: the plan's rectangles in LDS.
@@ -313,7 +325,13 @@ __device__ __forceinline__ void tile_build_map(const int4* s_ops, int nops, int 
       lo = yu >> 2; hi = (yd + 3) >> 2;
       done = in && mask != 0 && lo > g1;  // a gap of at least one group: the interval so far is complete
     }
-    for (unsigned long long pend = __ballot(done); pend != 0; pend &= pend - 1) {
+    // finished intervals go out now.  A small region (config 2: three items on average) is written by its own lane, all lanes
+    // at once; a large one (config 5's shape: 75 items) by the whole wave, one region after the other
+    int sh = 0;
+    const int n_mine = done ? tile_region_items(xb - xa, g1 - g0, mask, sh) : 0;
+    const bool big = n_mine > IPPM_TILE_COOP_ITEMS;
+    if (done && !big) tile_write_items(items, env_cap, atomicAdd(s_items, n_mine), 0, 1, n_mine, sh, slot, xa, xb, g0, g1, mask);
+    for (unsigned long long pend = __ballot(big); pend != 0; pend &= pend - 1) {
       const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)pend) - 1);
       tile_emit_region(items, env_cap, s_items, slot, tb_lane_i(xa, src), tb_lane_i(xb, src), tb_lane_i(g0, src), tb_lane_i(g1, src),
                        (unsigned)tb_lane_i((int)mask, src), lane);

@@ -793,11 +793,11 @@ def test_kernel_timing_reports_dispatch_durations():
     times = env.event_times_us()
     assert {"sense", "fuse", "plan"} <= set(times)
     # (template arguments as the launch site spells them: K3 <cells per lane, misaligned rows, explicit flips, sense records, dense lane
-    #  mapping, area sums>, the fusion <max ops, misaligned rows, area sums>)
-    for cls, kernel in (("sense", "k_sense_tiles<4, false, false, true, true, false>"), ("fuse", "k_fuse_tiles<6, false, false>"),
+    #  mapping, area sums[, wavefronts per workgroup, loads in flight per lane]>, the fusion <misaligned rows, area sums>)
+    for cls, kernel in (("sense", "k_sense_tiles<4, false, false, true, true, false"), ("fuse", "k_fuse_tiles<false, false>"),
                         ("plan", "k_plan_step")):
         rec = times[cls]
-        assert rec["launches"] == 5 and rec["kernel"] == kernel, (cls, rec)
+        assert rec["launches"] == 5 and rec["kernel"].startswith(kernel) and rec["kernel"].endswith(">" if "<" in kernel else "p"), (cls, rec)
         assert 1.0 < rec["min_us"] <= rec["avg_us"] < 2000.0, (cls, rec)
     assert env.event_times_us() == {}                            # reading resets
     env.reset(np.arange(100, 164))                               # the reset's kernels have their own classes

@@ -1,0 +1,7 @@
+#!/bin/bash
+OUT=gpurun_out/r5l; mkdir -p $OUT
+S=("" "IPPM_K3_WPG=1" "IPPM_K3_WPG=2" "IPPM_K3_WPG=2 IPPM_K3_CHN=2" "IPPM_K3_WPG=4 IPPM_K3_CHN=2" "IPPM_K3_WPG=1 IPPM_K3_CHN=4" "IPPM_K3_WPG=2 IPPM_K3_CHN=4" "IPPM_K3_WPG=4 IPPM_K3_CHN=4")
+for shape in "--envs 1024 --agents 4 --grid 256" "--envs 256 --agents 8 --grid 512" "--envs 64 --agents 16 --grid 1024 --actions 27 --episode-comm-range"; do
+  echo "=== $shape"
+  timeout 600 python tools/ab_knobs.py $shape --rounds 3 --draws 8 "${S[@]}" 2>&1 | grep -E "^\[|placement" | sed 's/fuse.*reset_maps/../' | cut -c1-200
+done | tee $OUT/k3_shapes.txt

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--grid", type=int, default=256)
     ap.add_argument("--actions", type=int, default=None)
     ap.add_argument("--episode-comm-range", action="store_true")
+    ap.add_argument("--comm-range", type=float, default=None)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--format", default=os.environ.get("IPPM_ITEM_FORMAT", "auto"), help="rows (round 4: x0 | rows << 16) or runs (round 5: start | count << 16)")
     a = ap.parse_args()
