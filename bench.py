@@ -23,6 +23,9 @@ The JSON line also carries
                      step / ms_per_step / peak
   roofline_kernels : the same for the fusion launch (K4+K5: 8 B per cell of the union + 1 B per (cell, message)), the small
                      plan kernel, the reset kernels and, when training is on, the K6 feature builders
+  resets_timed, steady_state : how many episode resets the timed window held, and the same loop's rate over three whole episodes
+                     right after it (exactly one reset per episode): the figure to quote for sustained throughput
+  per_rank         : every rank's own ms_per_step / rate / placement-search outcome; value_sum_of_ranks next to value_from_max_time
   ranks, rank_devices, collective : who took part (one entry per rank) and the gradient all-reduces RCCL carried in the
                      COMA leg (backend, calls, bytes)
   cpu_baseline     : the NumPy oracle (a port of the reference's CPU path, parity-pinned against it) stepping the same
@@ -89,7 +92,10 @@ def cpu_baseline(args, seconds=10.0):
     per = -(-64 // procs)
     stepsN, dtN = collect([launch(per, 1 + k * 100000) for k in range(procs)])
     shape = f"{args.agents} UAVs, {args.grid}x{args.grid}, env-only, {args.terrain} terrain"
-    return {"value": steps1 / dt1, "unit": "agent-env steps/s", "cores": 1, "kind": "port",
+    return {"value": steps1 / dt1, "unit": "agent-env steps/s", "cores": 1, "kind": "port", "host_cores": cores,
+            "torch_threads": torch.get_num_threads(), "numpy_threads": 1,
+            "form": "the oracle steps ONE env at a time, like the reference (missions/episode_generator.py:39-40); it has no form vectorised "
+                    "over envs, so the many-env figure is processes x one env each, not SURVEY 8d's E=64 vectorised stepper",
             "sample": f"{steps1} agent-env steps of 1 env ({shape}) in {dt1:.1f}s of the NumPy oracle on 1 of {cores} host cores",
             "many_env": {"value": stepsN / dtN, "unit": "agent-env steps/s", "cores": procs, "envs": per * procs,
                          "sample": f"{stepsN} agent-env steps of {per * procs} envs in {dtN:.1f}s, {procs} oracle processes "
@@ -303,11 +309,37 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    dt_rank = dt
     if dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt[0])
     counters = env.counters()
+    # Steady state: the timed region above holds however many resets --steps happens to span (the driver's 20 steps: one, i.e. one
+    # per 20 steps where an episode has one per 16); any window of whole episodes holds exactly one reset per episode whatever its
+    # phase, so the loop simply goes on for three more episodes' worth of steps under the same barrier / max-over-ranks clock.
+    ss_steps, ss_resets = 3 * T, 0
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    s0 = time.perf_counter()
+    for _ in range(ss_steps):
+        one_step(t_in_ep)
+        t_in_ep += 1
+        if t_in_ep == T:
+            ss_resets += 1
+            reset()
+            t_in_ep = 0
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ss_dt = time.perf_counter() - s0
+    if dist:
+        tt = torch.tensor([ss_dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        ss_dt = float(tt[0])
     faults = int(env.fault.abs().sum())
     grid = [env.d.grid_x, env.d.grid_y]
 
@@ -446,19 +478,25 @@ def main():
         coma["rollout_kernel_us"]["note"] = ("dispatch-bound start/stop events (kernel-only durations); sense/fuse here also maintain "
                                              "the 11x11 area sums of every map, which is what lets the K6 builders skip the maps")
         if roofline_kernels is not None and "actor_features" in kt:
-            c = tr.env.counters()
+            # K6 no longer reads the maps (SURVEY 8d priced it at 4 B per cell of the N+1 maps per step): its inputs, the 11 x 11 area
+            # sums, are kept current by the kernels that write maps.  What network inputs cost is therefore K6's own launches PLUS what
+            # tracking adds to K3 and to the fusion -- the difference between the rollout's tracked kernels and the env-only step's
+            # untracked ones (different cells per step: a learned policy flies elsewhere than a random one; both are given).
             k6_us = sum(kt[k]["avg_us"] for k in ("actor_features", "critic_features"))
+            untracked = {"sense": times.get("sense", {}).get("avg_us"), "fuse": times.get("fuse", {}).get("avg_us")}
             roofline_kernels.append({
-                "bound": "hbm", "kernel": "K6 (k_actor_features + k_critic_features) with tracked area sums", "unit": "GB/s",
-                "peak": HBM_PEAK_GBS, "avg_launch_us": k6_us,
-                "algorithmic_bytes_per_launch": 4.0 * (N + 1) * grid[0] * grid[1] * E,
-                "achieved": 4.0 * (N + 1) * grid[0] * grid[1] * E / (k6_us * 1e-6) / 1e9,
-                "frac": 4.0 * (N + 1) * grid[0] * grid[1] * E / (k6_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                "traffic": None,
-                "note": "SURVEY 8d prices K6 at 4 B per cell of the N+1 maps per env step (one streaming read); the maps are no "
-                        "longer read at all (their area sums are maintained by the kernels that write them), so the 'achieved' "
-                        "figure is the rate a streaming implementation would need to match this time and may exceed the peak",
-                "sense_cells_per_step": c["sense_cells"] / tr.T})
+                "kernel": "K6 (k_actor_features + k_critic_features) on tracked area sums", "what": "network inputs: the feature builders' own "
+                "launches plus what keeping the area sums current adds to K3 and to the fusion (no roofline fraction: the maps are not read)",
+                "k6_us": k6_us,
+                "tracking_cost_us": {k: (kt[k]["avg_us"] - untracked[k]) if k in kt and untracked[k] else None for k in ("sense", "fuse")},
+                "tracked_us": {k: kt[k]["avg_us"] for k in ("sense", "fuse") if k in kt},
+                "untracked_us": untracked,
+                "cells_per_step": {"tracked_rollout": coma["rollout_kernel_us"]["cells_per_step"],
+                                   "untracked_env_only": ({"sense": rl_counters["sense_cells"] / args.roofline_steps,
+                                                           "fuse_local": rl_counters["fuse_local_cells"] / args.roofline_steps,
+                                                           "fuse_global": rl_counters["fuse_global_cells"] / args.roofline_steps}
+                                                          if rl_counters else None)},
+                "streaming_form_bytes_per_step": 4.0 * (N + 1) * grid[0] * grid[1] * E})
         if world > 1:   # evidence that the gradient exchange really ran over `world` ranks: every rank's device, calls and bytes
             import socket
             mine = {"rank": rank, "host": socket.gethostname(), "device": torch.cuda.current_device(),
@@ -506,6 +544,15 @@ def main():
                                              "transitions_per_update": stats["transitions"], "envs": ref_envs,
                                              "adam_steps_per_update": stats["adam_steps"],
                                              "hip_graphs": "16 rollout-step graphs + 1 update graph per round (COMATrainer.capture_graphs)"}
+    # per-rank audit trail: each rank's own clock around the timed region and how its placement search ended, so that a multi-GPU
+    # line can be checked rank by rank (value = the units all ranks processed / the slowest rank's time)
+    mine = {"rank": rank, "device": torch.cuda.current_device(), "ms_per_step": 1e3 * dt_rank / args.steps,
+            "agent_env_steps_per_s": E * N * args.steps / dt_rank, "placement_stopped": (placement or {}).get("stopped"),
+            "placement_draws": (placement or {}).get("draws")}
+    per_rank = [mine]
+    if dist:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     if rank == 0:
         total_steps = E * N * args.steps * world
         is_c1 = (N, grid[0], E) == (4, 256, 1024) and env_actions == 6 and not args.episode_comm_range
@@ -524,6 +571,15 @@ def main():
                        "launches_per_step": 3, "hip_graphs": bool(args.graphs), "roofline_steps": args.roofline_steps,
                        "terrain_prefetch": bool(args.terrain_prefetch and args.terrain == "random_field")},
             "ranks": world,
+            "resets_timed": resets_timed,
+            "steady_state": {"ms_per_step": 1e3 * ss_dt / ss_steps, "value": E * N * ss_steps * world / ss_dt, "steps": ss_steps, "resets": ss_resets,
+                             "note": f"the same loop continued for {ss_steps} steps = 3 whole episodes (exactly one reset per {T} steps, as in an "
+                                     f"endless run); `value` above is the driver's window of --steps {args.steps}, which held {resets_timed} reset(s), "
+                                     f"i.e. one per {args.steps / max(resets_timed, 1):.1f} steps" + ("" if resets_timed else " (none at all)")
+                                     + ": quote steady_state for sustained throughput"},
+            "per_rank": {"ranks": per_rank, "slowest_rank": max(per_rank, key=lambda r: r["ms_per_step"])["rank"],
+                         "ms_per_step_min": min(r["ms_per_step"] for r in per_rank), "ms_per_step_max": max(r["ms_per_step"] for r in per_rank),
+                         "value_sum_of_ranks": sum(r["agent_env_steps_per_s"] for r in per_rank), "value_from_max_time": total_steps / dt},
             "collective": collective if args.train_rounds > 0 else None,
             "faults": faults,
             "cells": counters,

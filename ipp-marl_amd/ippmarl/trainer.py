@@ -22,10 +22,12 @@ from .vec_env import VecEnv, POLICY_ARGMAX, POLICY_SAMPLE
 class COMATrainer:
     def __init__(self, params: Dict, n_envs: int, device: str = "cuda:0", philox_seed: int = 3, waves_per_update: int = 1,
                  quirks: str = "reference", rank: int = 0, world: int = 1, first_episode: int = 1,
-                 terrain: str = "split", graphs: bool = False, placement_draws: int = 0):
+                 terrain: str = "split", graphs: bool = False, placement_draws: int = 24):
         self.params = params
         self.env = VecEnv(params, n_envs, device=device, philox_seed=philox_seed, terrain=terrain)
-        # (large batches: where the allocator put the maps decides ~10 % of the rollout's map kernels, VecEnv.tune_placement)
+        # Large batches: where the allocator put the maps decides ~10 % of the rollout's map kernels (VecEnv.tune_placement).  The
+        # default is bench.py's: the search stops at the first fast allocation (~10 ms a draw at config 2), returns None without
+        # drawing for batches below 2^24 cells, keeps its rejected candidates within half of the free memory; <= 1: no search.
         self.placement = self.env.tune_placement(placement_draws) if placement_draws > 1 else None
         self.device = self.env.device
         self.rank, self.world = rank, world

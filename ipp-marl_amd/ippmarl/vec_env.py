@@ -49,6 +49,28 @@ def placement_alive_cap(free_bytes: int, arena_bytes: int) -> int:
     return max(2, int(0.5 * free_bytes // (arena_bytes + ((PLACEMENT_SLACK_MB * 15) << 20))) + 1)
 
 
+def placement_stop_reason(scores) -> Optional[str]:
+    """Why VecEnv.tune_placement may stop after the draws ``scores`` (us per step of the two map kernels), or None to go on.
+    The two kinds of allocation are 7-8 % apart and each is sharp to ~1 %:
+      * a draw well below the MEDIAN of the draws is a fast one among slow ones (below the worst is not enough: a slow outlier among
+        slow draws -- 121, 121, 126 -- would end the search on a slow one);
+      * when fast draws are the majority the median is a fast score and that rule cannot fire: two draws within 2 % of the best and
+        a third more than 6 % above it show both kinds, the best is a fast one (113, 114, 122: stop at the third draw; 121, 121, 126 is
+        a slow outlier among slow draws again: go on);
+      * twelve draws in a row within 2 % of each other: the box has one kind only, nothing to search for."""
+    k = len(scores)
+    if k < 2:
+        return None
+    best = min(scores)
+    if best < 0.96 * float(np.median(scores)):
+        return "a fast allocation found"
+    if sum(1 for v in scores if v <= 1.02 * best) >= 2 and max(scores) > 1.06 * best:
+        return "a fast allocation found"
+    if k >= 12 and max(scores) < 1.02 * best:
+        return "no spread between the first draws"
+    return None
+
+
 class VecEnv:
     def __init__(self, params: Dict, n_envs: int, device: str = "cuda:0", philox_seed: int = 3, terrain: str = "split",
                  track_area: bool = True):
@@ -492,16 +514,11 @@ class VecEnv:
         scores, arenas = [score()], [self._arena]      # arenas[k] is None once released
         stopped = "draws exhausted"
         for k in range(1, draws):
-            # the two kinds are 7-8 % apart and each is sharp to 1 %: a candidate well below the MEDIAN of the draws is a good one
-            # (below the worst is not enough: a slow outlier among slow draws -- 121, 121, 126 -- would end the search on a bad one)
-            med = float(np.median(scores))
-            if k >= 2 and min(scores) < 0.96 * med and not os.environ.get("IPPM_PLACEMENT_NO_EARLY"):
-                stopped = "a fast allocation found"
-                break
-            # ... and a box on which twelve draws in a row differ by less than 2 % has one kind only: nothing to search for
-            if k >= 12 and max(scores) < 1.02 * min(scores) and not os.environ.get("IPPM_PLACEMENT_NO_EARLY"):
-                stopped = "no spread between the first draws"
-                break
+            if not os.environ.get("IPPM_PLACEMENT_NO_EARLY"):
+                why = placement_stop_reason(scores)
+                if why:
+                    stopped = why
+                    break
             alive = [i for i, a in enumerate(arenas) if a is not None]
             if len(alive) >= max_alive:    # hand the slowest candidates back (never the best one)
                 best_now = min(alive, key=scores.__getitem__)

@@ -166,6 +166,21 @@ def test_launcher_retries_once_with_the_other_ipc_setting(monkeypatch):
     assert [c[1] for c in calls] == ["unset", "0"]
 
 
+def test_placement_search_stop_rule():
+    """VecEnv.tune_placement's early exit: stops on a clear fast draw whether fast draws are the minority or the
+    majority, never on a slow outlier among slow draws, and gives up on a box with one kind only after twelve draws."""
+    from ippmarl.vec_env import placement_stop_reason as stop
+    assert stop([121.5]) is None and stop([121.5, 122.0]) is None
+    assert stop([121.5, 122.0, 113.4]) == "a fast allocation found"            # slow, slow, fast
+    assert stop([113.4, 121.9]) is None                                         # one of each: which is the outlier?
+    assert stop([113.4, 121.9, 113.9]) == "a fast allocation found"            # fast, slow, fast (the median is a fast score)
+    assert stop([113.4, 113.9, 114.1, 122.3]) == "a fast allocation found"     # fast draws in the majority
+    assert stop([121.0, 121.2, 126.0]) is None                                  # a slow outlier among slow draws
+    assert stop([121.0, 121.2, 126.0, 121.4, 120.9]) is None
+    assert stop([121.0 + 0.1 * k for k in range(11)]) is None
+    assert stop([121.0 + 0.1 * k for k in range(12)]) == "no spread between the first draws"
+
+
 def test_placement_search_memory_bound():
     """VecEnv.tune_placement keeps rejected candidates allocated only within half of the free device memory."""
     from ippmarl.vec_env import placement_alive_cap

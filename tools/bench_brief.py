@@ -5,7 +5,9 @@ import sys
 try:
     lines = [ln for ln in open(sys.argv[1]).read().splitlines() if ln.startswith("{")]
     d = json.loads(lines[-1])
-    print({k: d.get(k) for k in ("value", "ms_per_step", "n_gpus", "ranks", "faults")})
+    print({k: d.get(k) for k in ("value", "ms_per_step", "n_gpus", "ranks", "faults", "resets_timed")})
+    if d.get("steady_state"):
+        print("steady_state", {k: d["steady_state"][k] for k in ("ms_per_step", "value", "steps", "resets")})
     for r in d.get("roofline_kernels") or []:
         print((r.get("kernel") or "")[:48], {k: round(r[k], 3) if isinstance(r.get(k), float) else r.get(k)
                                             for k in ("avg_launch_us", "min_launch_us", "timed_launches", "frac", "us_per_step") if k in r})
