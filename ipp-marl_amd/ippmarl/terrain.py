@@ -49,7 +49,9 @@ class RandomFieldTerrain:
         if self.real_fft:
             amp = amp[:, : gy // 2 + 1]
         self.amp = torch.from_numpy(np.ascontiguousarray(amp).astype(np.float32)).to(device)
-        self.native = all(n & (n - 1) == 0 and 8 <= n <= 1024 for n in (gx, gy))
+        # the hand-written passes exist for 128 / 256 / 512 / 1024 cells a side (terrain_pow2_check in csrc/terrain.hip); every other
+        # size, smaller powers of two included, draws the spectrum with ippm_terrain_noise and inverts it with rocFFT
+        self.native = all(n in (128, 256, 512, 1024) for n in (gx, gy))
         self.chunk = max(1, chunk_bytes // (gx * gy * 4))
         self._noise: Optional[torch.Tensor] = None
         self._work: Optional[torch.Tensor] = None

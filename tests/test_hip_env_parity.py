@@ -113,6 +113,11 @@ EDGE_85 = ("default", dict(sensor__pixel__number_x=12, sensor__pixel__number_y=1
     # (prior > 0.5 pulls every cell below 0.499 within two steps; all class weights are then 0 and the reference's relative
     #  reward is 0 / 0 = nan from there on: not a case to pin anything on)
     ("c5", dict(experiment__missions__n_agents=16), 2),  # two envs of BASELINE config 5 at its largest: 16 UAVs, 1024 x 1024, 27 actions
+    # ... and its other team sizes ("mixed team sizes 2-16": the team size is a per-run parameter in the reference,
+    # coma_wrapper.py:25-26, missions/episode_generator.py:99-102), two envs each, per-episode comm range, 27 actions
+    ("c5", dict(experiment__missions__n_agents=2), 2),
+    ("c5", dict(experiment__missions__n_agents=4), 2),
+    ("c5", dict(experiment__missions__n_agents=8), 2),
     # altitudes beyond the sensor model's table (sensor_models.py:13-22: noise 0 unless z is 5 / 10 / 15 m): a measurement from
     # 20 m sets its cells to exactly 0 or 1, i.e. +-inf in log-odds storage, until the next fusion clips them
     ("small", dict(experiment__constraints__min_altitude=15, experiment__constraints__max_altitude=20,

@@ -230,6 +230,17 @@ def test_exact_mode_differs_only_by_reference_quantisation(golden, tag):
         np.testing.assert_allclose(np.array(rec["observations"]), fx["obs"][t], rtol=RTOL, atol=1e-5 if shifted else 1e-6)
     assert_posteriors(local_subset(fx, np.array([a["local_map"] for a in ep.agents])), fx["final_local"], strict=False, msg="final local", allow=RQ.get((tag, "final_local"), []))
     assert_posteriors(ep.global_map, fx["final_global"], strict=False, msg="final global", allow=RQ.get((tag, "final_global"), []))
+    # ... and the list is DERIVED, not tuned: the cells listed for this recording are exactly the cells in which the
+    # exact-float64 oracle and the reference's own recording differ by more than 1e-5 -- no cell is listed that does not need it, so
+    # the looser 3e-4 cap of assert_posteriors applies nowhere else.  (The GPU path itself is held to 1e-5 in EVERY cell against
+    # this exact-mode oracle; the list only ever loosens the comparison with the reference's float32-re-quantised recording.)
+    for key, got, want in (("final_local", local_subset(fx, np.array([a["local_map"] for a in ep.agents])), fx["final_local"]),
+                           ("final_global", ep.global_map, fx["final_global"])):
+        got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            rel = np.where(got == want, 0.0, np.abs(got - want) / np.abs(want))
+        deviating = sorted(tuple(int(v) for v in idx) for idx in np.argwhere(rel > 1e-5))
+        assert deviating == sorted(tuple(c) for c in RQ.get((tag, key), [])), (tag, key, deviating)
 
 
 IG_CASES = {"ig_c1_e1": dict(name="c1", over={}), "ig_small3_e4": dict(name="small", over=dict(experiment__missions__n_agents=3))}
