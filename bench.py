@@ -172,6 +172,8 @@ def main():
     ap.add_argument("--actions", type=int, default=None, choices=[4, 6, 9, 27], help="action set (default: params.yaml's 6)")
     ap.add_argument("--episode-comm-range", action="store_true", help="per-episode comm range from {0, 15, 25, 100} m "
                     "(experiment.uav.fix_range: False, BASELINE config 5's comm-range masking)")
+    ap.add_argument("--team-sizes", default=None, help="comma-separated team sizes dealt out to the envs in turn (BASELINE config 5's mixed teams, "
+                    "e.g. 2,4,8,16 with --agents 16): env e flies team_sizes[e %% len] of the --agents UAVs; agent-env steps count the flying ones")
     ap.add_argument("--comm-range", type=float, default=None, help="experiment.uav.communication_range in metres (default: params.yaml's 25)")
     ap.add_argument("--terrain", default="random_field", choices=["random_field", "split"],
                     help="ground truth: the power-law random field of ground_truths.py:25-40 generated on the device, or "
@@ -249,11 +251,16 @@ def main():
     from ippmarl.vec_env import VecEnv, POLICY_UNIFORM
     params = bench_params(args)
     # env-only stepping never builds network inputs: the area sums are not tracked here (the trainer below tracks them)
-    env = VecEnv(params, args.envs, device=device, philox_seed=3, terrain=args.terrain, track_area=False)
+    teams = None
+    if args.team_sizes:
+        pattern = [int(v) for v in args.team_sizes.split(",")]
+        teams = [pattern[e % len(pattern)] for e in range(args.envs)]
+    env = VecEnv(params, args.envs, device=device, philox_seed=3, terrain=args.terrain, track_area=False, team_sizes=teams)
     # where the allocator puts the maps is worth 10 % of the fusion kernel (VecEnv.tune_placement): a few candidate sets, one
     # episode each, before anything is timed
     placement = env.tune_placement(args.placement_draws)
     E, N, T = env.E, env.d.n_agents, env.d.budget + 1
+    flying = sum(teams) if teams else E * N        # agents stepped per env step of this rank (mixed team sizes: the flying ones)
     env_actions = env.d.n_actions
     wave = [0]
 
@@ -438,7 +445,7 @@ def main():
         env = None  # release the env-only state before the trainer allocates its own
         torch.cuda.empty_cache()
         tr = COMATrainer(params, args.envs, device=device, philox_seed=3, rank=rank, world=world, terrain=args.terrain,
-                         placement_draws=args.placement_draws)
+                         placement_draws=args.placement_draws, team_sizes=teams)
         tr.rollout("train")
         tr.update()  # warm-up round (MIOpen kernel selection, allocator)
         torch.cuda.synchronize()
@@ -458,7 +465,7 @@ def main():
         cdt = time.perf_counter() - c0
         coma = {"updates_per_s": args.train_rounds / cdt, "s_per_update": cdt / args.train_rounds,
                 "transitions_per_update": stats["transitions"], "adam_steps_per_update": stats["adam_steps"],
-                "rollout_agent_env_steps_per_s": tr.E * tr.N * tr.T * world * args.train_rounds / roll_s,
+                "rollout_agent_env_steps_per_s": flying * tr.T * world * args.train_rounds / roll_s,
                 "note": "one update = TD(lambda) targets + data_passes x batch_number minibatch steps of critic and actor "
                         "(reference round: 25+25 Adam steps on 300 transitions); nets float32 in PyTorch-ROCm"}
         # kernel times of one more learned-policy rollout (area sums tracked by K3/K4/K5, K6 = 121-cell assembly), untimed above.
@@ -514,7 +521,7 @@ def main():
                           "per_update": {"calls": tr.reducer.calls // (args.train_rounds + 1),
                                          "bytes": tr.reducer.bytes_reduced // (args.train_rounds + 1)},
                           "ranks": gathered}
-        if world == 1:
+        if world == 1 and not teams:
             # the reference's own round size for comparison with its 0.164 updates/s: 5 episodes ->
             # 300 transitions per update, 25 + 25 Adam steps on 60-sample minibatches
             del tr
@@ -547,16 +554,16 @@ def main():
     # per-rank audit trail: each rank's own clock around the timed region and how its placement search ended, so that a multi-GPU
     # line can be checked rank by rank (value = the units all ranks processed / the slowest rank's time)
     mine = {"rank": rank, "device": torch.cuda.current_device(), "ms_per_step": 1e3 * dt_rank / args.steps,
-            "agent_env_steps_per_s": E * N * args.steps / dt_rank, "placement_stopped": (placement or {}).get("stopped"),
+            "agent_env_steps_per_s": flying * args.steps / dt_rank, "placement_stopped": (placement or {}).get("stopped"),
             "placement_draws": (placement or {}).get("draws")}
     per_rank = [mine]
     if dist:
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
     if rank == 0:
-        total_steps = E * N * args.steps * world
-        is_c1 = (N, grid[0], E) == (4, 256, 1024) and env_actions == 6 and not args.episode_comm_range
-        shape = (f"{N} UAVs, {grid[0]}x{grid[1]} grid, {E} batched envs per GPU, random policy over {env_actions} actions"
+        total_steps = flying * args.steps * world
+        is_c1 = (N, grid[0], E) == (4, 256, 1024) and env_actions == 6 and not args.episode_comm_range and not teams
+        shape = ((f"teams of {args.team_sizes} of " if teams else "") + f"{N} UAVs, {grid[0]}x{grid[1]} grid, {E} batched envs per GPU, random policy over {env_actions} actions"
                  f"{', per-episode comm range' if args.episode_comm_range else ''}, env-step kernels only")
         out = {
             "metric": f"agent-env steps/s ({N} UAVs, {grid[0]}x{grid[1]} grid, random policy, env-step HIP kernels)",
@@ -572,7 +579,7 @@ def main():
                        "terrain_prefetch": bool(args.terrain_prefetch and args.terrain == "random_field")},
             "ranks": world,
             "resets_timed": resets_timed,
-            "steady_state": {"ms_per_step": 1e3 * ss_dt / ss_steps, "value": E * N * ss_steps * world / ss_dt, "steps": ss_steps, "resets": ss_resets,
+            "steady_state": {"ms_per_step": 1e3 * ss_dt / ss_steps, "value": flying * ss_steps * world / ss_dt, "steps": ss_steps, "resets": ss_resets,
                              "note": f"the same loop continued for {ss_steps} steps = 3 whole episodes (exactly one reset per {T} steps, as in an "
                                      f"endless run); `value` above is the driver's window of --steps {args.steps}, which held {resets_timed} reset(s), "
                                      f"i.e. one per {args.steps / max(resets_timed, 1):.1f} steps" + ("" if resets_timed else " (none at all)")

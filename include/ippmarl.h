@@ -256,6 +256,15 @@ int ippm_fuse_global_reward(ippm_ctx* ctx, float* global, const uint8_t* code, c
  *   `work` list of the same step's ippm_plan_step a fixed number of resident wavefronts strides over exactly the non-empty
  *   items; without it (NULL) the grid enumerates every (map, run) pair.
  * ippm_reward_finalize: reward[e] = (22*S1/S2 - 0.5, 10*S1/(gx*gy) - 0.17) from the accumulated sums (utils/reward.py:25-40). */
+/* Mixed team sizes in one batch (BASELINE config 5: "mixed team sizes 2-16 UAVs").  The reference's team size is a per-run
+ * parameter (coma_wrapper.py:25-26, missions/episode_generator.py:99-102); here env e of a batch may fly n_active[e] <= n_agents
+ * UAVs: it then evolves exactly like a run of the reference with n_agents = n_active[e] (same episode number): agents
+ * >= n_active[e] are heard by nobody, hear nobody, do not move, sense or publish, and the agent-id plane of the network inputs is
+ * (i + 1) / n_active[e].  n_active: DEVICE int32 [n_envs], caller-owned, read at every launch of the batched step
+ * (ippm_plan_step, ippm_fuse_step, ippm_sense_step, ippm_reset_maps, ippm_actor_features, ippm_critic_features); NULL (the
+ * default): every env flies n_agents.  Arrays keep their [E, n_agents, ...] strides; rows of inactive agents are not meaningful.
+ * The single-purpose entry points (ippm_comm_matrix, ippm_fuse_local, ippm_ig_*, ...) do not look at it. */
+int ippm_set_team_sizes(ippm_ctx* ctx, const int32_t* n_active);
 int ippm_plan_step(ippm_ctx* ctx, const int64_t* episode, int32_t* pos, const float* comm_range, const double* draws,
                    uint8_t* comm, const int32_t* rect, int32_t* ws, int32_t t, int32_t flags, const float* probs,
                    const int32_t* action_in, int32_t policy, uint8_t* mask, int32_t* action, int32_t* fault,

@@ -133,6 +133,12 @@ extern "C" int ippm_ctx_create(const ippm_config* cfg, ippm_ctx** out) {
   return 0;
 }
 
+extern "C" int ippm_set_team_sizes(ippm_ctx* ctx, const int32_t* n_active) {
+  if (!ctx) { ippm_set_error("ippm_set_team_sizes: null context"); return -1; }
+  ctx->n_active = n_active;
+  return 0;
+}
+
 extern "C" int ippm_ctx_destroy(ippm_ctx* ctx) {
   if (!ctx) return 0;
   if (ctx->dcfg) (void)hipFree(ctx->dcfg);

@@ -166,7 +166,7 @@ k_sense_update(const ippm_config* __restrict__ c, const int64_t* __restrict__ ep
                const uint8_t* __restrict__ flips, uint8_t* __restrict__ code, const int32_t* __restrict__ rect_in,
                int32_t* __restrict__ rect_out, int32_t* __restrict__ ws, double* __restrict__ area,
                double* __restrict__ sums, float* __restrict__ reward, unsigned long long* __restrict__ counters, int stage,
-               int agent_sel, int split, int n_tiles, int n_envs) {
+               int agent_sel, int split, int n_tiles, int n_envs, const int32_t* __restrict__ n_active) {
   if ((int)blockIdx.x >= n_tiles * split) {  // reward-finalize tail
     const int e = ((int)blockIdx.x - n_tiles * split) * 256 + (int)threadIdx.x;
     if (e < n_envs) ippm_reward_finalize_env(c, sums, reward, e);
@@ -177,6 +177,7 @@ k_sense_update(const ippm_config* __restrict__ c, const int64_t* __restrict__ ep
   int e, i;
   if (agent_sel >= 0) { e = tile; i = agent_sel; }
   else { e = tile / n; i = tile % n; }
+  if (n_active && i >= n_active[e]) return;   // not flying in this env (ippm_set_team_sizes)
   const int gx = c->grid_x, gy = c->grid_y, S = c->tile_stride;
   const int32_t* p = pos + (size_t)(e * n + i) * 3;
   int r[4];
@@ -324,7 +325,7 @@ k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int sta
               const ippm_config* __restrict__ c, const int32_t* __restrict__ pos,
               const uint8_t* __restrict__ flips, int32_t* __restrict__ rect_out, int32_t* __restrict__ ws,
               double* __restrict__ sums, float* __restrict__ reward, unsigned long long* __restrict__ counters,
-              double* __restrict__ area) {
+              double* __restrict__ area, const int32_t* __restrict__ n_active) {
   // Argument order = latency order.  A workgroup lives for one trip, so what stands in front of its map loads is paid by every
   // wavefront: with the config fields behind the config pointer behind the kernel-argument load, the footprint came in three
   // dependent scalar round trips.  The first 14 argument words arrive in SGPRs with the wavefront (kernel-argument preload,
@@ -371,6 +372,9 @@ k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int sta
     lm0 = __int_as_float(b0); lm1 = __int_as_float(b1); lc = __int_as_float(b2);
     ep = (int64_t)(((uint64_t)(uint32_t)e1 << 32) | (uint32_t)e0);
   }
+  // (an agent that does not fly in this env, ippm_set_team_sizes: K1 left it an empty sense record; without records the team
+  //  size decides)
+  if (!REC && n_active && i >= n_active[e]) { r[0] = r[1] = r[2] = r[3] = 0; }
   const int yu = r[0], yd = r[1], xl = r[2], xr = r[3];
   if (rect_out && part == 0 && threadIdx.x < 4) rect_out[(size_t)(e * n + i) * 4 + threadIdx.x] = r[threadIdx.x];
   const int h = xr - xl, w = yd - yu;
@@ -562,17 +566,19 @@ k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int sta
 __global__ void __launch_bounds__(256)
 k_reset_maps(const ippm_config* __restrict__ c, const int64_t* __restrict__ episode, const int32_t* __restrict__ pos,
              const uint8_t* __restrict__ truth, float* __restrict__ local, float* __restrict__ global, const uint8_t* __restrict__ flips,
-             uint8_t* __restrict__ code, const int32_t* __restrict__ rect, int32_t* __restrict__ ws, int full, int fill_chunks) {
+             uint8_t* __restrict__ code, const int32_t* __restrict__ rect, int32_t* __restrict__ ws, int full, int fill_chunks,
+             const int32_t* __restrict__ n_active) {
   const int n = c->n_agents, gx = c->grid_x, gy = c->grid_y, S = c->tile_stride;
   const int e = blockIdx.z, m = blockIdx.y;
   const bool is_global = m == n;
+  const bool flying = is_global || !n_active || m < n_active[e];   // (ippm_set_team_sizes: the others neither sense nor publish)
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int32_t* w = ws + (size_t)(e * (n + 1) + m) * IPPM_WS_WORDS;
   // everything a workgroup needs comes in ONE round trip: the start footprint was projected by the launch before this one
   // (343 k workgroups of one 16-byte store per lane: with the position -> lattice index -> centre table chain in front of the
   // stores the launch ran at the pace of that chain, 214 us)
   int yu = 0, yd = 0, xl = 0, xr = 0;
-  if (!is_global) {
+  if (!is_global && flying) {
     const int4 r = *reinterpret_cast<const int4*>(rect + (size_t)(e * n + m) * 4);
     yu = r.x; yd = r.y; xl = r.z; xr = r.w;
     if (xr <= xl || yd <= yu) { yu = yd = xl = xr = 0; }
@@ -767,7 +773,7 @@ extern "C" int ippm_reset_maps(ippm_ctx* ctx, const int64_t* episode, const int3
   const int fill_chunks = (c.grid_x + IPPM_RESET_ROWS - 1) / IPPM_RESET_ROWS, sense_parts = (h_max + 31) / 32;
   dim3 grid((unsigned)(fill_chunks + sense_parts), (unsigned)(c.n_agents + 1), (unsigned)n_envs);
   IPPM_LAUNCH(ctx, IPPM_T_RESET_MAPS, k_reset_maps, grid, dim3(256), S_(stream), ctx->dcfg, episode, pos, truth, local, global, flips, code, rect,
-              ws, full ? 1 : 0, fill_chunks);
+              ws, full ? 1 : 0, fill_chunks, ctx->n_active);
   IPPM_LAUNCH_CHECK("reset_maps");
   return 0;
 }
@@ -867,7 +873,7 @@ extern "C" int ippm_sense_step(ippm_ctx* ctx, const int64_t* episode, const int3
 #define IPPM_K3T___(V, M, F, R, D, T, ...)                                                                                       \
   IPPM_LAUNCH(ctx, IPPM_T_SENSE, (k_sense_tiles<V, M, F, R, D, T __VA_OPT__(,) __VA_ARGS__>), grid, block, S_(stream), rect_in, c.n_agents, agent_sel, stage, rows_per_part, \
               c.grid_y, c.grid_x, local, truth, episode, code, c.tile_stride, c.logit_clip, (uint32_t)c.philox_seed,                 \
-              (uint32_t)(c.philox_seed >> 32), ctx->dcfg, pos, flips, rect_out, ws, sums, reward, ctx->dcounters, area)
+              (uint32_t)(c.philox_seed >> 32), ctx->dcfg, pos, flips, rect_out, ws, sums, reward, ctx->dcounters, area, ctx->n_active)
 #define IPPM_K3T__(V, M, F, R, D) do { if (area) IPPM_K3T___(V, M, F, R, D, true); else IPPM_K3T___(V, M, F, R, D, false); } while (0)
 #define IPPM_K3T_(V, M, F, R) do { if (dense) IPPM_K3T__(V, M, F, R, true); else IPPM_K3T__(V, M, F, R, false); } while (0)
 #define IPPM_K3T(V, M, F) do { if (rect_in) IPPM_K3T_(V, M, F, true); else IPPM_K3T_(V, M, F, false); } while (0)
@@ -898,7 +904,7 @@ extern "C" int ippm_sense_step(ippm_ctx* ctx, const int64_t* episode, const int3
   int32_t* rect_out = rect_in == rect ? nullptr : rect;
 #define IPPM_K3_LAUNCH(V, U, T)                                                                                               \
   IPPM_LAUNCH(ctx, IPPM_T_SENSE, (k_sense_update<V, U, T>), grid, block, S_(stream), ctx->dcfg, episode, pos, truth, local, flips, code, \
-              rect_in, rect_out, ws, area, sums, reward, ctx->dcounters, stage, agent_sel, split, maps, n_envs)
+              rect_in, rect_out, ws, area, sums, reward, ctx->dcounters, stage, agent_sel, split, maps, n_envs, ctx->n_active)
   if (ctx->vec == 4) {
     if (area) { if (unr >= 2) IPPM_K3_LAUNCH(4, 2, true); else IPPM_K3_LAUNCH(4, 1, true); }
     else if (unr >= 4) IPPM_K3_LAUNCH(4, 4, false);

@@ -174,9 +174,15 @@ __device__ void indicator_plane(RectList& L, int n, int gx, int gy, float other_
 __global__ void __launch_bounds__(K6_THREADS)
 k_actor_features(const ippm_config* __restrict__ c, const double* __restrict__ area, const uint8_t* __restrict__ code,
                  const int32_t* __restrict__ rect, const int32_t* __restrict__ pos, const uint8_t* __restrict__ comm, int t,
-                 float* __restrict__ obs) {
+                 float* __restrict__ obs, const int32_t* __restrict__ n_active) {
   const int n = c->n_agents;
   const int e = blockIdx.x / n, i = blockIdx.x % n;
+  const int na = n_active ? min(max(n_active[e], 0), n) : n;   // agents flying in this env (ippm_set_team_sizes)
+  if (i >= na) {   // not flying: an all-zero observation
+    float* out0 = obs + (size_t)(e * n + i) * FEAT2 * IPPM_ACTOR_PLANES;
+    for (int q = threadIdx.x; q < FEAT2 * IPPM_ACTOR_PLANES; q += blockDim.x) out0[q] = 0.f;
+    return;
+  }
   const int gx = c->grid_x, gy = c->grid_y, S = c->tile_stride;
   extern __shared__ uint32_t s_tile[];  // the agent's code tile
   __shared__ RectList L;
@@ -195,7 +201,7 @@ k_actor_features(const ippm_config* __restrict__ c, const double* __restrict__ a
   if (tid < n) {
     const int j = tid;
     for (int q = 0; q < 4; ++q) L.r[j][q] = rect[(size_t)(e * n + j) * 4 + q];
-    const int rcv = comm[(size_t)(e * n + i) * n + j];
+    const int rcv = j < na ? comm[(size_t)(e * n + i) * n + j] : 0;
     s_recv[j] = rcv;
     L.kind[j] = j == i ? 1 : (rcv ? 2 : 0);
     const int32_t* pj = pos + (size_t)(e * n + j) * 3;
@@ -272,7 +278,7 @@ k_actor_features(const ippm_config* __restrict__ c, const double* __restrict__ a
     const float fp = (float)(0.5 + (mv1 * (double)s_c1[o] + mv0 * (double)(s_call[o] - s_c1[o])) * inv_img);
     float* dst = out + (size_t)o * IPPM_ACTOR_PLANES;
     dst[0] = (float)(c->budget - t) / (float)c->budget;
-    dst[1] = (float)(i + 1) / (float)n;
+    dst[1] = (float)(i + 1) / (float)na;
     dst[2] = pm;
     dst[3] = ippm_weight(q) * ippm_entropy(q, lo, hi);
     dst[4] = ippm_weight(fp) * ippm_entropy(fp, lo, hi);
@@ -288,9 +294,10 @@ k_actor_features(const ippm_config* __restrict__ c, const double* __restrict__ a
 __global__ void __launch_bounds__(K6_THREADS)
 k_critic_features(const ippm_config* __restrict__ c, const double* __restrict__ area, const int32_t* __restrict__ rect,
                   const int32_t* __restrict__ pos_pre, const int32_t* __restrict__ action, const float* __restrict__ obs,
-                  float* __restrict__ state) {
+                  float* __restrict__ state, const int32_t* __restrict__ n_active) {
   const int n = c->n_agents;
   const int e = blockIdx.x;
+  const int na = n_active ? min(max(n_active[e], 0), n) : n;   // agents flying in this env: the planes below know no others
   const int gx = c->grid_x, gy = c->grid_y;
   __shared__ RectList L;
   __shared__ int s_idx[IPPM_MAX_AGENTS][3];
@@ -303,7 +310,7 @@ k_critic_features(const ippm_config* __restrict__ c, const double* __restrict__ 
   if (tid < n) {
     const int j = tid;
     for (int q = 0; q < 4; ++q) L.r[j][q] = rect[(size_t)(e * n + j) * 4 + q];
-    L.kind[j] = 2;
+    L.kind[j] = j < na ? 2 : 0;
     const int32_t* pj = pos_pre + (size_t)(e * n + j) * 3;
     ippm_pos_to_index(c, pj[0], pj[1], pj[2], s_idx[j][0], s_idx[j][1], s_idx[j][2]);
     s_act[j] = action[e * n + j];
@@ -312,11 +319,11 @@ k_critic_features(const ippm_config* __restrict__ c, const double* __restrict__ 
   indicator_plane(L, n, gx, gy, 1.f, s_F);  // plane 10: 1 where any agent's measurement lies, else 0.5 (:91-108)
   const float lo = c->clip_lo, hi = c->clip_hi;
   const int Z = c->space_z, A = c->n_actions;
-  for (int w = tid; w < n * FEAT2; w += blockDim.x) {
+  for (int w = tid; w < na * FEAT2; w += blockDim.x) {
     const int i = w / FEAT2, o = w % FEAT2;
     const int a = o / IPPM_FEAT, b = o % IPPM_FEAT;
     float pm = 0.f, am_ = 0.f;
-    for (int j = 0; j < n; ++j) {
+    for (int j = 0; j < na; ++j) {
       if (s_idx[j][0] == a && s_idx[j][1] == b) {
         pm = (float)(s_idx[j][2] + 1) / (float)Z;
         if (j != i) am_ = (float)(s_act[j] + 1) / (float)A;
@@ -466,7 +473,7 @@ extern "C" int ippm_actor_features(ippm_ctx* ctx, const double* area, const uint
   const ippm_config& c = ctx->cfg;
   const size_t tile = ippm_tile_bytes(c.tile_stride, ctx->vec);
   IPPM_LAUNCH_SH(ctx, IPPM_T_ACTOR_FEAT, k_actor_features, dim3(n_envs * c.n_agents), dim3(K6_THREADS), (tile + 3) / 4 * 4, S_(stream), ctx->dcfg, area,
-                     code, rect, pos, comm, t, obs);
+                     code, rect, pos, comm, t, obs, ctx->n_active);
   IPPM_LAUNCH_CHECK("actor_features");
   return 0;
 }
@@ -476,7 +483,7 @@ extern "C" int ippm_critic_features(ippm_ctx* ctx, const double* area, const int
   if (!ctx || !area || !rect || !pos_pre || !action || !obs || !state) { ippm_set_error("ippm_critic_features: null argument"); return -1; }
   if (int rc = feature_checks(ctx, "ippm_critic_features")) return rc;
   if (n_envs <= 0) return 0;
-  IPPM_LAUNCH(ctx, IPPM_T_CRITIC_FEAT, k_critic_features, dim3(n_envs), dim3(K6_THREADS), S_(stream), ctx->dcfg, area, rect, pos_pre, action, obs, state);
+  IPPM_LAUNCH(ctx, IPPM_T_CRITIC_FEAT, k_critic_features, dim3(n_envs), dim3(K6_THREADS), S_(stream), ctx->dcfg, area, rect, pos_pre, action, obs, state, ctx->n_active);
   IPPM_LAUNCH_CHECK("critic_features");
   return 0;
 }

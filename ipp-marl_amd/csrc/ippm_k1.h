@@ -83,8 +83,9 @@ __device__ __forceinline__ void wave_sync_lds() {
 // actor/network.py:90-96, coma_wrapper.py:97-104)
 __device__ void k1_env(const ippm_config* __restrict__ c, int64_t ep, int32_t* s_pos, const float* __restrict__ probs_e,
                        const int32_t* __restrict__ action_in_e, int policy, int t, uint8_t* __restrict__ mask_e,
-                       int32_t* __restrict__ action_e, int32_t* __restrict__ fault_e) {
-  const int n = c->n_agents, A = c->n_actions, s = c->spacing;
+                       int32_t* __restrict__ action_e, int32_t* __restrict__ fault_e, int n_act = -1) {
+  // n = the agents that fly in this env (ippm_set_team_sizes; all of them by default): the loops below never look at the others
+  const int n = n_act >= 0 ? n_act : c->n_agents, A = c->n_actions, s = c->spacing;
   const int lane = threadIdx.x & 63;
   const uint32_t k0 = (uint32_t)c->philox_seed, k1 = (uint32_t)(c->philox_seed >> 32);
   int flt = 0;

@@ -88,9 +88,10 @@ __device__ __forceinline__ void plan_push(const ippm_config* __restrict__ c, int
 // prefetched by the caller (global memory or LDS / registers).
 __device__ __forceinline__ int plan_map(const ippm_config* __restrict__ c, const int32_t* rect_e, const int32_t* pos_e, uint32_t recv,
                                          int32_t* __restrict__ ws, int global_maps, int e, int i, const int32_t* st,
-                                         int4* s_ops = nullptr, int32_t* s_nops = nullptr) {
-  const int n = c->n_agents;
-  int32_t* w = ws + (size_t)(e * (n + 1) + i) * IPPM_WS_WORDS;
+                                         int4* s_ops = nullptr, int32_t* s_nops = nullptr, int n_act = -1) {
+  const int n_all = c->n_agents;
+  const int n = n_act >= 0 ? n_act : n_all;   // agents flying in this env (messages come from them only)
+  int32_t* w = ws + (size_t)(e * (n_all + 1) + i) * IPPM_WS_WORDS;
   int nops = 0, x0 = 1 << 30, x1 = -1, y0 = 1 << 30, y1 = -1;
   int last_src = -1;
   for (int j = 0; j < n; ++j) {
@@ -145,9 +146,9 @@ __device__ __forceinline__ int plan_map(const ippm_config* __restrict__ c, const
 // serial loop was 4 of the kernel's 12 us).  Same results as plan_map, field by field.
 __device__ __forceinline__ int plan_map_fast(const ippm_config* __restrict__ c, const int4* s_rect4, const int4* s_rec, uint32_t recv,
                                               int32_t* __restrict__ ws, int global_maps, int e, int i, const int32_t* st,
-                                              int4* s_ops, int32_t* s_nops) {
-  const int n = c->n_agents;
-  int32_t* w = ws + (size_t)(e * (n + 1) + i) * IPPM_WS_WORDS;
+                                              int4* s_ops, int32_t* s_nops, int n_act) {
+  const int n = n_act;    // agents flying in this env (messages come from them only); strides use the configured team size
+  int32_t* w = ws + (size_t)(e * (c->n_agents + 1) + i) * IPPM_WS_WORDS;
   const uint32_t all = n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
   const uint32_t takes = global_maps ? all : (recv & ~(1u << i) & all);
   int32_t* hdr = w + WS_PLAN;
@@ -405,7 +406,7 @@ k_plan_step(int32_t* __restrict__ pos, const int32_t* __restrict__ rect, int32_t
             const float* __restrict__ probs,
             const int32_t* __restrict__ action_in, uint8_t* __restrict__ mask, int32_t* __restrict__ action,
             int32_t* __restrict__ fault, int32_t* __restrict__ rect_next, int agent_sel, int32_t* __restrict__ work,
-            int wave_rows, int env_cap, unsigned long long* __restrict__ stamps) {
+            int wave_rows, int env_cap, unsigned long long* __restrict__ stamps, const int32_t* __restrict__ n_active) {
   // (argument order = latency order: what the first loads need -- positions, footprints, the maps' clamp state, the team size --
   // arrives in SGPRs with the wavefront, so the loads go out before anything else has been read)
   // Wavefront 0 plans (comm matrix, fusion plans, written-cells boxes).  With a tile-form work list the workgroup carries more
@@ -418,6 +419,9 @@ k_plan_step(int32_t* __restrict__ pos, const int32_t* __restrict__ rect, int32_t
   // releases), K1 waits for nobody.  K1's LDS traffic stays inside its wavefront (wave_sync_lds).
   const int e = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int A = c->n_actions;
+  // na: the agents that fly in this env (ippm_set_team_sizes; n = the configured team size = the arrays' stride, by default all fly).
+  // The others are heard by nobody and hear nobody, get no plan, do not move and get no sense record: K3 finds an empty footprint.
+  const int na = n_active ? min(max(n_active[e], 0), n) : n;
   __shared__ int32_t s_pos[IPPM_MAX_AGENTS * 3];    // pre-move positions: what comm and the plans see
   __shared__ int32_t s_pos1[IPPM_MAX_AGENTS * 3];   // K1's working copy (moved in place)
   __shared__ int4 s_rect4[IPPM_MAX_AGENTS];
@@ -475,7 +479,7 @@ k_plan_step(int32_t* __restrict__ pos, const int32_t* __restrict__ rect, int32_t
         const int p = p0 + lane;
         if (p < n * n) {
           const int i = (int)(((float)p + 0.5f) * inv_n), j = p - i * n;
-          const bool ok = comm_pair(c, ep, s_pos, range, draws, t, e, i, j);
+          const bool ok = i < na && j < na && comm_pair(c, ep, s_pos, range, draws, t, e, i, j);
           comm[(size_t)e * n * n + p] = ok ? 1 : 0;
           if (ok) atomicOr(&s_recv[i], 1u << j);
         }
@@ -486,15 +490,15 @@ k_plan_step(int32_t* __restrict__ pos, const int32_t* __restrict__ rect, int32_t
     PLAN_STAMP(7);
     if (tiled) {
       wave_sync_lds();
-      if ((flags & IPPM_STEP_COMM) && lane < n && (agent_sel < 0 || agent_sel == lane))
-        hull_rows = plan_map_fast(c, s_rect4, s_rec, recv, ws, 0, e, lane, st, s_ops + lane * IPPM_MAX_OPS, s_nops + lane);
+      if ((flags & IPPM_STEP_COMM) && lane < na && (agent_sel < 0 || agent_sel == lane))
+        hull_rows = plan_map_fast(c, s_rect4, s_rec, recv, ws, 0, e, lane, st, s_ops + lane * IPPM_MAX_OPS, s_nops + lane, na);
       if ((flags & IPPM_STEP_GLOBAL) && lane == n)
-        hull_rows = plan_map_fast(c, s_rect4, s_rec, 0u, ws, 1, e, n, st, s_ops + n * IPPM_MAX_OPS, s_nops + n);
+        hull_rows = plan_map_fast(c, s_rect4, s_rec, 0u, ws, 1, e, n, st, s_ops + n * IPPM_MAX_OPS, s_nops + n, na);
     } else {
-      if ((flags & IPPM_STEP_COMM) && lane < n && (agent_sel < 0 || agent_sel == lane))
-        hull_rows = plan_map(c, s_rect, s_pos, recv, ws, 0, e, lane, st);
+      if ((flags & IPPM_STEP_COMM) && lane < na && (agent_sel < 0 || agent_sel == lane))
+        hull_rows = plan_map(c, s_rect, s_pos, recv, ws, 0, e, lane, st, nullptr, nullptr, na);
       if ((flags & IPPM_STEP_GLOBAL) && lane == n)
-        hull_rows = plan_map(c, s_rect, s_pos, 0u, ws, 1, e, n, st);
+        hull_rows = plan_map(c, s_rect, s_pos, 0u, ws, 1, e, n, st, nullptr, nullptr, na);
     }
     // the map's fused-cells box takes in this step's plan hull (ippm_reset_maps fills only the boxes at the next reset)
     if (lane <= n && hull_rows > 0) {
@@ -556,9 +560,14 @@ k_plan_step(int32_t* __restrict__ pos, const int32_t* __restrict__ rect, int32_t
   PLAN_STAMP(5);
   k1_env(c, episode ? episode[e] : 0, s_pos1, probs ? probs + (size_t)e * n * A : nullptr,
          action_in ? action_in + (size_t)e * n : nullptr, policy, t, mask + (size_t)e * n * A, action + (size_t)e * n,
-         fault ? fault + e : nullptr);
+         fault ? fault + e : nullptr, na);
   if (lane < n * 3) pg[lane] = s_pos1[lane];
-  if (rect_next && lane < n) {
+  if (rect_next && lane >= na && lane < n) {   // not flying: an empty sense record (K3's workgroups for it leave at once)
+    int4* r = reinterpret_cast<int4*>(rect_next + (size_t)(e * n + lane) * IPPM_SENSE_REC_WORDS);
+    r[0] = make_int4(0, 0, 0, 0);
+    r[1] = make_int4(0, 0, 0, 0);
+  }
+  if (rect_next && lane < na) {
     // the agent's sense record: K3 starts from these 32 bytes alone (footprint + the measurement constants of the new altitude)
     int cl[4];
     ippm_footprint_rect(c, s_pos1[lane * 3], s_pos1[lane * 3 + 1], s_pos1[lane * 3 + 2], cl, nullptr);
@@ -667,7 +676,7 @@ extern "C" int ippm_plan_step(ippm_ctx* ctx, const int64_t* episode, int32_t* po
   IPPM_LAUNCH(ctx, IPPM_T_PLAN, k_plan_step, dim3(n_envs), dim3(64 * plan_waves), S_(stream), pos, rect, ws, ctx->cfg.n_agents, flags, t, policy,
                      ctx->dcfg, episode, comm_range, draws, comm, probs, action_in, mask, action, fault, rect_next, -1, plans ? work : nullptr,
                      ippm_fuse_wave_rows(ctx, n_envs), (flags & IPPM_STEP_TILES) ? ippm_tile_env_cap(ctx) : ippm_work_env_cap(ctx, n_envs),
-                     ctx->dcounters);
+                     ctx->dcounters, ctx->n_active);
   IPPM_LAUNCH_CHECK("plan_step");
   return 0;
 }

@@ -68,6 +68,7 @@ PROTOTYPES = {
     "ippm_stream_copy": [P, P, P, I64, P],
     "ippm_sense_update": [P, P, P, P, P, P, P, P, P, I32, I32, I32, P],
     "ippm_sense_step": [P, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, P],
+    "ippm_set_team_sizes": [P, P],
     "ippm_plan_step": [P, P, P, P, P, P, P, P, I32, I32, P, P, I32, P, P, P, P, P, I32, P],
     "ippm_fuse_step": [P, P, P, P, P, P, P, P, I32, P],
     "ippm_reward_finalize": [P, P, P, I32, P],

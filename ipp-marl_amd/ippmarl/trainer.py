@@ -22,9 +22,10 @@ from .vec_env import VecEnv, POLICY_ARGMAX, POLICY_SAMPLE
 class COMATrainer:
     def __init__(self, params: Dict, n_envs: int, device: str = "cuda:0", philox_seed: int = 3, waves_per_update: int = 1,
                  quirks: str = "reference", rank: int = 0, world: int = 1, first_episode: int = 1,
-                 terrain: str = "split", graphs: bool = False, placement_draws: int = 24):
+                 terrain: str = "split", graphs: bool = False, placement_draws: int = 24, team_sizes=None):
         self.params = params
-        self.env = VecEnv(params, n_envs, device=device, philox_seed=philox_seed, terrain=terrain)
+        # team_sizes: mixed team sizes in one batch (VecEnv): the transitions of agents that do not fly never enter a minibatch
+        self.env = VecEnv(params, n_envs, device=device, philox_seed=philox_seed, terrain=terrain, team_sizes=team_sizes)
         # Large batches: where the allocator put the maps decides ~10 % of the rollout's map kernels (VecEnv.tune_placement).  The
         # default is bench.py's: the search stops at the first fast allocation (~10 ms a draw at config 2), returns None without
         # drawing for batches below 2^24 cells, keeps its rejected candidates within half of the free memory; <= 1: no search.
@@ -137,8 +138,8 @@ class COMATrainer:
         selection, allocator warm-up); waves_per_update = 1, hard target updates, one rank."""
         if not self.graphs:
             raise _ffi.IppmError("COMATrainer(graphs=True) is needed: captured optimizer steps keep their counters on the device")
-        if self.waves_per_update != 1 or self.world != 1 or self.critic_learner.target_update_mode != "hard":
-            raise _ffi.IppmError("capture_graphs: one wave per update, one rank and hard target updates only")
+        if self.waves_per_update != 1 or self.world != 1 or self.critic_learner.target_update_mode != "hard" or self.env.n_active is not None:
+            raise _ffi.IppmError("capture_graphs: one wave per update, one rank, hard target updates and one team size only")
         env = self.env
         env.profile = False
         torch.cuda.synchronize(self.device)
@@ -215,8 +216,17 @@ class COMATrainer:
                     "adam_steps": 2 * self.data_passes * self.batch_number, "train_step": self.train_step}
         closs, aloss = self._update_compute(None, self.eps_dev if self.graphs else self.eps, diagnostics)
         self.filled = 0
+        if self.env.n_active is not None:
+            n = int(self.env.n_active.sum()) * W * T
         return {"critic_loss": float(closs), "actor_loss": float(aloss), "transitions": n * self.world,
                 "adam_steps": 2 * self.data_passes * self.batch_number, "train_step": self.train_step}
+
+    def valid_transitions(self, waves: int) -> Optional[torch.Tensor]:
+        """Indices into the flattened [waves, T, E, N] buffers of the transitions of agents that fly (None: all of them do)."""
+        if self.env.n_active is None:
+            return None
+        flying = torch.arange(self.N, device=self.device).view(1, self.N) < self.env.n_active.view(self.E, 1)     # [E, N]
+        return flying.view(1, 1, self.E, self.N).expand(waves, self.T, self.E, self.N).reshape(-1).nonzero().view(-1)
 
     def _update_compute(self, perms, eps, diagnostics: bool):
         """The arithmetic of one round.  ``perms`` None: eager (draws the minibatch permutations, syncs the target network and
@@ -230,10 +240,14 @@ class COMATrainer:
         states = self.buf_state[:W].reshape(n, 11, 11, 12)
         actions = self.buf_action[:W].reshape(n)
         masks = self.buf_mask[:W].reshape(n, self.A)
-        bs = n // self.batch_number
+        flying = self.valid_transitions(W)           # mixed team sizes: minibatches are drawn from the agents that fly
+        nv = n if flying is None else int(flying.numel())
+        bs = nv // self.batch_number
         closs = aloss = torch.zeros((), device=self.device)
         for data_pass in range(self.data_passes):
-            perm = torch.randperm(n, device=self.device) if eager else perms[data_pass]
+            perm = torch.randperm(nv, device=self.device) if eager else perms[data_pass]
+            if flying is not None:
+                perm = flying[perm]
             if eager:
                 self.critic_learner.update_target_network(self.train_step, data_pass)
             collect = diagnostics and data_pass == 0

@@ -73,7 +73,7 @@ def placement_stop_reason(scores) -> Optional[str]:
 
 class VecEnv:
     def __init__(self, params: Dict, n_envs: int, device: str = "cuda:0", philox_seed: int = 3, terrain: str = "split",
-                 track_area: bool = True):
+                 track_area: bool = True, team_sizes=None):
         if not torch.cuda.is_available():
             raise _ffi.IppmError("VecEnv needs an AMD GPU (HIP): there is no CPU path for the env step")
         self.params = params
@@ -97,6 +97,17 @@ class VecEnv:
         self._hot_shapes = (("local", (E, N, d.grid_x, d.grid_y), torch.float32), ("glob", (E, d.grid_x, d.grid_y), torch.float32),
                             ("code", (E, N, d.tile_bytes), torch.uint8), ("truth", (E, d.truth_bytes), torch.uint8))
         self._place_hot()
+        # Mixed team sizes in one batch (BASELINE config 5): env e flies team_sizes[e] <= n_agents UAVs and evolves exactly like a
+        # run of the reference with that n_agents (its team size is a per-run parameter: coma_wrapper.py:25-26,
+        # missions/episode_generator.py:99-102).  Arrays keep the [E, n_agents, ...] shapes; rows of agents that do not fly are
+        # not meaningful (their observations are zero, their sense records empty).  None: every env flies n_agents.
+        self.n_active = None
+        if team_sizes is not None:
+            ts = torch.as_tensor(team_sizes, dtype=torch.int32).reshape(-1)
+            if ts.numel() != E or int(ts.min()) < 1 or int(ts.max()) > N:
+                raise ValueError(f"team_sizes: {E} values in 1..{N} (params' n_agents is the capacity)")
+            self.n_active = ts.to(dev)
+            self.ctx.call("ippm_set_team_sizes", self._p(self.n_active))
         self.comm = z(E, N, N, dtype=torch.uint8)
         self.comm_range = z(E, dtype=torch.float32)
         self.mask = z(E, N, A, dtype=torch.uint8)
@@ -328,6 +339,8 @@ class VecEnv:
 
     def fuse_local(self, agent: int = -1):
         """Stand-alone K4 (drop-in Agent.receive_messages); does not track the area sums."""
+        if self.n_active is not None:
+            raise _ffi.IppmError("fuse_local: the single-purpose entry points know one team size per context (team_sizes is set)")
         self._boxes_valid = False
         self.ctx.call("ippm_fuse_local", self._p(self.local), self._p(self.code), self._p(self.rect), self._p(self.pos),
                       self._p(self.comm), self._p(self.ws), agent, self.E, self.stream)
@@ -417,6 +430,8 @@ class VecEnv:
     def ig_actions(self, communication: bool = True) -> torch.Tensor:
         """Actions int32 [E,N] of the greedy expected-information-gain planner on the current local maps: masks against the
         current positions of the agents before each one (the reference's quirk), K9 candidate gains, K10 selection."""
+        if self.n_active is not None:
+            raise _ffi.IppmError("ig_actions: the greedy planner's kernels know one team size per context (team_sizes is set)")
         d, E, N, A = self.d, self.E, self.d.n_agents, self.d.n_actions
         others = self.pos.view(E, 1, N, 3).expand(E, N, N, 3).contiguous()
         n_others = torch.arange(N, dtype=torch.int32, device=self.device).view(1, N).expand(E, N).contiguous()

@@ -48,9 +48,11 @@ def _job(args):
 def philox_episodes(params, episodes, seed, truths=None, min_parallel_cells=1 << 19):
     """[philox_episode(...)] for every episode of a batch; in worker processes when the grid is large enough to pay for them."""
     truths = [None] * len(episodes) if truths is None else list(truths)
-    jobs = [(params, int(ep), seed, tr) for ep, tr in zip(episodes, truths)]
+    # (params: one dict for the batch, or one per episode -- mixed team sizes: env e is a run with its own n_agents)
+    per_env = list(params) if isinstance(params, (list, tuple)) else [params] * len(episodes)
+    jobs = [(pr, int(ep), seed, tr) for pr, ep, tr in zip(per_env, episodes, truths)]
     import ipp_oracle as O
-    d = O.Derived(params)
+    d = O.Derived(max(per_env, key=lambda pr: pr["experiment"]["missions"]["n_agents"]))
     if len(jobs) < 2 or d.gx * d.gy * d.n_agents < min_parallel_cells:
         return [_job(j) for j in jobs]
     workers = min(len(jobs), max(1, (os.cpu_count() or 2) - 1))

@@ -129,21 +129,26 @@ def test_production_randomness_matches_oracle(name, over, n_envs):
     check_philox_episodes(name, over, n_envs)
 
 
-def check_philox_episodes(name, over, n_envs, seed=0x1234567ABC, first_episode=11, track_area=True, fused_step=False, terrain="split"):
+def check_philox_episodes(name, over, n_envs, seed=0x1234567ABC, first_episode=11, track_area=True, fused_step=False, terrain="split",
+                          team_sizes=None):
     """The every-step comparison of a batch with the oracle under the production randomness; returns the number of class-weight
     threshold ties met (conftest).  (``seed`` / ``first_episode``: tools/stress_parity.py sweeps random configurations through it.)
     ``fused_step``: ``steps()`` alone, i.e. ONE plan launch (comm + plans + work list + K1) -> fusion -> K3, the exact launch
     sequence bench.py times; the locally fused maps cannot be looked at between fusion and sensing then, so the local maps are
     compared after the step's sensing instead.  ``terrain="random_field"``: the device synthesises the field (bench.py's input);
-    the generated truth is handed to the oracle, whose own field uses NumPy's legacy normal stream instead of Philox."""
+    the generated truth is handed to the oracle, whose own field uses NumPy's legacy normal stream instead of Philox.
+    ``team_sizes``: env e flies team_sizes[e] of the configured n_agents UAVs and is compared with an oracle run whose n_agents is
+    team_sizes[e] (the reference's team size is a per-run parameter)."""
     from oracle_pool import philox_episodes
     from ippmarl.vec_env import POLICY_UNIFORM
     params = make_params(name, **over)
-    env = _env(params, n_envs, philox_seed=seed, track_area=track_area, terrain=terrain)
+    env = _env(params, n_envs, philox_seed=seed, track_area=track_area, terrain=terrain, team_sizes=team_sizes)
     eps = [first_episode + 7 * k for k in range(n_envs)]
     env.reset(eps)
     truths = None if terrain == "split" else list(env.truth_map.numpy().astype(np.float64))
-    oracles = philox_episodes(params, eps, seed, truths)
+    teams = [env.d.n_agents] * n_envs if team_sizes is None else [int(v) for v in team_sizes]
+    oracles = philox_episodes(params if team_sizes is None else
+                              [make_params(name, **dict(over, experiment__missions__n_agents=n_e)) for n_e in teams], eps, seed, truths)
     T = env.d.budget + 1
     feats = track_area and not fused_step   # (the 493 x 493 default grid included: its feature bins are not whole cells wide)
     ties = 0
@@ -159,22 +164,23 @@ def check_philox_episodes(name, over, n_envs, seed=0x1234567ABC, first_episode=1
         sensed = env.posterior_local().cpu().numpy() if fused_step else None
         for e, (log, _, _) in enumerate(oracles):
             rec = log[t]
-            n = env.d.n_agents
-            want_comm = np.zeros((n, n), dtype=np.uint8)
+            n = teams[e]                      # the agents flying in this env (all of them unless team_sizes is given)
+            want_comm = np.zeros((env.d.n_agents, env.d.n_agents), dtype=np.uint8)   # (nobody hears, or is heard by, the others)
             for i, ks in enumerate(rec["received"]):
                 want_comm[i, ks] = 1
             assert np.array_equal(comm[e], want_comm), (t, e)
-            assert np.array_equal(env.mask[e].cpu().numpy(), rec["masks"].astype(np.uint8)), (t, e)
-            assert np.array_equal(env.action[e].cpu().numpy(), rec["actions"]), (t, e)
-            assert np.array_equal(env.pos[e].cpu().numpy(), rec["next_positions"]), (t, e)
-            assert np.array_equal(env.rect[e].cpu().numpy(), rec["next_rects"]), (t, e)
+            assert np.array_equal(env.mask[e, :n].cpu().numpy(), rec["masks"].astype(np.uint8)), (t, e)
+            assert np.array_equal(env.action[e, :n].cpu().numpy(), rec["actions"]), (t, e)
+            assert np.array_equal(env.pos[e, :n].cpu().numpy(), rec["next_positions"]), (t, e)
+            assert np.array_equal(env.rect[e, :n].cpu().numpy(), rec["next_rects"]), (t, e)
+            assert not env.rect[e, n:].any(), (t, e)          # the others publish empty footprints
             # every cell of every map within 1e-5 -- prior != 0.5 included: there every message shifts every cell of the grid, and the
             # chain of a fusion runs in float64 registers and is rounded once, at the store
             strict = True
             if fused_step:
-                assert_posteriors(sensed[e], np.array(rec["sensed_local"]), strict=strict, msg=f"local after sensing t={t} e={e}")
+                assert_posteriors(sensed[e, :n], np.array(rec["sensed_local"]), strict=strict, msg=f"local after sensing t={t} e={e}")
             else:
-                assert_posteriors(local[e], np.array(rec["fused_local"]), strict=strict, msg=f"fused local t={t} e={e}")
+                assert_posteriors(local[e, :n], np.array(rec["fused_local"]), strict=strict, msg=f"fused local t={t} e={e}")
             assert_posteriors(glob[e], rec["global_map"], strict=strict, msg=f"global t={t} e={e}")
             # returns: 1e-5 in every regime.  (Altitudes outside the sensor model's table are noise-free: cells jump between exactly
             # 0 / 1 and the clip, the reward terms are of size 1 with both signs and S1 is what is left after they cancel -- every
@@ -203,9 +209,29 @@ def check_philox_episodes(name, over, n_envs, seed=0x1234567ABC, first_episode=1
                     ties += assert_features_or_ties(got_state[i], rec["states"][i], dec, RTOL, fa, f"state t={t} e={e} i={i}")
     final = env.posterior_local().cpu().numpy()
     for e, (_, final_local, _) in enumerate(oracles):
-        assert_posteriors(final[e], final_local, strict=True, msg=f"final local e={e}")
+        assert_posteriors(final[e, :teams[e]], final_local, strict=True, msg=f"final local e={e}")
+        assert (final[e, teams[e]:] == env.d.prior).all(), e       # the maps of agents that do not fly stay at the prior
     assert env.counters()["work_list_rejects"] == 0
     return ties
+
+
+@pytest.mark.parametrize("name,over,teams", [
+    ("small", dict(experiment__missions__n_agents=6), [1, 2, 3, 6, 4, 5]),
+    ("small", dict(experiment__missions__n_agents=5, experiment__uav__failure_rate=0.3, experiment__uav__fix_range=False,
+                   experiment__constraints__num_actions=27), [5, 2, 4]),
+    # BASELINE config 5 as it is worded: "mixed team sizes 2-16 UAVs, 3D altitude action space, 1024 x 1024 grid with comm-range
+    # masking" -- four envs of one batch flying 2, 4, 8 and 16 UAVs, each against an oracle run of that team size
+    ("c5", dict(experiment__missions__n_agents=16), [2, 4, 8, 16]),
+])
+@pytest.mark.parametrize("fused_step", [False, True])
+def test_mixed_team_sizes_in_one_batch_match_oracle(name, over, teams, fused_step):
+    """VecEnv(team_sizes=...): env e flies teams[e] of the configured UAVs and evolves, step by step, exactly like a run of the
+    reference (oracle) whose n_agents is teams[e] -- comm matrices, masks, actions, positions, footprints bit for bit, maps, rewards
+    and network inputs (agent-id plane (i + 1) / teams[e]) at 1e-5; with the network inputs built (two plan launches per step,
+    tracked kernels) and in the env-only form bench.py times."""
+    if name == "c5" and not fused_step:
+        pytest.skip("the 1024 x 1024 batch runs once, in the env-only form (the tracked form is covered at 128 x 128)")
+    check_philox_episodes(name, over, len(teams), team_sizes=teams, fused_step=fused_step, track_area=not fused_step)
 
 
 @pytest.mark.parametrize("name,over,n_envs", [

@@ -152,6 +152,56 @@ def test_sampling_policy_matches_oracle():
     assert np.array_equal(act, np.argmax(probs * mask, axis=-1))
 
 
+def test_trainer_round_with_mixed_team_sizes():
+    """COMATrainer(team_sizes=...): a learned-policy rollout and a COMA update over a batch whose envs fly 1 .. 4 of 4 UAVs: the
+    agents that do not fly stay where they started, get all-zero observations, publish nothing, and none of their transitions
+    enters a minibatch; TD(lambda) chains of flying agents against the oracle's restatement."""
+    from ippmarl.trainer import COMATrainer
+    params = make_params("small")
+    teams = [1, 2, 3, 4, 4, 2]
+    torch.manual_seed(5)
+    tr = COMATrainer(params, n_envs=len(teams), first_episode=3, team_sizes=teams)
+    E, N, T = tr.E, tr.N, tr.T
+    tr.keep_rollout_log = True
+    start = None
+    stats = tr.rollout("train")
+    assert stats["faults"] == 0
+    flying = np.array([[i < n_e for i in range(N)] for n_e in teams])
+    obs = tr.buf_obs[0].cpu().numpy()                    # [T, E, N, 11, 11, 7]
+    assert not obs[:, ~flying].any()                     # all-zero observations for agents that do not fly
+    assert np.allclose(obs[:, flying][..., 1].reshape(T, -1, 121).min(axis=2), obs[:, flying][..., 1].reshape(T, -1, 121).max(axis=2))
+    want_id = np.concatenate([[(i + 1) / n_e for i in range(n_e)] for n_e in teams])
+    np.testing.assert_allclose(obs[0][flying][:, 0, 0, 1], want_id, rtol=1e-6)     # agent-id plane (i + 1) / team size
+    comm = tr.env.comm.cpu().numpy()
+    for e, n_e in enumerate(teams):
+        assert not comm[e, n_e:].any() and not comm[e, :, n_e:].any()
+    idx = tr.valid_transitions(1).cpu().numpy()
+    assert len(idx) == sum(teams) * T
+    agent_of = idx % N
+    env_of = (idx // N) % E
+    assert all(agent_of[k] < teams[env_of[k]] for k in range(len(idx)))
+    td, _ = tr.td_targets()
+    td = td.view(1, T, E, N).cpu().numpy()
+    rew = tr.buf_reward[:1].cpu().numpy()
+    g, lam = params["networks"]["gamma"], params["networks"]["lambda"]
+    dones = np.zeros(T, dtype=bool)
+    dones[T - 1] = True
+    for e, i in ((0, 0), (1, 1), (2, 2), (5, 1)):
+        with torch.no_grad():
+            q, _ = tr.frozen_target(tr.buf_state[0, :, e, i].reshape(T, 11, 11, 12).contiguous())
+        q_sel = q.gather(1, tr.buf_action[0, :, e, i].reshape(-1, 1).long()).view(-1).cpu().numpy()
+        want, _ = O.td_lambda_targets(rew[0, :, e], dones, q_sel, g, lam)
+        np.testing.assert_allclose(td[0, :, e, i], want, rtol=1e-5, atol=2e-6)
+    before = [p.detach().clone() for p in tr.actor.parameters()]
+    out = tr.update()
+    assert out["transitions"] == sum(teams) * T and out["adam_steps"] == 50
+    assert np.isfinite(out["critic_loss"]) and np.isfinite(out["actor_loss"])
+    assert any(not torch.equal(a, b.detach()) for a, b in zip(before, tr.actor.parameters()))
+    with pytest.raises(Exception, match="one team size"):
+        COMATrainer(params, n_envs=2, graphs=True, team_sizes=[1, 2]).capture_graphs()
+    del start
+
+
 def test_evaluation_metrics_match_oracle():
     """COMATrainer.map_metrics / evaluate: target entropy and F1 of the global maps against the oracle's restatement."""
     from ippmarl.trainer import COMATrainer

@@ -12,7 +12,16 @@ import torch  # noqa: E402
 from ippmarl.params import grid256_params  # noqa: E402
 from ippmarl.trainer import COMATrainer  # noqa: E402
 
-tr = COMATrainer(grid256_params(), int(os.environ.get("ENVS", 1024)))
+tr = COMATrainer(grid256_params(), int(os.environ.get("ENVS", 1024)), terrain=os.environ.get("TERRAIN", "split"))
+if os.environ.get("ROLLOUT_ONLY", "0") == "1":   # counter passes: the rollout's map kernels only (three stream copies of the local maps first:
+    scratch = torch.empty_like(tr.env.local)      # the calibration of tools/pmc_summary.py)
+    for _ in range(3):
+        tr.env.ctx.call("ippm_stream_copy", tr.env._p(tr.env.local), tr.env._p(scratch), tr.env.local.numel() * 4, tr.env.stream)
+    tr.rollout("train"); tr.filled = 0
+    tr.rollout("train"); tr.filled = 0
+    torch.cuda.synchronize()
+    print("two rollouts")
+    raise SystemExit(0)
 tr.rollout("train"); tr.update()
 torch.cuda.synchronize()
 t0 = time.perf_counter(); tr.rollout("train"); torch.cuda.synchronize(); t1 = time.perf_counter()
