@@ -149,14 +149,15 @@ def ipc_env_setting(env, mode: str) -> str:
     return mode
 
 
-def newest_pmc_summary(n_envs, n_agents, grid):
+def newest_pmc_summary(n_envs, n_agents, grid, launch_envs=None):
     """profiles/rNN/pmc_summary*.json of the newest round that has one FOR THIS SHAPE (written by tools/pmc_summary.py from
     separate rocprofv3 --pmc passes of this command: pmc_summary.json = config 2, pmc_summary_c4.json / _c5.json = the shapes of
     BASELINE configs 4 and 5)."""
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]", "pmc_summary*.json")), reverse=True):
         with open(path) as f:
             rec = json.load(f)
-        if (rec.get("envs_per_gpu"), rec.get("n_agents"), rec.get("grid")) == (n_envs, n_agents, grid):
+        if (rec.get("envs_per_gpu"), rec.get("n_agents"), rec.get("grid")) == (n_envs, n_agents, grid) and \
+                rec.get("envs_per_launch", rec.get("envs_per_gpu")) == (launch_envs or n_envs):
             return rec, os.path.relpath(path, ROOT)
     return None, None
 
@@ -172,6 +173,9 @@ def main():
     ap.add_argument("--actions", type=int, default=None, choices=[4, 6, 9, 27], help="action set (default: params.yaml's 6)")
     ap.add_argument("--episode-comm-range", action="store_true", help="per-episode comm range from {0, 15, 25, 100} m "
                     "(experiment.uav.fix_range: False, BASELINE config 5's comm-range masking)")
+    ap.add_argument("--streams", type=int, default=2, help="step the batch as this many sub-batches, each on its own HIP stream "
+                    "(ippmarl.vec_env.SplitVecEnv): the latency-bound plan kernel and the reset of one runs beside the bandwidth-bound map "
+                    "kernels of the other -- 0.1526 -> 0.141 ms per step at config 2; 1 = one stream, one launch per kernel and step")
     ap.add_argument("--team-sizes", default=None, help="comma-separated team sizes dealt out to the envs in turn (BASELINE config 5's mixed teams, "
                     "e.g. 2,4,8,16 with --agents 16): env e flies team_sizes[e %% len] of the --agents UAVs; agent-env steps count the flying ones")
     ap.add_argument("--comm-range", type=float, default=None, help="experiment.uav.communication_range in metres (default: params.yaml's 25)")
@@ -248,17 +252,27 @@ def main():
 
     from ippmarl import _ffi
     from ippmarl.parallel import episode_ids
-    from ippmarl.vec_env import VecEnv, POLICY_UNIFORM
+    from ippmarl.vec_env import SplitVecEnv, VecEnv, POLICY_UNIFORM
     params = bench_params(args)
     # env-only stepping never builds network inputs: the area sums are not tracked here (the trainer below tracks them)
     teams = None
     if args.team_sizes:
         pattern = [int(v) for v in args.team_sizes.split(",")]
         teams = [pattern[e % len(pattern)] for e in range(args.envs)]
-    env = VecEnv(params, args.envs, device=device, philox_seed=3, terrain=args.terrain, track_area=False, team_sizes=teams)
+    split = args.streams > 1 and not args.graphs and not args.terrain_prefetch
+    if split:   # the batch as sub-batches on their own streams (same envs, same episodes, same results)
+        env = SplitVecEnv(params, args.envs, parts=args.streams, device=device, philox_seed=3, terrain=args.terrain, team_sizes=teams)
+    else:
+        env = VecEnv(params, args.envs, device=device, philox_seed=3, terrain=args.terrain, track_area=False, team_sizes=teams)
+    # The roofline leg measures the kernels ONE LAUNCH AT A TIME at the full batch: with sub-batches on several streams that is a
+    # second, whole-batch VecEnv (same config, same library, its own placement search), stepped on one stream after the timed loops.
+    roof_env = VecEnv(params, args.envs, device=device, philox_seed=3, terrain=args.terrain, track_area=False, team_sizes=teams) \
+        if split and args.roofline_steps > 0 else env
+    first = roof_env if split and args.roofline_steps > 0 else (env.parts[0] if split else env)   # (copy-rate yardstick, PMC calibration)
     # where the allocator puts the maps is worth 10 % of the fusion kernel (VecEnv.tune_placement): a few candidate sets, one
     # episode each, before anything is timed
     placement = env.tune_placement(args.placement_draws)
+    roof_placement = roof_env.tune_placement(args.placement_draws) if roof_env is not env else None
     E, N, T = env.E, env.d.n_agents, env.d.budget + 1
     flying = sum(teams) if teams else E * N        # agents stepped per env step of this rank (mixed team sizes: the flying ones)
     env_actions = env.d.n_actions
@@ -275,18 +289,21 @@ def main():
     def one_step(t):
         if args.graphs:
             env.step_graphed(t)
+        elif split:
+            env.steps(t, policy=POLICY_UNIFORM)
         else:
             env.steps(t, policy=POLICY_UNIFORM, features=False)
 
     reset()
     if args.graphs:
         env.capture_step_graphs(POLICY_UNIFORM)
-    scratch = torch.empty_like(env.local)
+    scratch = torch.empty_like(first.local)
 
     def stream_copy():
-        env.ctx.call("ippm_stream_copy", env._p(env.local), _ffi.ptr(scratch), env.local.numel() * 4, env.stream)
+        first.ctx.call("ippm_stream_copy", first._p(first.local), _ffi.ptr(scratch), first.local.numel() * 4, first.stream)
 
     if args.calib:
+        torch.cuda.synchronize()     # (the sub-batches' resets run on their own streams: the marker copies must not fall among them)
         for _ in range(3):
             stream_copy()
         torch.cuda.synchronize()
@@ -347,27 +364,67 @@ def main():
         tt = torch.tensor([ss_dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         ss_dt = float(tt[0])
-    faults = int(env.fault.abs().sum())
+    faults = int(env.fault.abs().sum())        # (SplitVecEnv: joins its streams first)
     grid = [env.d.grid_x, env.d.grid_y]
 
     # Roofline leg: the same loop goes on for --roofline-steps more env steps (resets included) with kernel timing on -- every
     # launch of the timed classes carries a start/stop event pair bound to its own dispatch (kernel begin -> end, the figure
     # rocprofv3's kernel trace reports; no barrier packets, nothing to calibrate away) -- and with its own work counters, so
     # bytes and durations cover exactly the same launches whatever --steps was.
-    times, rl_counters, rl_resets = {}, None, 0
+    times, rl_counters, rl_resets, overlapped = {}, None, 0, None
     if args.roofline_steps > 0 and not args.graphs:
-        env.counters(reset=True)
-        env.profile = True
+        if split:
+            # With sub-batches on several streams a kernel's begin-to-end time in the loops above includes what the other streams'
+            # kernels took from it.  First a short stretch of that loop with the events on (`overlapped_us`: what a sub-batch's kernels
+            # take there; one stream's plan + fusion + K3 add up to the step); then the roofline leg proper: the WHOLE batch per launch
+            # on one stream (roof_env), every launch alone on the device -- the kernel's own rate, the figure rocprofv3 reports for
+            # the same launches (tools/loop_stats.py and tools/pmc_summary.py tell the stretches apart by the marker copies of --calib).
+            env.profile = True
+            for _ in range(2 * T):
+                one_step(t_in_ep)
+                t_in_ep += 1
+                if t_in_ep == T:
+                    reset()
+                    t_in_ep = 0
+            env.profile = False
+            ov = env.event_times_us()
+            overlapped = {k: {"avg_us": v["avg_us"], "launches": v["launches"]} for k, v in ov.items()}
+            torch.cuda.synchronize()
+        # the leg itself: whole episodes of the whole batch on ONE stream (roof_env is env itself with --streams 1)
+        t_leg = t_in_ep if roof_env is env else 0
+
+        def leg_reset():
+            roof_env.reset(episode_ids(1, wave[0], E, rank, world))
+            wave[0] += 1
+
+        if roof_env is not env:
+            leg_reset()
+            for t in range(T):     # untimed: first touch of its arena, one whole episode
+                roof_env.steps(t, policy=POLICY_UNIFORM, features=False)
+            leg_reset()
+            torch.cuda.synchronize()
+            if args.calib:       # marker for the profile tools: what follows, up to the yardstick copies, is the roofline leg
+                for _ in range(2):
+                    stream_copy()
+                torch.cuda.synchronize()
+        roof_env.counters(reset=True)
+        roof_env.profile = True
         for _ in range(args.roofline_steps):
-            one_step(t_in_ep)
-            t_in_ep += 1
-            if t_in_ep == T:
+            if roof_env is env:
+                one_step(t_leg)
+            else:
+                roof_env.steps(t_leg, policy=POLICY_UNIFORM, features=False)
+            t_leg += 1
+            if t_leg == T:
                 rl_resets += 1
-                reset()
-                t_in_ep = 0
-        env.profile = False
-        times = env.event_times_us()
-        rl_counters = env.counters()
+                if roof_env is env:
+                    reset()
+                else:
+                    leg_reset()
+                t_leg = 0
+        roof_env.profile = False
+        times = roof_env.event_times_us()
+        rl_counters = roof_env.counters()
     # second denominator: what a plain 16 B/lane device-to-device copy of the local maps reaches on this box
     stream_copy()
     ca, cb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -376,9 +433,10 @@ def main():
         stream_copy()
     cb.record()
     torch.cuda.synchronize()
-    copy_gbs = 3 * 2 * env.local.numel() * 4 / (ca.elapsed_time(cb) * 1e-3) / 1e9
+    copy_gbs = 3 * 2 * first.local.numel() * 4 / (ca.elapsed_time(cb) * 1e-3) / 1e9
     del scratch
-    pmc, pmc_path = newest_pmc_summary(E, N, grid[0])
+    launch_envs = roof_env.E if args.roofline_steps > 0 else first.E     # envs per kernel launch of the roofline leg
+    pmc, pmc_path = newest_pmc_summary(E, N, grid[0], launch_envs)
     pmc_ok = bool(pmc)
 
     TIMING = ("HIP start/stop events bound to each dispatch (hipExtLaunchKernelGGL): the kernel's own begin-to-end duration, as "
@@ -411,8 +469,14 @@ def main():
         cells = rl_counters["sense_cells"] / k3["launches"]
         roofline = roofline_entry("k_sense_update", "K3: sense + Bayes update of the footprint tiles", K3_BYTES_PER_CELL * cells, k3,
                                   {"algorithmic_bytes_per_cell": K3_BYTES_PER_CELL, "cells_per_launch": cells,
+                                   "launch_envs": launch_envs,
                                    "launches": f"the K3 launches of {args.roofline_steps} steps ({rl_resets} resets among them) right after "
-                                               "the timed region"})
+                                               "the timed region" + (f": the whole batch of {launch_envs} envs per launch on one stream, every launch alone "
+                                               f"on the device (a second VecEnv of the same config); the timed region steps {args.streams} sub-batches of "
+                                               f"{env.sizes[0]} envs on {args.streams} streams, whose kernels run side by side: overlapped_us = their "
+                                               "durations there, whole_step = what the device as a whole made of the HBM peak" if split else "")})
+        if overlapped:
+            roofline["overlapped_us"] = {k: round(v["avg_us"], 2) for k, v in overlapped.items() if k in ("sense", "fuse", "plan", "reset_maps", "terrain")}
         # every algorithmic byte of a step of the TIMED region (K3 + fusion; the small plan kernel's ~2.4 MB left out) against
         # the step's wall time: what the whole step, launch gaps and resets included, makes of the HBM peak
         step_bytes = (K3_BYTES_PER_CELL * counters["sense_cells"] + fusion_bytes(counters)) / args.steps
@@ -554,8 +618,9 @@ def main():
     # per-rank audit trail: each rank's own clock around the timed region and how its placement search ended, so that a multi-GPU
     # line can be checked rank by rank (value = the units all ranks processed / the slowest rank's time)
     mine = {"rank": rank, "device": torch.cuda.current_device(), "ms_per_step": 1e3 * dt_rank / args.steps,
-            "agent_env_steps_per_s": flying * args.steps / dt_rank, "placement_stopped": (placement or {}).get("stopped"),
-            "placement_draws": (placement or {}).get("draws")}
+            "agent_env_steps_per_s": flying * args.steps / dt_rank,
+            "placement_stopped": [(p or {}).get("stopped") for p in (placement if isinstance(placement, list) else [placement])],
+            "placement_draws": [(p or {}).get("draws") for p in (placement if isinstance(placement, list) else [placement])]}
     per_rank = [mine]
     if dist:
         per_rank = [None] * world
@@ -575,7 +640,8 @@ def main():
             "config": {"workload": ("BASELINE.json configs[1]: " if is_c1 else "NOT the metric's config (a parity-test shape): ") + shape,
                        "envs_per_gpu": E, "n_agents": N, "grid": grid,
                        "episode_steps": T, "terrain": args.terrain, "parallelism": f"env-sharded x{world} (no data-path collective)",
-                       "launches_per_step": 3, "hip_graphs": bool(args.graphs), "roofline_steps": args.roofline_steps,
+                       "streams": args.streams if split else 1, "envs_per_launch": env.sizes[0] if split else E,
+                       "launches_per_step": 3 * (args.streams if split else 1), "hip_graphs": bool(args.graphs), "roofline_steps": args.roofline_steps,
                        "terrain_prefetch": bool(args.terrain_prefetch and args.terrain == "random_field")},
             "ranks": world,
             "resets_timed": resets_timed,
@@ -592,7 +658,7 @@ def main():
             "cells": counters,
             "roofline": roofline,
             "roofline_kernels": roofline_kernels,
-            "placement": placement,
+            "placement": placement, "roofline_leg_placement": roof_placement,
             "coma_training": coma,
         }
     if dist:   # every collective is done: the other ranks may leave while rank 0 times the CPU baseline on the host cores

@@ -578,3 +578,114 @@ class VecEnv:
                 if tiles[e][i] is not None:
                     out[e, i] = self.d.pack_tile(rects[e, i], tiles[e][i])
         return torch.from_numpy(out).to(self.device)
+
+
+class SplitVecEnv:
+    """A batch of envs stepped as ``parts`` sub-batches, each a ``VecEnv`` on its own HIP stream (env-only stepping).
+
+    The envs of a batch share nothing, so any split of them computes the same episodes; what the split buys is overlap: an env step
+    is three launches -- a latency-bound plan kernel (a few hundred bytes per env, 15 us at config 2 with the device nearly idle),
+    then two bandwidth-bound map kernels -- and on ONE stream nothing else can run under the plan kernel.  With two half-batches on
+    two streams the plan kernel (and the reset's issue-bound terrain passes) of one half runs beside the map kernels of the other:
+    0.1526 -> 0.140-0.1425 ms per step of 1024 envs x 4 UAVs x 256^2 (26.8 -> 28.7-29.3 M agent-env steps/s, profiles/r05/
+    two_streams_probe.txt; three parts 0.1425-0.1446, four 0.1475: smaller launches cost more than the extra overlap gives).
+    Round 4 tried overlap INSIDE one batch's step -- the global fusion beside the local one, the next wave's terrain beside the
+    steps -- and lost: two bandwidth-bound launches only get in each other's way.  Here each stream's own sequence stays as it is.
+
+    Part k owns envs [k * E / parts, (k + 1) * E / parts) in the order of ``episodes`` / ``team_sizes``; streams are ordered against
+    the caller's current stream at the start of every call, and ``join()`` makes the current stream wait for all parts (call it
+    before reading state; ``torch.cuda.synchronize()`` also does).  Rollouts that feed a network step all envs at the same ``t``
+    through one actor batch and use ``VecEnv`` directly."""
+
+    def __init__(self, params: Dict, n_envs: int, parts: int = 2, device: str = "cuda:0", philox_seed: int = 3, terrain: str = "split",
+                 track_area: bool = False, team_sizes=None):
+        if parts < 1 or n_envs < parts:
+            raise ValueError("SplitVecEnv: 1 <= parts <= n_envs")
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        base, extra = divmod(int(n_envs), parts)
+        self.sizes = [base + (1 if k < extra else 0) for k in range(parts)]
+        self.offsets = [sum(self.sizes[:k]) for k in range(parts)]
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(parts)]
+        ts = None if team_sizes is None else [int(v) for v in team_sizes]
+        self.parts = []
+        for k, (n, off) in enumerate(zip(self.sizes, self.offsets)):
+            with torch.cuda.stream(self.streams[k]):
+                self.parts.append(VecEnv(params, n, device=device, philox_seed=philox_seed, terrain=terrain, track_area=track_area,
+                                         team_sizes=None if ts is None else ts[off:off + n]))
+        self.E = int(n_envs)
+        self.d = self.parts[0].d
+        self.params = params
+
+    # -- stream plumbing ------------------------------------------------------------------------------
+    def _each(self):
+        """(part, its slice of the batch) with the part's stream current and ordered behind the caller's stream."""
+        cur = torch.cuda.current_stream(self.device)
+        entered = torch.cuda.Event()
+        entered.record(cur)
+        for k, env in enumerate(self.parts):
+            self.streams[k].wait_event(entered)
+            with torch.cuda.stream(self.streams[k]):
+                yield env, slice(self.offsets[k], self.offsets[k] + self.sizes[k])
+
+    def join(self):
+        """The caller's current stream waits for everything queued on the parts' streams."""
+        cur = torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            done = torch.cuda.Event()
+            done.record(s)
+            cur.wait_event(done)
+
+    # -- the VecEnv surface the env-only loop uses -------------------------------------------------------
+    def reset(self, episodes, **kw):
+        ep = torch.as_tensor(episodes, dtype=torch.int64).reshape(self.E)
+        for env, sl in self._each():
+            env.reset(ep[sl], **{k: (v[sl] if v is not None and hasattr(v, "__getitem__") and not isinstance(v, str) else v) for k, v in kw.items()})
+
+    def steps(self, t: int, policy: int = POLICY_UNIFORM, actions: Optional[torch.Tensor] = None):
+        """One env step of every part (plan -> fusion -> K3 on its stream); nothing is returned: ``join()``, then read ``reward``."""
+        for env, sl in self._each():
+            env.steps(t, policy=policy, actions=None if actions is None else actions[sl], features=False)
+
+    def tune_placement(self, draws: int = 24):
+        return [env.tune_placement(draws) for env, _ in self._each()]
+
+    @property
+    def profile(self) -> bool:
+        return self.parts[0].profile
+
+    @profile.setter
+    def profile(self, on: bool):
+        for env in self.parts:
+            env.profile = on
+
+    def counters(self, reset: bool = False) -> dict:
+        total: Dict[str, int] = {}
+        for env, _ in self._each():
+            for k, v in env.counters(reset).items():
+                total[k] = total.get(k, 0) + v
+        return total
+
+    def event_times_us(self, clear: bool = True) -> Dict[str, Dict[str, float]]:
+        """Launch-weighted merge of the parts' dispatch-bound kernel times (a launch = one part's kernel)."""
+        out: Dict[str, Dict[str, float]] = {}
+        for env, _ in self._each():
+            for cls, rec in env.event_times_us(clear).items():
+                acc = out.setdefault(cls, {"launches": 0, "avg_us": 0.0, "min_us": rec["min_us"], "kernel": rec["kernel"]})
+                acc["avg_us"] = (acc["avg_us"] * acc["launches"] + rec["avg_us"] * rec["launches"]) / (acc["launches"] + rec["launches"])
+                acc["launches"] += rec["launches"]
+                acc["min_us"] = min(acc["min_us"], rec["min_us"])
+        return out
+
+    def _cat(self, name):
+        self.join()
+        return torch.cat([getattr(env, name) for env in self.parts], dim=0)
+
+    pos = property(lambda self: self._cat("pos"))
+    local = property(lambda self: self._cat("local"))
+    glob = property(lambda self: self._cat("glob"))
+    reward = property(lambda self: self._cat("reward"))
+    action = property(lambda self: self._cat("action"))
+    mask = property(lambda self: self._cat("mask"))
+    fault = property(lambda self: self._cat("fault"))
+    sums = property(lambda self: self._cat("sums"))

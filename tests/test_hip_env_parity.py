@@ -624,6 +624,32 @@ def test_work_list_form_follows_the_context():
         assert a.counters()["work_list_rejects"] == 0 and b.counters()["work_list_rejects"] == 0
 
 
+def test_split_batch_on_two_streams_equals_the_batch():
+    """SplitVecEnv: the batch stepped as sub-batches on their own HIP streams (bench.py's default: the plan kernel and the resets
+    of one half run beside the map kernels of the other) computes, bit for bit, what one VecEnv computes for the same episodes --
+    uneven split, mixed team sizes and a reset in the middle included."""
+    from ippmarl.vec_env import SplitVecEnv, POLICY_UNIFORM
+    params = make_params("small", experiment__uav__fix_range=False, experiment__uav__failure_rate=0.2)
+    teams = [4, 2, 3, 4, 1, 4, 2]
+    one = _env(params, 7, track_area=False, terrain="random_field", team_sizes=teams)
+    for parts in (2, 3):
+        split = SplitVecEnv(params, 7, parts=parts, terrain="random_field", team_sizes=teams)
+        assert split.sizes == ([4, 3] if parts == 2 else [3, 2, 2])
+        for wave in range(2):
+            eps = np.arange(5, 12) + 50 * wave
+            one.reset(eps)
+            split.reset(eps)
+            for t in range(one.d.budget + 1):
+                r1, _, _ = one.steps(t, policy=POLICY_UNIFORM, features=False)
+                split.steps(t, policy=POLICY_UNIFORM)
+                assert torch.equal(split.pos, one.pos) and torch.equal(split.action, one.action), (parts, wave, t)
+                assert torch.equal(split.reward, r1), (parts, wave, t)
+            assert torch.equal(split.local, one.local) and torch.equal(split.glob, one.glob), (parts, wave)
+        got, want = split.counters(), one.counters(reset=True)
+        assert got == want, (got, want)
+        assert int(split.fault.abs().sum()) == 0
+
+
 def test_fused_comm_and_plan_equals_separate_calls():
     """ippm_comm_fuse_local == ippm_comm_matrix + ippm_fuse_local (bitwise), incl. link failures and per-episode ranges."""
     from ippmarl.vec_env import POLICY_UNIFORM

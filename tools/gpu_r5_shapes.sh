@@ -14,19 +14,19 @@ shape() {   # name, E, N, G, bench args
   local name=$1 E=$2 N=$3 G=$4; shift 4
   local ARGS="$*"
   local LINE="python bench.py $ARGS --steps 30 --warmup 15 --no-cpu-baseline --train-rounds 0"
-  local SHORT="python bench.py $ARGS --steps 16 --warmup 16 --no-cpu-baseline --train-rounds 0 --roofline-steps 0 --placement-draws 1 --calib"
+  local SHORT="python bench.py $ARGS --steps 16 --warmup 16 --no-cpu-baseline --train-rounds 0 --roofline-steps 16 --placement-draws 1 --calib"
   echo "=== $name: $ARGS"
   if [ -z "$SQ_ONLY" ]; then
   timeout 600 $LINE > $OUT/bench_$name.json 2> $OUT/bench_$name.err
   python tools/bench_brief.py $OUT/bench_$name.json | grep -E "value|k_sense|k_fuse|k_plan|k_reset_maps|whole_step"
   timeout -k 10 $PT rocprofv3 --kernel-trace --output-format csv -d $OUT/${name}_trace_csv -o p -- $SHORT > /dev/null 2> $OUT/${name}_trace_csv.err
   python tools/loop_stats.py $(find $OUT/${name}_trace_csv -name "*kernel_trace.csv" | head -1) $OUT/kernel_stats_loop_$name.csv > $OUT/loop_stats_$name.txt 2>&1
-  head -12 $OUT/loop_stats_$name.txt
+  grep -A6 'roofline leg' $OUT/loop_stats_$name.txt | cut -c1-60,330-420
   timeout -k 10 $PT rocprofv3 --kernel-trace -d $OUT/${name}_trace -o p -- $SHORT > /dev/null 2> $OUT/${name}_trace.err
   timeout -k 10 $PT rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/${name}_fetch -o p -- $SHORT > /dev/null 2> $OUT/${name}_fetch.err
   timeout -k 10 $PT rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/${name}_write -o p -- $SHORT > /dev/null 2> $OUT/${name}_write.err
   python tools/pmc_summary.py $(find $OUT/${name}_fetch -name "*.db" | head -1) $(find $OUT/${name}_write -name "*.db" | head -1) \
-    $(find $OUT/${name}_trace -name "*.db" | head -1) $E $N $G $OUT/pmc_summary_$name.json > $OUT/pmc_summary_$name.log 2>&1
+    $(find $OUT/${name}_trace -name "*.db" | head -1) $E $N $G $OUT/pmc_summary_$name.json $E > $OUT/pmc_summary_$name.log 2>&1
   python - <<PY
 import json
 try:

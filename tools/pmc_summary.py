@@ -7,7 +7,10 @@ FETCH_SIZE under-reports wide coalesced reads by 2x.  Instead of assuming the fa
 with known traffic captured in the same run: k_stream_copy (ippm_stream_copy), which reads and writes exactly the local-map
 tensor with 16 B per lane.
 
-    python tools/pmc_summary.py <fetch.db> <write.db> <trace.db> <n_envs> <n_agents> <grid> [out.json]
+    python tools/pmc_summary.py <fetch.db> <write.db> <trace.db> <n_envs> <n_agents> <grid> [out.json [envs_per_launch]]
+
+envs_per_launch (default n_envs): bench.py --streams P steps the batch as P sub-batches, one launch per sub-batch and kernel; the
+calibration copy moves one sub-batch's local maps, and every per-launch figure below is a sub-batch's.
 """
 import json
 import sqlite3
@@ -16,18 +19,41 @@ import sys
 import pandas as pd
 
 
+def segment(names):
+    """(lo, hi) of the rows that belong to the measured stretch of a `bench.py --calib` process, given the kernel names in launch
+    order: behind the three marker copies in front of the loops and, when the process has one, behind the TWO marker copies in
+    front of the roofline leg (bench.py --streams P > 1: the loops before it step sub-batches side by side, the leg steps the whole
+    batch per launch) -- up to the next copy (the copy-rate yardstick)."""
+    is_copy = [("k_stream_copy" in n) for n in names]
+    n = len(names)
+    lo = next((i + 3 for i in range(n - 2) if is_copy[i] and is_copy[i + 1] and is_copy[i + 2]), None)
+    if lo is None:
+        return 0, n
+    hi = next((i for i in range(lo, n) if is_copy[i]), n)
+    if hi + 1 < n and is_copy[hi + 1] and not (hi + 2 < n and is_copy[hi + 2]):     # exactly two copies: the roofline leg follows
+        lo = hi + 2
+        hi = next((i for i in range(lo, n) if is_copy[i]), n)
+    return lo, hi
+
+
 def counters(path, counter):
     df = pd.read_sql("select kernel_name, dispatch_id, counter_name, value from counters_collection", sqlite3.connect(path))
     df = df[df["counter_name"] == counter]
-    per_dispatch = df.groupby(["dispatch_id", "kernel_name"])["value"].sum().reset_index()
-    return per_dispatch.groupby("kernel_name")["value"].agg(["mean", "count", "max"])
+    per_dispatch = df.groupby(["dispatch_id", "kernel_name"])["value"].sum().reset_index().sort_values("dispatch_id").reset_index(drop=True)
+    lo, hi = segment(list(per_dispatch["kernel_name"]))
+    copies = per_dispatch[per_dispatch["kernel_name"].str.contains("k_stream_copy")]
+    part = pd.concat([per_dispatch.iloc[lo:hi], copies])
+    return part.groupby("kernel_name")["value"].agg(["mean", "count", "max"])
 
 
 def durations(path):
     df = pd.read_sql("select * from kernels", sqlite3.connect(path))
     name = [c for c in df.columns if c in ("name", "kernel_name")][0]
+    df = df.sort_values("start").reset_index(drop=True)
     df["us"] = (df["end"] - df["start"]) / 1e3
-    return df.rename(columns={name: "kernel"})[["kernel", "us"]]
+    lo, hi = segment(list(df[name]))
+    part = pd.concat([df.iloc[lo:hi], df[df[name].str.contains("k_stream_copy")]])
+    return part.rename(columns={name: "kernel"})[["kernel", "us"]]
 
 
 def pick(df, pat):
@@ -39,12 +65,13 @@ def main():
     fetch_db, write_db, trace_db, n_envs, n_agents, grid = sys.argv[1:7]
     out_path = sys.argv[7] if len(sys.argv) > 7 else "pmc_summary.json"
     n_envs, n_agents, grid = int(n_envs), int(n_agents), int(grid)
-    copy_bytes = n_envs * n_agents * grid * grid * 4   # read once and written once by k_stream_copy
+    per_launch = int(sys.argv[8]) if len(sys.argv) > 8 else n_envs
+    copy_bytes = per_launch * n_agents * grid * grid * 4   # read once and written once by k_stream_copy
     fetch, write, trace = counters(fetch_db, "FETCH_SIZE"), counters(write_db, "WRITE_SIZE"), durations(trace_db)
     cal_f, cal_w = pick(fetch, "k_stream_copy"), pick(write, "k_stream_copy")
     f_scale = copy_bytes / (cal_f["mean"] * 1024.0)  # true bytes per reported KiB
     w_scale = copy_bytes / (cal_w["mean"] * 1024.0)
-    summary = {"envs_per_gpu": n_envs, "n_agents": n_agents, "grid": grid, "calibration": {
+    summary = {"envs_per_gpu": n_envs, "envs_per_launch": per_launch, "n_agents": n_agents, "grid": grid, "calibration": {
         "kernel": "k_stream_copy of the local maps (ippm_stream_copy, 16 B per lane)", "bytes_each_way": copy_bytes,
         "FETCH_SIZE_reported_KiB": float(cal_f["mean"]), "WRITE_SIZE_reported_KiB": float(cal_w["mean"]),
         "fetch_correction": f_scale, "write_correction": w_scale}}
