@@ -7,7 +7,7 @@ OUT=gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 PT=${PROF_TIMEOUT:-300}
 echo "=== config 2 profiles"; bash tools/gpu_profiles_r4.sh $TAG > $OUT/profiles.log 2>&1; tail -25 $OUT/profiles.log | cut -c1-220
-bash tools/gpu_pmc.sh ${TAG}_sq "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" > $OUT/pmc_sq_summary.txt 2>&1
+BENCH_ARGS="--streams 1" bash tools/gpu_pmc.sh ${TAG}_sq "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" > $OUT/pmc_sq_summary.txt 2>&1
 echo "=== configs 4 / 5 counters"; SHAPES="c4 c5" bash tools/gpu_r5_shapes.sh $TAG > $OUT/shapes.log 2>&1; grep -E "^===|pmc k_|value" $OUT/shapes.log | cut -c1-200
 mkdir -p profiles/r05; cp $OUT/pmc_summary.json $OUT/pmc_summary_c4.json $OUT/pmc_summary_c5.json profiles/r05/ 2>/dev/null   # (on the box: the lines below read their traffic there)
 echo "=== bench lines"
@@ -16,10 +16,16 @@ for k in 1 2 3; do
   echo "default run $k: $(python tools/bench_brief.py $OUT/bench_default_run_$k.json | grep -E "value|steady|k_sense|k_fuse_tiles|k_plan" | cut -c1-200 | tr '\n' ' ')"
 done
 timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_window.json 2>/dev/null
+timeout 600 python bench.py --streams 1 --no-cpu-baseline --train-rounds 0 > $OUT/bench_one_stream.json 2>/dev/null
+echo "one stream: $(python tools/bench_brief.py $OUT/bench_one_stream.json | grep -E "value|steady|k_sense|k_fuse_tiles|k_plan" | cut -c1-200 | tr '\n' ' ')"
+timeout 300 python tools/two_streams_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/two_streams_probe.txt; cat $OUT/two_streams_probe.txt
 echo "driver window: $(python tools/bench_brief.py $OUT/bench_driver_window.json | grep -E "value|steady|coma" | cut -c1-300 | tr '\n' ' ')"
 timeout 600 python bench.py --envs 1024 --agents 8 --grid 512 --steps 45 --warmup 15 --no-cpu-baseline --train-rounds 1 > $OUT/bench_config4_per_gpu_shape.json 2> $OUT/c4.err
 echo "c4: $(python tools/bench_brief.py $OUT/bench_config4_per_gpu_shape.json | grep -E "value|steady|k_sense|k_fuse_tiles|k_plan|coma" | cut -c1-250 | tr '\n' ' ')"
 timeout 900 python bench.py --envs 64 --agents 16 --grid 1024 --actions 27 --episode-comm-range --steps 45 --warmup 15 --no-cpu-baseline --train-rounds 0 > $OUT/bench_config5_shape.json 2> $OUT/c5.err
+timeout 900 python bench.py --envs 64 --agents 16 --grid 1024 --actions 27 --episode-comm-range --streams 3 --steps 45 --warmup 15 --no-cpu-baseline --train-rounds 0 > $OUT/bench_config5_shape_3streams.json 2>/dev/null
+timeout 900 python bench.py --envs 64 --agents 16 --grid 1024 --actions 27 --episode-comm-range --team-sizes 2,4,8,16 --steps 45 --warmup 15 --no-cpu-baseline --train-rounds 0 > $OUT/bench_config5_mixed_teams.json 2>/dev/null
+echo "c5 x3 streams: $(python tools/bench_brief.py $OUT/bench_config5_shape_3streams.json | grep -E "value" | cut -c1-120)  mixed teams: $(python tools/bench_brief.py $OUT/bench_config5_mixed_teams.json | grep -E "value" | cut -c1-120)"
 echo "c5: $(python tools/bench_brief.py $OUT/bench_config5_shape.json | grep -E "value|steady|k_sense|k_fuse_tiles|k_plan" | cut -c1-200 | tr '\n' ' ')"
 timeout 600 python bench.py --gpus 2 --dist-backend gloo --envs 256 --steps 30 --warmup 10 --train-rounds 1 --no-cpu-baseline > $OUT/bench_gpus2_selflaunched_gloo_one_gpu.json 2> $OUT/g2.err
 echo "gloo x2: $(python tools/bench_brief.py $OUT/bench_gpus2_selflaunched_gloo_one_gpu.json | grep -E "value|collective" | cut -c1-300)"

@@ -41,7 +41,8 @@ PY
   i=0
   for set in "$SQ1" "$SQ2"; do
     i=$((i+1))
-    timeout -k 10 $PT rocprofv3 --pmc $set --kernel-trace -d $OUT/${name}_sq$i -o p -- $SHORT > /dev/null 2> $OUT/${name}_sq$i.err
+    # (instruction / cycle counters per launch: one stream, the whole batch per launch, like the roofline leg)
+    timeout -k 10 $PT rocprofv3 --pmc $set --kernel-trace -d $OUT/${name}_sq$i -o p -- $SHORT --streams 1 --roofline-steps 0 > /dev/null 2> $OUT/${name}_sq$i.err
     python tools/pmc_db_summary.py $(find $OUT/${name}_sq$i -name "*.db" | head -1) >> $OUT/pmc_sq_$name.txt 2>&1
   done
   grep -E "counter_name|k_sense_tiles|k_fuse_tiles|k_plan_step|k_reset_maps" $OUT/pmc_sq_$name.txt | cut -c1-230
