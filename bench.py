@@ -436,8 +436,9 @@ def main():
     copy_gbs = 3 * 2 * first.local.numel() * 4 / (ca.elapsed_time(cb) * 1e-3) / 1e9
     del scratch
     launch_envs = roof_env.E if args.roofline_steps > 0 else first.E     # envs per kernel launch of the roofline leg
+    sub_envs = env.sizes[0] if split else E                              # envs per kernel launch of the timed loops
     pmc, pmc_path = newest_pmc_summary(E, N, grid[0], launch_envs)
-    pmc_ok = bool(pmc)
+    pmc_ok = bool(pmc) and not teams and args.comm_range is None     # (counter passes of this command at this shape and workload)
 
     TIMING = ("HIP start/stop events bound to each dispatch (hipExtLaunchKernelGGL): the kernel's own begin-to-end duration, as "
               "rocprofv3's kernel trace reports it; no bracket overhead to subtract, so frac_raw == frac")
@@ -473,7 +474,7 @@ def main():
                                    "launches": f"the K3 launches of {args.roofline_steps} steps ({rl_resets} resets among them) right after "
                                                "the timed region" + (f": the whole batch of {launch_envs} envs per launch on one stream, every launch alone "
                                                f"on the device (a second VecEnv of the same config); the timed region steps {args.streams} sub-batches of "
-                                               f"{env.sizes[0]} envs on {args.streams} streams, whose kernels run side by side: overlapped_us = their "
+                                               f"{sub_envs} envs on {args.streams} streams, whose kernels run side by side: overlapped_us = their "
                                                "durations there, whole_step = what the device as a whole made of the HBM peak" if split else "")})
         if overlapped:
             roofline["overlapped_us"] = {k: round(v["avg_us"], 2) for k, v in overlapped.items() if k in ("sense", "fuse", "plan", "reset_maps", "terrain")}
@@ -506,7 +507,7 @@ def main():
     if args.train_rounds > 0:
         # BASELINE configs[2]: full COMA actor + counterfactual critic training on the same env config
         from ippmarl.trainer import COMATrainer
-        env = None  # release the env-only state before the trainer allocates its own
+        env = roof_env = first = None  # release the env-only state before the trainer allocates its own
         torch.cuda.empty_cache()
         tr = COMATrainer(params, args.envs, device=device, philox_seed=3, rank=rank, world=world, terrain=args.terrain,
                          placement_draws=args.placement_draws, team_sizes=teams)
@@ -640,7 +641,7 @@ def main():
             "config": {"workload": ("BASELINE.json configs[1]: " if is_c1 else "NOT the metric's config (a parity-test shape): ") + shape,
                        "envs_per_gpu": E, "n_agents": N, "grid": grid,
                        "episode_steps": T, "terrain": args.terrain, "parallelism": f"env-sharded x{world} (no data-path collective)",
-                       "streams": args.streams if split else 1, "envs_per_launch": env.sizes[0] if split else E,
+                       "streams": args.streams if split else 1, "envs_per_launch": sub_envs,
                        "launches_per_step": 3 * (args.streams if split else 1), "hip_graphs": bool(args.graphs), "roofline_steps": args.roofline_steps,
                        "terrain_prefetch": bool(args.terrain_prefetch and args.terrain == "random_field")},
             "ranks": world,
