@@ -18,14 +18,18 @@ def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     t0 = time.time()
-    ties = 0
+    ties = mixed = 0
     for k in range(n_cases):
         name, over, n_envs, seed, ep0, n, A = random_case(rng)
         try:
             # every fourth case: the untracked kernels (tile-item fusion), half of those as steps() alone (bench.py's launch sequence)
             # (class-weight threshold ties are recognised by the comparison itself -- tests/conftest.py::assert_features_or_ties admits a
             #  whole-class-weight difference only where the oracle's deciding area average is within 32 ulp of 0.499 / 0.501 -- and counted)
-            ties += check(name, over, n_envs, seed=seed, first_episode=ep0, track_area=k % 4 != 1, fused_step=k % 8 == 5)
+            # every fifth case as a batch of MIXED team sizes (round 5): env e flies 1 .. N of the configured UAVs and is compared with an
+            # oracle run of that team size
+            teams = [rng.randint(1, n) for _ in range(n_envs)] if k % 5 == 2 else None
+            mixed += teams is not None
+            ties += check(name, over, n_envs, seed=seed, first_episode=ep0, track_area=k % 4 != 1, fused_step=k % 8 == 5, team_sizes=teams)
             # every third case also through the greedy planner (K9 + K10) -- not above 15 m: the reference's planner divides by the
             # sensor noise, which its sensor model sets to 0 there (ZeroDivisionError in IG_baseline.py, as in the oracle)
             if over.get("mapping__prior", 0.5) == 0.5 and k % 3 == 0 and over.get("experiment__constraints__max_altitude", 15) <= 15:
@@ -37,8 +41,8 @@ def main():
                 continue
             raise
         print(f"case {k}: {name} px={over.get('sensor__pixel__number_x', '-')} prior={over.get('mapping__prior', 0.5)} N={n} A={A} range={over['experiment__uav__communication_range']} fail={over['experiment__uav__failure_rate']} "
-              f"fix={over['experiment__uav__fix_range']} envs={n_envs} ok ({time.time() - t0:.0f}s)", flush=True)
-    print("all", n_cases, "cases match the oracle;", ties, "feature elements sat on a proven class-weight threshold tie")
+              f"fix={over['experiment__uav__fix_range']} envs={n_envs}{' teams=' + str(teams) if teams else ''} ok ({time.time() - t0:.0f}s)", flush=True)
+    print("all", n_cases, "cases match the oracle (", mixed, "of them batches of mixed team sizes );", ties, "feature elements sat on a proven class-weight threshold tie")
 
 
 if __name__ == "__main__":   # (the oracle pool spawns workers that re-import this module)
