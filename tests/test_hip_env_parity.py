@@ -210,7 +210,7 @@ def check_philox_episodes(name, over, n_envs, seed=0x1234567ABC, first_episode=1
     final = env.posterior_local().cpu().numpy()
     for e, (_, final_local, _) in enumerate(oracles):
         assert_posteriors(final[e, :teams[e]], final_local, strict=True, msg=f"final local e={e}")
-        assert (final[e, teams[e]:] == env.d.prior).all(), e       # the maps of agents that do not fly stay at the prior
+        assert np.allclose(final[e, teams[e]:], env.d.prior, rtol=1e-6, atol=0), e   # the maps of agents that do not fly stay at the prior
     assert env.counters()["work_list_rejects"] == 0
     return ties
 
