@@ -210,7 +210,8 @@ extern "C" int ippm_read_kernel_times(ippm_ctx* ctx, int32_t cls, int32_t reset,
     // "(k_fuse_rows<4, false, 6, false>)" as written at the launch site -> without the macro's parentheses
     std::string s = ctx->ev_name[cls] ? ctx->ev_name[cls] : "";
     if (s.size() >= 2 && s.front() == '(' && s.back() == ')') s = s.substr(1, s.size() - 2);
-    for (size_t at; (at = s.find(" >")) != std::string::npos;) s.erase(at, 1);   // (an empty variadic tail of the launch macro leaves "false >")
+    for (size_t at; (at = s.find(" >")) != std::string::npos;) s.erase(at, 1);   // (an empty variadic tail of the launch macro leaves "false >",
+    for (size_t at; (at = s.find(" ,")) != std::string::npos;) s.erase(at, 1);   //  a non-empty one "false , 2, 2>")
     std::strncpy(name, s.c_str(), (size_t)name_len - 1);
     name[name_len - 1] = 0;
   }
