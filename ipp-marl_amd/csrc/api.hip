@@ -109,6 +109,10 @@ extern "C" int ippm_ctx_create(const ippm_config* cfg, ippm_ctx** out) {
     const bool narrow = wmax <= 64;
     ctx->k3_wpg = knob("IPPM_K3_WPG", narrow ? 2 : 4);
     ctx->k3_chn = knob("IPPM_K3_CHN", narrow ? 2 : 3);
+    // ... and the order of its workgroups: with rows of up to 32 groups (256^2) consecutive workgroups take the agents of an env
+    // (a map's parts n workgroups apart): 33.94 - 34.04 -> 33.54 - 33.70 us in four alternating processes; 512^2 63.0 -> 63.5,
+    // 1024^2 91.3 -> 96.6: the parts of a footprint first there
+    ctx->k3_go = knob("IPPM_K3_GO", wmax <= 32 ? 1 : 0);
   }
   ctx->knob_k3_dense = knob("IPPM_K3_DENSE", 1);   // 0: the power-of-two lane layout of round 3 (A/B: tools/ab_knobs.py)
   ctx->tiles = (ctx->vec == 4 && c.logit_prior == 0.f && c.grid_x < 32768 && c.grid_y <= 1024 && !knob("IPPM_NO_TILES", 0)) ? 1 : 0;

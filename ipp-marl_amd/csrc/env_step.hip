@@ -303,6 +303,9 @@ typedef unsigned ippm_k3_u4 __attribute__((ext_vector_type(4)));
 #ifndef IPPM_K3_CH         // loads in flight per lane of k_sense_tiles (variant builds)
 #define IPPM_K3_CH 3
 #endif
+#ifndef IPPM_K3_GRID_ORDER // default workgroup order of k_sense_tiles (template parameter GO)
+#define IPPM_K3_GRID_ORDER 0
+#endif
 #ifndef IPPM_K3_LOAD_AUX   // cache policy of the map accesses (bit 1 = non-temporal on gfx950)
 #define IPPM_K3_LOAD_AUX 0
 #endif
@@ -317,7 +320,8 @@ typedef unsigned ippm_k3_u4 __attribute__((ext_vector_type(4)));
 // cell-by-cell tail stores nor the flips resource (the kernel sits at the SGPR limit: every uniform it holds less is a
 // v_writelane / v_readlane pair less in its instruction stream).
 // WPG x CH: wavefronts per workgroup and loads in flight per lane (the production shape is chosen per grid width, ippm_sense_step)
-template <int VEC, bool MIS, bool FLIPS, bool REC, bool DENSE, bool TRACK, int WPG = IPPM_K3_WAVES, int CHN = IPPM_K3_CH>
+// GO: the launch's fastest-varying workgroup index -- 0: a footprint's parts, 1: the agents of an env (a map's parts n workgroups apart)
+template <int VEC, bool MIS, bool FLIPS, bool REC, bool DENSE, bool TRACK, int WPG = IPPM_K3_WAVES, int CHN = IPPM_K3_CH, int GO = IPPM_K3_GRID_ORDER>
 __global__ void __launch_bounds__(64 * WPG)
 k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int stage, int rows_per_part, int gy, int gx,
               float* __restrict__ local, const uint8_t* __restrict__ truth, const int64_t* __restrict__ episode,
@@ -333,15 +337,11 @@ k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int sta
   // nothing else, and every config scalar the kernel uses is passed by value -- one scalar round trip, then the map loads.
   constexpr int CH = CHN;
   // grid = (row parts, agents, envs): no index arithmetic to undo
-#ifdef IPPM_K3_GRID_SWAP   // experiment: consecutive workgroups = the agents of an env, a map's parts n workgroups apart
-  const int part = blockIdx.y, e = blockIdx.z, i = agent_sel >= 0 ? agent_sel : (int)blockIdx.x;
-  const int tile = e * n + (int)blockIdx.x;
-  const int agent_blk = blockIdx.x;
-#else
-  const int part = blockIdx.x, e = blockIdx.z, i = agent_sel >= 0 ? agent_sel : (int)blockIdx.y;
-  const int tile = e * n + (int)blockIdx.y;
-  const int agent_blk = blockIdx.y;
-#endif
+  // (GO == 2, variant builds: the parts slowest -- all first parts, then all second parts, ...: 37 us at config 2 against 34)
+  const int part = GO == 1 ? blockIdx.y : (GO == 2 ? blockIdx.z : blockIdx.x), e = GO == 2 ? blockIdx.y : blockIdx.z;
+  const int agent_blk = GO == 0 ? blockIdx.y : blockIdx.x;
+  const int i = agent_sel >= 0 ? agent_sel : agent_blk;
+  const int tile = e * n + agent_blk;
   int r[4];
   float lm0, lm1;
   uint32_t thr;
@@ -864,11 +864,10 @@ extern "C" int ippm_sense_step(ippm_ctx* ctx, const int64_t* episode, const int3
       parts = need;
     }
     if (n_envs > 65535) { ippm_set_error("ippm_sense_step: more than 65535 envs per launch"); return -1; }
-#ifdef IPPM_K3_GRID_SWAP
-    dim3 grid((unsigned)(agent_sel >= 0 ? 1 : c.n_agents), (unsigned)parts, (unsigned)n_envs);
-#else
-    dim3 grid((unsigned)parts, (unsigned)(agent_sel >= 0 ? 1 : c.n_agents), (unsigned)n_envs);
-#endif
+    const unsigned g_agents = (unsigned)(agent_sel >= 0 ? 1 : c.n_agents);
+    const int go = shaped ? ctx->k3_go : IPPM_K3_GRID_ORDER;
+    dim3 grid = go == 1 ? dim3(g_agents, (unsigned)parts, (unsigned)n_envs)
+              : (go == 2 ? dim3(g_agents, (unsigned)n_envs, (unsigned)parts) : dim3((unsigned)parts, g_agents, (unsigned)n_envs));
     int32_t* rect_out = rect_in == rect ? nullptr : rect;
 #define IPPM_K3T___(V, M, F, R, D, T, ...)                                                                                       \
   IPPM_LAUNCH(ctx, IPPM_T_SENSE, (k_sense_tiles<V, M, F, R, D, T __VA_OPT__(,) __VA_ARGS__>), grid, block, S_(stream), rect_in, c.n_agents, agent_sel, stage, rows_per_part, \
@@ -877,9 +876,9 @@ extern "C" int ippm_sense_step(ippm_ctx* ctx, const int64_t* episode, const int3
 #define IPPM_K3T__(V, M, F, R, D) do { if (area) IPPM_K3T___(V, M, F, R, D, true); else IPPM_K3T___(V, M, F, R, D, false); } while (0)
 #define IPPM_K3T_(V, M, F, R) do { if (dense) IPPM_K3T__(V, M, F, R, true); else IPPM_K3T__(V, M, F, R, false); } while (0)
 #define IPPM_K3T(V, M, F) do { if (rect_in) IPPM_K3T_(V, M, F, true); else IPPM_K3T_(V, M, F, false); } while (0)
-    if (shaped && !(wpg == IPPM_K3_WAVES && chn == IPPM_K3_CH)) {   // the closing K3 of the env-only step in another workgroup shape
-#define IPPM_K3S(W_, C_) if (wpg == W_ && chn == C_) { IPPM_K3T___(4, false, false, true, true, false, W_, C_); IPPM_LAUNCH_CHECK("sense_tiles"); return 0; }
-      IPPM_K3S(1, 3) IPPM_K3S(2, 3) IPPM_K3S(2, 2) IPPM_K3S(1, 4) IPPM_K3S(2, 4) IPPM_K3S(4, 4) IPPM_K3S(4, 2)
+    if (shaped && !(wpg == IPPM_K3_WAVES && chn == IPPM_K3_CH && go == IPPM_K3_GRID_ORDER)) {   // the closing K3 of the env-only step in another workgroup shape / order
+#define IPPM_K3S(W_, C_, G_) if (wpg == W_ && chn == C_ && go == G_) { IPPM_K3T___(4, false, false, true, true, false, W_, C_, G_); IPPM_LAUNCH_CHECK("sense_tiles"); return 0; }
+      IPPM_K3S(2, 2, 1) IPPM_K3S(2, 2, 0) IPPM_K3S(1, 3, 0) IPPM_K3S(2, 3, 0) IPPM_K3S(1, 4, 0) IPPM_K3S(2, 4, 0) IPPM_K3S(4, 4, 0) IPPM_K3S(4, 2, 0) IPPM_K3S(4, 3, 1)
 #undef IPPM_K3S
       ippm_set_error("ippm_sense_step: no instantiation for this K3 shape (IPPM_K3_WPG x IPPM_K3_CHN)");
       return -1;
