@@ -7,13 +7,13 @@
 // The row walker (fuse.hip) gives every wavefront a run of rows of a plan's hull: per item a work-list entry, then the plan,
 // then the rows two at a time -- about ten dependent memory round trips with two 16-byte loads in flight per lane, and the
 // kernel runs at the speed of those chains (rounds x latency), not of the memory system.  Here the plan kernel
-// (step_small.hip, tile_build_map) hands out self-contained ITEMS: a block of rows of one (slab, column interval) of a plan,
-// at most 64 * slots lane-loads, with the mask of the ops that meet it.  A wavefront does an item in three trips, the first
-// and the last short:
+// (step_small.hip, tile_build_map) hands out self-contained ITEMS: a run of consecutive lane-loads of one (slab, column interval)
+// of a plan in row-major order, at most 64 * slots of them, with the mask of the ops that meet it.  A wavefront does an item in
+// three trips, the first and the last short:
 //   1. the item (16 bytes, scalar; the next item is requested while this one is worked on);
 //   2. the op records of the mask TOGETHER WITH every map cell of the item: the cells' addresses follow from the item alone
-//      -- lane-load t = slot * 64 + lane is row t / W, group t % W of the item, so the lanes are dense whatever the interval's
-//      width (a 90-cell footprint: 23 groups x 11 rows = 253 of 256 lane-loads);
+//      -- lane-load t = slot * 64 + lane is element start + t of the region's row-major order, (row (start + t) / W, group
+//      (start + t) % W), so every item but a region's last is full whatever the interval's width;
 //   3. the measurement-code bytes of every (slot, op), whose addresses need the op records (a small, cache-resident plane);
 // then the ordered clamp/add chain in registers and one store per slot.  Nothing is carried from item to item except the
 // wavefront's reward and counter sums, so register use is that of one item and the launch is many short independent chains.

@@ -94,7 +94,8 @@ void ippm_set_error(const std::string& msg);
 int ippm_fuse_wave_rows(const ippm_ctx* ctx, int n_envs);  // rows per work item (fuse.hip)
 int ippm_work_env_cap(const ippm_ctx* ctx, int n_envs);    // items an env's slice can hold
 // The tile form of the list (IPPM_STEP_TILES; fuse_tiles.hip): [E] counts tagged IPPM_WORK_TILED, then from word (E + 3) & ~3 on
-// [E][cap] items of 4 words {env, x0 | rows << 16, first group | groups << 16, op mask | map slot << 24}, cap = ippm_tile_env_cap().
+// [E][cap] items of 4 words {run's first group | lane-loads << 16, first row, region's first group | groups per row << 16,
+// op mask | map slot << 24}, cap = ippm_tile_env_cap().
 int ippm_tile_env_cap(const ippm_ctx* ctx);
 int ippm_launch_fuse_tiles(ippm_ctx* ctx, float* local, float* global, const uint8_t* code, int32_t* ws, double* sums, double* area,
                            const int32_t* work, int n_envs, hipStream_t st);   // fuse_tiles.hip (area != nullptr: area sums tracked)

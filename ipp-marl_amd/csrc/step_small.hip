@@ -231,12 +231,11 @@ __global__ void k_plan(const ippm_config* __restrict__ c, const int32_t* __restr
 //
 // The ops of a plan are rectangles.  Along x the set of ops covering a row changes only at rectangle edges (SLABS); inside a
 // slab the covered columns are the union of the active ops' column ranges, i.e. a few disjoint INTERVALS of 4-cell groups.
-// An item is a block of rows of one (slab, interval): at most 64 * slots lane-loads of 16 bytes (slots = 4, 2 or 1 loads in
-// flight per lane, by the number of ops that meet the interval), with the mask of exactly those ops.  Every cell of the union
-// belongs to exactly one item; gaps between side-by-side rectangles belong to none.
+// An item is a RUN of one (slab, interval)'s lane-loads in row-major order: at most 64 * slots lane-loads of 16 bytes (slots = 4 or 2
+// loads in flight per lane, by the number of ops that meet the interval), with the mask of exactly those ops.  Every cell of the
+// union belongs to exactly one item; gaps between side-by-side rectangles belong to none.
 // Wave-cooperative per map: lane l ranks edge l (rank sort + one ds_permute, as the row walker did per item), lane s then owns
-// slab s and merges the intervals of the ops sorted by their first column; a first pass counts the slabs' items (prefix sum
-// over lanes), a second writes them.
+// slab s and merges the intervals of the ops sorted by their first column; finished intervals go out as the walk proceeds.
 // ======================================================================================================
 __device__ __forceinline__ int tb_lane_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
