@@ -173,9 +173,11 @@ def main():
     ap.add_argument("--actions", type=int, default=None, choices=[4, 6, 9, 27], help="action set (default: params.yaml's 6)")
     ap.add_argument("--episode-comm-range", action="store_true", help="per-episode comm range from {0, 15, 25, 100} m "
                     "(experiment.uav.fix_range: False, BASELINE config 5's comm-range masking)")
-    ap.add_argument("--streams", type=int, default=2, help="step the batch as this many sub-batches, each on its own HIP stream "
+    ap.add_argument("--streams", type=int, default=0, help="step the batch as this many sub-batches, each on its own HIP stream "
                     "(ippmarl.vec_env.SplitVecEnv): the latency-bound plan kernel and the reset of one runs beside the bandwidth-bound map "
-                    "kernels of the other -- 0.1526 -> 0.141 ms per step at config 2; 1 = one stream, one launch per kernel and step")
+                    "kernels of the other -- 0.1526 -> 0.141 ms per step at config 2; 1 = one stream, one launch per kernel and step; "
+                    "0 (default) = 2, or 3 where the envs' work differs many-fold (--episode-comm-range, --team-sizes: a launch's tail is "
+                    "its few heavy envs, and a third stream fills it: 1.01 -> 1.38-1.43 M agent-env steps/s at config 5's shape)")
     ap.add_argument("--team-sizes", default=None, help="comma-separated team sizes dealt out to the envs in turn (BASELINE config 5's mixed teams, "
                     "e.g. 2,4,8,16 with --agents 16): env e flies team_sizes[e %% len] of the --agents UAVs; agent-env steps count the flying ones")
     ap.add_argument("--comm-range", type=float, default=None, help="experiment.uav.communication_range in metres (default: params.yaml's 25)")
@@ -206,6 +208,8 @@ def main():
     ap.add_argument("--calib", action="store_true", help="PMC calibration: 3 device-to-device copies of the local maps (known "
                     "bytes read and written by a 16 B/lane streaming kernel) before the timed loop")
     args = ap.parse_args()
+    if args.streams <= 0:
+        args.streams = 3 if (args.episode_comm_range or args.team_sizes) else 2
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus, args.ipc_legacy, args.ipc_retry))   # not under a launcher: start the ranks ourselves and relay rank 0's line

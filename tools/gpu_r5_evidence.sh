@@ -23,9 +23,9 @@ echo "driver window: $(python tools/bench_brief.py $OUT/bench_driver_window.json
 timeout 600 python bench.py --envs 1024 --agents 8 --grid 512 --steps 45 --warmup 15 --no-cpu-baseline --train-rounds 1 > $OUT/bench_config4_per_gpu_shape.json 2> $OUT/c4.err
 echo "c4: $(python tools/bench_brief.py $OUT/bench_config4_per_gpu_shape.json | grep -E "value|steady|k_sense|k_fuse_tiles|k_plan|coma" | cut -c1-250 | tr '\n' ' ')"
 timeout 900 python bench.py --envs 64 --agents 16 --grid 1024 --actions 27 --episode-comm-range --steps 45 --warmup 15 --no-cpu-baseline --train-rounds 0 > $OUT/bench_config5_shape.json 2> $OUT/c5.err
-timeout 900 python bench.py --envs 64 --agents 16 --grid 1024 --actions 27 --episode-comm-range --streams 3 --steps 45 --warmup 15 --no-cpu-baseline --train-rounds 0 > $OUT/bench_config5_shape_3streams.json 2>/dev/null
+timeout 900 python bench.py --envs 64 --agents 16 --grid 1024 --actions 27 --episode-comm-range --streams 2 --steps 45 --warmup 15 --no-cpu-baseline --train-rounds 0 > $OUT/bench_config5_shape_2streams.json 2>/dev/null
 timeout 900 python bench.py --envs 64 --agents 16 --grid 1024 --actions 27 --episode-comm-range --team-sizes 2,4,8,16 --steps 45 --warmup 15 --no-cpu-baseline --train-rounds 0 > $OUT/bench_config5_mixed_teams.json 2>/dev/null
-echo "c5 x3 streams: $(python tools/bench_brief.py $OUT/bench_config5_shape_3streams.json | grep -E "value" | cut -c1-120)  mixed teams: $(python tools/bench_brief.py $OUT/bench_config5_mixed_teams.json | grep -E "value" | cut -c1-120)"
+echo "c5 x2 streams: $(python tools/bench_brief.py $OUT/bench_config5_shape_2streams.json | grep -E "value" | cut -c1-120)  mixed teams: $(python tools/bench_brief.py $OUT/bench_config5_mixed_teams.json | grep -E "value" | cut -c1-120)"
 echo "c5: $(python tools/bench_brief.py $OUT/bench_config5_shape.json | grep -E "value|steady|k_sense|k_fuse_tiles|k_plan" | cut -c1-200 | tr '\n' ' ')"
 timeout 600 python bench.py --gpus 2 --dist-backend gloo --envs 256 --steps 30 --warmup 10 --train-rounds 1 --no-cpu-baseline > $OUT/bench_gpus2_selflaunched_gloo_one_gpu.json 2> $OUT/g2.err
 echo "gloo x2: $(python tools/bench_brief.py $OUT/bench_gpus2_selflaunched_gloo_one_gpu.json | grep -E "value|collective" | cut -c1-300)"
