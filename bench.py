@@ -6,10 +6,12 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus 8 --steps 150 --warmup 30           # the same, under an external launcher
 
-A "step" is one environment step of ALL envs on a rank, three launches: comm matrix + fusion plans + mask/act/move with a
-uniform random valid policy (K1) -> local fusion (K4) and global fusion + reward terms (K5) -> sense + Bayes update at the
+A "step" is one environment step of ALL envs on a rank, three launches per sub-batch: comm matrix + fusion plans + mask/act/move
+with a uniform random valid policy (K1) -> local fusion (K4) and global fusion + reward terms (K5) -> sense + Bayes update at the
 new positions (K3, which also completes the reward); every 15 steps the envs are reset to fresh episodes inside the timed
-region (device-side MT19937 + Philox, terrain synthesis included).
+region (device-side MT19937 + Philox, terrain synthesis included).  The batch is stepped as --streams sub-batches, each on its own
+HIP stream (default 2: the latency-bound plan kernel and the reset of one half run beside the bandwidth-bound map kernels of the
+other; same episodes, bit for bit); the roofline leg then measures every kernel with the whole batch per launch, alone on the device.
 Default workload = BASELINE.json configs[1]: 4 UAVs, 256 x 256 grid, 1024 batched envs per GPU, random policy.
 Inputs are synthetic and resident in HBM (truth fields generated on the device).  Envs are independent, so N GPUs
 shard envs with no data-path collective ("weak" scaling: 1024 envs per GPU).
