@@ -36,7 +36,9 @@ def main():
                 check_ig(name, over, seed=seed & 0xFFFFFFFF, first_episode=ep0, n_envs=n_envs)
         except Exception as exc:
             msg = str(exc)
-            if "footprint image smaller than 11 cells" in msg:   # a documented restriction: footprint images are only ever shrunk to 11 x 11
+            # (an agent boxed in by the others: the reference's torch.multinomial raises on the all-zero mask, the oracle with it; the
+            #  device sets fault[e] -- tests/test_hip_env_parity.py::test_empty_mask_sets_fault_flag)
+            if "footprint image smaller than 11 cells" in msg or "empty action mask" in msg:   # documented restrictions
                 print(f"case {k}: skipped ({exc})", flush=True)
                 continue
             raise
