@@ -338,6 +338,9 @@ k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int sta
   constexpr int CH = CHN;
   // grid = (row parts, agents, envs): no index arithmetic to undo
   // (GO == 2, variant builds: the parts slowest -- all first parts, then all second parts, ...: 37 us at config 2 against 34)
+  // (GO == 3, round 5, removed: every workgroup of an env on ONE XCD -- x = (env % 8) + 8 * agent, y = part, z = env / 8, so that the
+  //  parts of a footprint share one L2's truth and code-tile lines, on the XCD the fusion's wavefronts of that env run on: 36.2 us
+  //  against 34.7 at 256^2, 68.5 / 62.8 at 512^2, 110 / 94 at 1024^2 -- spreading a footprint over the XCDs is what it wants)
   const int part = GO == 1 ? blockIdx.y : (GO == 2 ? blockIdx.z : blockIdx.x), e = GO == 2 ? blockIdx.y : blockIdx.z;
   const int agent_blk = GO == 0 ? blockIdx.y : blockIdx.x;
   const int i = agent_sel >= 0 ? agent_sel : agent_blk;
