@@ -389,13 +389,21 @@ __device__ __forceinline__ void tile_item_long(const TileCtx& w, TileAcc& acc, i
 #endif
 template <bool MIS, bool TRACK>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(!MIS && !TRACK ? 6 : (TRACK ? 4 : IPPM_TILE_WAVES_PER_EU), 8)))
-k_fuse_tiles(const int32_t* __restrict__ work, int n_envs, int env_cap, int n, int gx, int gy, int row_bytes, int TB, float lc, float wt,
+k_fuse_tiles(const int32_t* __restrict__ work, int n_envs, int env_cap, int rot, int n, int gx, int gy, int row_bytes, int TB, float lc, float wt,
              const int32_t* __restrict__ plan_ro, float* __restrict__ local, float* __restrict__ global,
              const uint8_t* __restrict__ code, int32_t* __restrict__ ws, double* __restrict__ sums,
              unsigned long long* __restrict__ counters, double* __restrict__ area) {
   // (argument order = latency order, as in k_sense_tiles: the work list's address and sizes arrive in SGPRs with the wavefront,
   // every config scalar by value -- the count and the first item are one scalar round trip away, the first item's cells two)
-  const int env = blockIdx.x, first = blockIdx.y, step = gridDim.y;   // consecutive workgroups = consecutive envs
+  // Consecutive workgroups = consecutive envs, and the hardware deals consecutive workgroups out to the eight XCDs in turn: with a
+  // batch that is a multiple of 8 envs, wavefront `first` of env e would run on XCD e % 8 for EVERY first -- each env's whole list
+  // on one eighth of the chip.  Harmless while the lists are alike; with per-episode comm ranges or mixed team sizes (config 5)
+  // the lists differ fifty-fold and the launch waits for the XCD that drew the long ones (teams dealt out 2, 4, 8, 16 by e % 4:
+  // every 16-UAV env on XCDs 3 and 7).  `rot`: wavefront `first` of an env sits (first % 8) places further on, so an env's
+  // wavefronts visit all eight XCDs.
+  const int first = blockIdx.y, step = gridDim.y;
+  int env = blockIdx.x + (rot ? (first & 7) : 0);
+  env -= env >= n_envs ? n_envs : 0;
   const int4* __restrict__ items = reinterpret_cast<const int4*>(work + ((n_envs + 3) & ~3)) + (size_t)env * env_cap;
   // count and first item are requested together (the item's address does not depend on the count)
   int tag = work[env];
@@ -482,9 +490,10 @@ int ippm_launch_fuse_tiles(ippm_ctx* ctx, float* local, float* global, const uin
   // Per-episode comm ranges (experiment.uav.fix_range: False, config 5): an env that hears nobody fuses its global map only, one
   // whose range is 100 m fuses sixteen local maps as well -- 484 .. 21 611 items per env at 64 envs x 16 UAVs x 1024^2.  There the
   // wavefronts are dealt out in proportion to the lists (eight items each), from a grid tall enough for the longest.
+  const int rot = (n_envs >= 8 && ctx->knob_tile_rotate) ? 1 : 0;
   dim3 grid((unsigned)n_envs, (unsigned)per_env), block(64);
 #define IPPM_FT_(M, T) \
-  IPPM_LAUNCH(ctx, IPPM_T_FUSE, (k_fuse_tiles<M, T>), grid, block, st, work, n_envs, env_cap, c.n_agents, c.grid_x, c.grid_y, c.tile_stride >> 2, \
+  IPPM_LAUNCH(ctx, IPPM_T_FUSE, (k_fuse_tiles<M, T>), grid, block, st, work, n_envs, env_cap, rot, c.n_agents, c.grid_x, c.grid_y, c.tile_stride >> 2, \
               (int)ippm_tile_bytes(c.tile_stride, 4), c.logit_clip, c.logit_weight_thr, ws, local, global, code, ws, sums, ctx->dcounters, area)
 #define IPPM_FT(M) do { if (area) IPPM_FT_(M, true); else IPPM_FT_(M, false); } while (0)
   // rows only 4-byte aligned (grid_y not a multiple of 4): the instantiation with the cell-by-cell row-tail stores

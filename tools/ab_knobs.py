@@ -25,18 +25,21 @@ def main():
     ap.add_argument("--grid", type=int, default=256)
     ap.add_argument("--actions", type=int, default=None)
     ap.add_argument("--episode-comm-range", action="store_true")
+    ap.add_argument("--team-sizes", default=None, help="e.g. 2,4,8,16: env e flies team_sizes[e % len] of the --agents UAVs")
     ap.add_argument("--tracked", action="store_true", help="the training sequence: area sums tracked, two plan launches per step")
     ap.add_argument("--draws", type=int, default=8, help="placement search on the first env before the comparison")
     ap.add_argument("settings", nargs="+")
     a = ap.parse_args()
     a.terrain = "random_field"
+    pattern = [int(v) for v in a.team_sizes.split(",")] if a.team_sizes else None
+    teams = [pattern[e % len(pattern)] for e in range(a.envs)] if pattern else None
     envs = []
     for setting in a.settings:
         pairs = [kv.split("=", 1) for kv in setting.split()]
         saved = {k: os.environ.get(k) for k, _ in pairs}
         for k, v in pairs:
             os.environ[k] = v
-        envs.append(VecEnv(bench_params(a), a.envs, philox_seed=3, terrain="random_field", track_area=a.tracked))
+        envs.append(VecEnv(bench_params(a), a.envs, philox_seed=3, terrain="random_field", track_area=a.tracked, team_sizes=teams))
         for k, v in saved.items():
             if v is None:
                 os.environ.pop(k, None)
