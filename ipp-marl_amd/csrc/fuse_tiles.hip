@@ -395,12 +395,13 @@ k_fuse_tiles(const int32_t* __restrict__ work, int n_envs, int env_cap, int rot,
              unsigned long long* __restrict__ counters, double* __restrict__ area) {
   // (argument order = latency order, as in k_sense_tiles: the work list's address and sizes arrive in SGPRs with the wavefront,
   // every config scalar by value -- the count and the first item are one scalar round trip away, the first item's cells two)
-  // Consecutive workgroups = consecutive envs, and the hardware deals consecutive workgroups out to the eight XCDs in turn: with a
-  // batch that is a multiple of 8 envs, wavefront `first` of env e would run on XCD e % 8 for EVERY first -- each env's whole list
-  // on one eighth of the chip.  Harmless while the lists are alike; with per-episode comm ranges or mixed team sizes (config 5)
-  // the lists differ fifty-fold and the launch waits for the XCD that drew the long ones (teams dealt out 2, 4, 8, 16 by e % 4:
-  // every 16-UAV env on XCDs 3 and 7).  `rot`: wavefront `first` of an env sits (first % 8) places further on, so an env's
-  // wavefronts visit all eight XCDs.
+  // Consecutive workgroups = consecutive envs, and the hardware deals consecutive workgroups out to the eight XCDs in turn:
+  // wavefront `first` of env e is workgroup e + n_envs * first and runs on XCD (e + (n_envs % 8) * first) % 8.  With an odd batch
+  // an env's wavefronts visit all eight XCDs; with a multiple of 8 envs every one of them runs on XCD e % 8 -- each env's whole
+  // list on one eighth of the chip.  Harmless while the lists are alike; with per-episode comm ranges or mixed team sizes
+  // (config 5) the lists differ fifty-fold and the launch waits for the XCD that drew the long ones (teams dealt out 2, 4, 8, 16
+  // by e % 4: every 16-UAV env on XCDs 3 and 7).  `rot` (set for even batches): wavefront `first` of an env sits (first % 8)
+  // places further on in its row of workgroups, XCD (e + (n_envs % 8 - 1) * first) % 8 -- an odd coefficient again.
   const int first = blockIdx.y, step = gridDim.y;
   int env = blockIdx.x + (rot ? (first & 7) : 0);
   env -= env >= n_envs ? n_envs : 0;
@@ -490,7 +491,7 @@ int ippm_launch_fuse_tiles(ippm_ctx* ctx, float* local, float* global, const uin
   // Per-episode comm ranges (experiment.uav.fix_range: False, config 5): an env that hears nobody fuses its global map only, one
   // whose range is 100 m fuses sixteen local maps as well -- 484 .. 21 611 items per env at 64 envs x 16 UAVs x 1024^2.  There the
   // wavefronts are dealt out in proportion to the lists (eight items each), from a grid tall enough for the longest.
-  const int rot = (n_envs >= 8 && ctx->knob_tile_rotate) ? 1 : 0;
+  const int rot = (n_envs >= 8 && n_envs % 2 == 0 && ctx->knob_tile_rotate) ? 1 : 0;   // (odd batches spread by themselves)
   dim3 grid((unsigned)n_envs, (unsigned)per_env), block(64);
 #define IPPM_FT_(M, T) \
   IPPM_LAUNCH(ctx, IPPM_T_FUSE, (k_fuse_tiles<M, T>), grid, block, st, work, n_envs, env_cap, rot, c.n_agents, c.grid_x, c.grid_y, c.tile_stride >> 2, \

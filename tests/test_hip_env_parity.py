@@ -650,6 +650,42 @@ def test_split_batch_on_two_streams_equals_the_batch():
         assert int(split.fault.abs().sum()) == 0
 
 
+def test_tile_fusion_xcd_rotation_changes_nothing():
+    """The tile fusion deals an env's wavefronts out over the eight XCDs by rotating the env index with the wavefront index when the
+    batch is even and at least 8 envs (fuse_tiles.hip); odd or smaller batches launch unrotated.  Which wavefront does which item
+    must not show: a batch of 16 envs (rotated) against the same episodes as sub-batches of 6 + 5 + 5 (unrotated), and against
+    IPPM_TILE_ROTATE=0, bit for bit -- maps, rewards, work counters."""
+    from ippmarl.vec_env import SplitVecEnv, POLICY_UNIFORM
+    params = make_params("small", experiment__uav__fix_range=False, experiment__uav__failure_rate=0.1, experiment__missions__n_agents=5)
+    teams = [5, 2, 3, 5, 1, 4, 5, 5] * 2
+    one = _env(params, 16, track_area=False, terrain="random_field", team_sizes=teams)
+    split = SplitVecEnv(params, 16, parts=3, terrain="random_field", team_sizes=teams)
+    assert split.sizes == [6, 5, 5]
+    saved = os.environ.get("IPPM_TILE_ROTATE")
+    os.environ["IPPM_TILE_ROTATE"] = "0"      # (read at ippm_ctx_create)
+    try:
+        plain = _env(params, 16, track_area=False, terrain="random_field", team_sizes=teams)
+    finally:
+        if saved is None:
+            os.environ.pop("IPPM_TILE_ROTATE", None)
+        else:
+            os.environ["IPPM_TILE_ROTATE"] = saved
+    eps = np.arange(21, 37)
+    for env in (one, split, plain):
+        env.reset(eps)
+    for t in range(one.d.budget + 1):
+        r1, _, _ = one.steps(t, policy=POLICY_UNIFORM, features=False)
+        split.steps(t, policy=POLICY_UNIFORM)
+        r3, _, _ = plain.steps(t, policy=POLICY_UNIFORM, features=False)
+        assert torch.equal(split.pos, one.pos) and torch.equal(plain.pos, one.pos), t
+        assert torch.equal(split.reward, r1) and torch.equal(r3, r1), t
+    assert torch.equal(split.local, one.local) and torch.equal(split.glob, one.glob)
+    assert torch.equal(plain.local, one.local) and torch.equal(plain.glob, one.glob)
+    want = one.counters(reset=True)
+    assert split.counters() == want and plain.counters(reset=True) == want
+    assert want["fuse_local_cells"] > 0 and want["work_list_rejects"] == 0
+
+
 def test_fused_comm_and_plan_equals_separate_calls():
     """ippm_comm_fuse_local == ippm_comm_matrix + ippm_fuse_local (bitwise), incl. link failures and per-episode ranges."""
     from ippmarl.vec_env import POLICY_UNIFORM
