@@ -39,7 +39,8 @@ except Exception as e:
 PY
   fi
   i=0
-  for set in "$SQ1" "$SQ2"; do
+  for set in ${NO_SQ:+} $( [ -z "$NO_SQ" ] && echo SQ1 SQ2 ); do
+    set=$( [ "$set" = SQ1 ] && echo "$SQ1" || echo "$SQ2" )
     i=$((i+1))
     # (instruction / cycle counters per launch: one stream, the whole batch per launch, like the roofline leg)
     timeout -k 10 $PT rocprofv3 --pmc $set --kernel-trace -d $OUT/${name}_sq$i -o p -- $SHORT --streams 1 --roofline-steps 0 > /dev/null 2> $OUT/${name}_sq$i.err
