@@ -97,7 +97,7 @@ extern "C" int ippm_ctx_create(const ippm_config* cfg, ippm_ctx** out) {
   ctx->knob_nowork = knob("IPPM_FUSE_NOWORK", 0);
   ctx->knob_split = knob("IPPM_FUSE_SPLIT", 0);
   ctx->knob_tile_waves = knob("IPPM_TILE_WAVES", 0);
-  ctx->knob_tile_rotate = knob("IPPM_TILE_ROTATE", 1);
+  ctx->knob_tile_rotate = knob("IPPM_TILE_ROTATE", -1);   // -1: by the launch (fuse_tiles.hip); 0: off; k: groups of 2^(k-1) wavefronts
   ctx->knob_plan_builders = knob("IPPM_PLAN_BUILDERS", 0);
   // Workgroup shape of the env-only step's K3 (wavefronts per workgroup x loads in flight per lane), by the width of the widest
   // footprint row in 4-cell groups.  Measured on one allocation per grid, alternating episodes (tools/ab_knobs.py,

@@ -401,9 +401,10 @@ k_fuse_tiles(const int32_t* __restrict__ work, int n_envs, int env_cap, int rot,
   // list on one eighth of the chip.  Harmless while the lists are alike; with per-episode comm ranges or mixed team sizes
   // (config 5) the lists differ fifty-fold and the launch waits for the XCD that drew the long ones (teams dealt out 2, 4, 8, 16
   // by e % 4: every 16-UAV env on XCDs 3 and 7).  `rot` (set for even batches): wavefront `first` of an env sits (first % 8)
-  // places further on in its row of workgroups, XCD (e + (n_envs % 8 - 1) * first) % 8 -- an odd coefficient again.
+  // places further on in its row of workgroups, XCD (e + (n_envs % 8 - 1) * first) % 8 -- an odd coefficient again.  (rot > 1: 2^(rot-1)
+  // consecutive wavefronts stay on one XCD -- ((first >> (rot - 1)) % 8) places further on: neighbouring items share lines.)
   const int first = blockIdx.y, step = gridDim.y;
-  int env = blockIdx.x + (rot ? (first & 7) : 0);
+  int env = blockIdx.x + (rot ? ((first >> (rot - 1)) & 7) : 0);   // (rot - 1: consecutive wavefronts per XCD, as a power of two)
   env -= env >= n_envs ? n_envs : 0;
   const int4* __restrict__ items = reinterpret_cast<const int4*>(work + ((n_envs + 3) & ~3)) + (size_t)env * env_cap;
   // count and first item are requested together (the item's address does not depend on the count)
@@ -481,17 +482,22 @@ int ippm_launch_fuse_tiles(ippm_ctx* ctx, float* local, float* global, const uin
   // in length (484 .. 21 611 items at 64 envs x 16 UAVs x 1024^2) and the wavefronts of a long list are the launch's tail --
   // 256 / 1024 / 2048 per env: 962 / 853 / 850 us there; a wavefront whose env has nothing left for it costs a scalar load.
   // (Dealing the wavefronts out in proportion to the lists -- ceil(count / 8 .. 64) per env from a taller grid -- was 6 - 15 % SLOWER
-  // than 1024 for everybody: the launch is throughput-bound at ~600 items per microsecond, like configs 2 and 4, not held up by
-  // its longest chains; profiles/r05/c5_wave_distribution.txt)
+  // than 1024 for everybody -- measured while each env's list still ran on one XCD (see `rot` below), which is what held those
+  // launches up, not their longest chains; profiles/r05/c5_wave_distribution.txt)
   const double est_items = 0.5 * (c.n_agents + 1) * (double)c.grid_x * c.grid_y / 3.0 / (256.0 * ippm_tile_slots(max_ops));
   int per_env = ctx->knob_tile_waves > 0 ? ctx->knob_tile_waves : (int)std::max(4.0, std::min(1024.0, est_items / 3.0));
   per_env = std::max(1, std::min(per_env, env_cap));
   // a launch smaller than the chip's wave slots leaves CUs idle: small batches take more wavefronts per env
   while ((long long)per_env * n_envs < 16384 && per_env * 2 <= env_cap && per_env < 256) per_env *= 2;
-  // Per-episode comm ranges (experiment.uav.fix_range: False, config 5): an env that hears nobody fuses its global map only, one
-  // whose range is 100 m fuses sixteen local maps as well -- 484 .. 21 611 items per env at 64 envs x 16 UAVs x 1024^2.  There the
-  // wavefronts are dealt out in proportion to the lists (eight items each), from a grid tall enough for the longest.
-  const int rot = (n_envs >= 8 && n_envs % 2 == 0 && ctx->knob_tile_rotate) ? 1 : 0;   // (odd batches spread by themselves)
+  // rot - 1 = log2 of the consecutive wavefronts of an env that share an XCD: neighbouring items share code-tile lines and the
+  // line at the seam of their runs, so four in a row on one L2 are 1 - 1.5 % faster than one (profiles/r05/tile_rotate_group_ab.txt)
+  // -- as long as an env's wavefronts still go round all eight XCDs.  Odd batches spread by themselves.
+  int rot = 0;
+  if (n_envs >= 8 && n_envs % 2 == 0 && ctx->knob_tile_rotate != 0) {
+    rot = 1;
+    while (rot < 3 && (per_env >> rot) >= 8) ++rot;
+    if (ctx->knob_tile_rotate > 0) rot = std::min(ctx->knob_tile_rotate, 6);
+  }
   dim3 grid((unsigned)n_envs, (unsigned)per_env), block(64);
 #define IPPM_FT_(M, T) \
   IPPM_LAUNCH(ctx, IPPM_T_FUSE, (k_fuse_tiles<M, T>), grid, block, st, work, n_envs, env_cap, rot, c.n_agents, c.grid_x, c.grid_y, c.tile_stride >> 2, \
