@@ -2,7 +2,7 @@
 tests/test_hip_env_parity.py::test_random_configurations_match_oracle for a fixed dozen)."""
 
 
-def random_case(rng, pixels=(11, 12, 13, 14, 16, 17, 18, 19)):
+def random_case(rng, pixels=(11, 12, 13, 14, 16, 17, 18, 19), even_batches=False):
     """-> (params set name, overrides, n_envs, philox seed, first episode, n_agents, n_actions)"""
     u = rng.random()
     name = "c4" if u < 0.03 else ("c2" if u < 0.2 else "small")   # 512 x 512 / 256 x 256 / 128 x 128 (and other sizes below)
@@ -25,4 +25,8 @@ def random_case(rng, pixels=(11, 12, 13, 14, 16, 17, 18, 19)):
     seed, ep0, n_envs = rng.getrandbits(40), rng.randrange(1, 5000), (1 if name == "c4" else rng.choice([1, 2, 3]))
     if name == "small" and n <= 4 and rng.random() < 0.06:
         n_envs = 48   # a batch large enough for other launch shapes (rows per work item, wavefronts per env)
+    if even_batches and name == "small" and n <= 6 and rng.random() < 0.12:
+        # even batches of 8 or more envs: the tile fusion rotates the env index with the wavefront index (fuse_tiles.hip), with
+        # E % 8 = 0, 2, 4, 6 -- the long sweeps only (an extra draw would change the fixed dozen of the test suite)
+        n_envs = rng.choice([8, 10, 12, 14, 16, 24])
     return name, over, n_envs, seed, ep0, n, A

@@ -20,7 +20,7 @@ def main():
     t0 = time.time()
     ties = mixed = 0
     for k in range(n_cases):
-        name, over, n_envs, seed, ep0, n, A = random_case(rng)
+        name, over, n_envs, seed, ep0, n, A = random_case(rng, even_batches=True)
         try:
             # every fourth case: the untracked kernels (tile-item fusion), half of those as steps() alone (bench.py's launch sequence)
             # (class-weight threshold ties are recognised by the comparison itself -- tests/conftest.py::assert_features_or_ties admits a
