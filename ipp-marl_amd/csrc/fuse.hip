@@ -475,12 +475,19 @@ k_fuse_rows(const ippm_config* __restrict__ c, float* __restrict__ local, float*
             int n_envs_total, int env_cap) {
   __shared__ double s_area[TRACK ? (IPPM_FEAT + 1) * IPPM_AREA_LD : 1];
   const int n = c->n_agents;
-  if (work) {  // gridDim.x is a multiple of the env count: wavefront b serves env b % E, taking every (gridDim.x / E)-th item
-    const int env = blockIdx.x % n_envs_total;
+  if (work) {  // gridDim.x is a multiple of the env count: wavefront b serves an env of row b / E, taking every (gridDim.x / E)-th item
+    // (which env: b % E, moved on by one place every fourth row for even batches of 8 or more -- consecutive workgroups go to
+    //  consecutive XCDs, and with E a multiple of 8 plain b % E would run each env's whole list on XCD env % 8; fuse_tiles.hip)
+    const int row = blockIdx.x / n_envs_total;
+    int env = blockIdx.x - row * n_envs_total;
+    if (n_envs_total >= 8 && (n_envs_total & 1) == 0) {
+      env += (row >> 2) & 7;
+      env -= env >= n_envs_total ? n_envs_total : 0;
+    }
     const int count = (work[env] & IPPM_WORK_TILED) ? 0 : work[env];  // a list in the tile form is fuse_tiles.hip's
     const int32_t* items = work + n_envs_total + (size_t)env * env_cap;
     const int step = gridDim.x / n_envs_total;
-    for (int i = blockIdx.x / n_envs_total; i < count; i += step) {
+    for (int i = row; i < count; i += step) {
       const int item = items[i];
       const int m = item >> 8;
       fuse_item<VEC, TRACK, NAMAX, SHIFT>(c, local, global, code, plan_ro, ws, sums, area, counters, s_area, wave_rows, min_ops, n_envs_total,

@@ -380,8 +380,8 @@ __device__ __forceinline__ void tile_item_long(const TileCtx& w, TileAcc& acc, i
   else { acc.cells_l += cells; acc.ops_l += opcells; }
 }
 
-// Workgroup = one wavefront; gridDim.x is a multiple of the env count: wavefront b serves env b % E and takes every
-// (gridDim.x / E)-th item of the env's list.
+// Workgroup = one wavefront; the grid is (envs, wavefronts per env): wavefront `first` = blockIdx.y of an env takes items first,
+// first + gridDim.y, ... of the env's list (which env a workgroup serves: blockIdx.x, rotated with `first` -- see the kernel).
 // (wavefronts per SIMD: the untracked instantiation fits in 80 VGPRs without scratch and takes 6 -- for every team size since
 // round 5, items met by more than six ops run the chain in chunks)
 #ifndef IPPM_TILE_WAVES_PER_EU

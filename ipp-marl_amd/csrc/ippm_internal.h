@@ -90,7 +90,7 @@ void ippm_set_error(const std::string& msg);
 // k_plan for local (global_maps == 0) or global fusion plans; step_small.hip
 // Fusion work list (int32, caller-owned, ippm_work_words() long): [E] item counts, then [E][cap] items (map << 8 | run of
 // rows), cap = (N+1) * runs per map.  Every env owns its slice: the plan wavefront of env e WRITES count and items (no atomics,
-// nothing to clear between steps), the fusion's resident wavefronts b serve env b % E.
+// nothing to clear between steps), the fusion's wavefronts each serve ONE env and stride through its list.
 int ippm_fuse_wave_rows(const ippm_ctx* ctx, int n_envs);  // rows per work item (fuse.hip)
 int ippm_work_env_cap(const ippm_ctx* ctx, int n_envs);    // items an env's slice can hold
 // The tile form of the list (IPPM_STEP_TILES; fuse_tiles.hip): [E] counts tagged IPPM_WORK_TILED, then from word (E + 3) & ~3 on

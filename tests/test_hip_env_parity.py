@@ -650,13 +650,16 @@ def test_split_batch_on_two_streams_equals_the_batch():
         assert int(split.fault.abs().sum()) == 0
 
 
-def test_tile_fusion_xcd_rotation_changes_nothing():
+@pytest.mark.parametrize("prior", [0.5, 0.3])
+def test_tile_fusion_xcd_rotation_changes_nothing(prior):
     """The tile fusion deals an env's wavefronts out over the eight XCDs by rotating the env index with the wavefront index when the
     batch is even and at least 8 envs (fuse_tiles.hip); odd or smaller batches launch unrotated.  Which wavefront does which item
     must not show: a batch of 16 envs (rotated) against the same episodes as sub-batches of 6 + 5 + 5 (unrotated), and against
-    IPPM_TILE_ROTATE=0, bit for bit -- maps, rewards, work counters."""
+    IPPM_TILE_ROTATE=0, bit for bit -- maps, rewards, work counters.  prior 0.3: the row walker's work list (fuse.hip), whose
+    wavefronts are rotated the same way (no knob there: the third env repeats the first)."""
     from ippmarl.vec_env import SplitVecEnv, POLICY_UNIFORM
-    params = make_params("small", experiment__uav__fix_range=False, experiment__uav__failure_rate=0.1, experiment__missions__n_agents=5)
+    params = make_params("small", experiment__uav__fix_range=False, experiment__uav__failure_rate=0.1, experiment__missions__n_agents=5,
+                         mapping__prior=prior)
     teams = [5, 2, 3, 5, 1, 4, 5, 5] * 2
     one = _env(params, 16, track_area=False, terrain="random_field", team_sizes=teams)
     split = SplitVecEnv(params, 16, parts=3, terrain="random_field", team_sizes=teams)
