@@ -166,6 +166,36 @@ def test_launcher_retries_once_with_the_other_ipc_setting(monkeypatch):
     assert [c[1] for c in calls] == ["unset", "0"]
 
 
+def test_fusion_rotation_rule_spreads_every_env_over_all_xcds():
+    """The launch rule of the tile fusion and of the row walker's work-list form (fuse_tiles.hip, fuse.hip), restated: workgroup
+    (x, f) of a grid (E, per_env) is linear workgroup x + E * f and runs on XCD (x + E * f) % 8; it serves env
+    (x + ((f >> s) & 7)) mod E for even E >= 8 (s = 2 where the launch has at least 32 wavefronts per env, else 1 or 0) and env x
+    otherwise.  For every batch size: each (env, f) is served exactly once, and an env's wavefronts are spread over the eight XCDs
+    when E is odd or rotated -- the property whose absence cost config 5's mixed batches 20-45 % of the fusion."""
+    for E in list(range(1, 41)) + [64, 85, 86, 128, 256, 512, 1024]:
+        for per_env in (8, 16, 35, 64, 1024):
+            rot = 0
+            if E >= 8 and E % 2 == 0:
+                rot = 1
+                while rot < 3 and (per_env >> rot) >= 8:
+                    rot += 1
+            share = {}
+            for f in range(per_env):
+                served = set()
+                for x in range(E):
+                    env = x + (((f >> (rot - 1)) & 7) if rot else 0)
+                    env -= E if env >= E else 0
+                    served.add(env)
+                    per_xcd = share.setdefault(env, [0] * 8)
+                    per_xcd[(x + E * f) % 8] += 1
+                assert served == set(range(E)), (E, per_env, f)
+            if E % 2 == 1 or rot:
+                # no XCD holds more than 26 % of any env's wavefronts (unrotated even batches: up to all of them); with 16 or more
+                # wavefronts per env every env visits all eight (with 8, the wrap at the batch's end costs the first envs an XCD or two)
+                assert max(max(v) for v in share.values()) <= 0.26 * per_env + 1e-9, (E, per_env, rot)
+                if per_env >= 16:
+                    assert all(min(v) > 0 for v in share.values()), (E, per_env, rot)
+
 def test_placement_search_stop_rule():
     """VecEnv.tune_placement's early exit: stops on a clear fast draw whether fast draws are the minority or the
     majority, never on a slow outlier among slow draws, and gives up on a box with one kind only after twelve draws."""
