@@ -178,8 +178,8 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="step the batch as this many sub-batches, each on its own HIP stream "
                     "(ippmarl.vec_env.SplitVecEnv): the latency-bound plan kernel and the reset of one runs beside the bandwidth-bound map "
                     "kernels of the other -- 0.1526 -> 0.141 ms per step at config 2; 1 = one stream, one launch per kernel and step; "
-                    "0 (default) = 2, or 3 where the envs' work differs many-fold (--episode-comm-range, --team-sizes: a launch's tail is "
-                    "its few heavy envs, and a third stream fills it: 1.01 -> 1.38-1.43 M agent-env steps/s at config 5's shape)")
+                    "0 (default) = 2, or 3 where the envs' work differs many-fold (--episode-comm-range, --team-sizes: 1.09 / 1.13 / 1.32 M "
+                    "agent-env steps/s on 1 / 2 / 3 streams at config 5's shape)")
     ap.add_argument("--team-sizes", default=None, help="comma-separated team sizes dealt out to the envs in turn (BASELINE config 5's mixed teams, "
                     "e.g. 2,4,8,16 with --agents 16): env e flies team_sizes[e %% len] of the --agents UAVs; agent-env steps count the flying ones")
     ap.add_argument("--comm-range", type=float, default=None, help="experiment.uav.communication_range in metres (default: params.yaml's 25)")
