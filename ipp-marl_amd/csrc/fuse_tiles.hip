@@ -478,14 +478,16 @@ int ippm_launch_fuse_tiles(ippm_ctx* ctx, float* local, float* global, const uin
   const int max_ops = c.n_agents + 1;
   const int env_cap = ippm_tile_env_cap(ctx);
   // wavefronts per env: about three items each.  An item is <= 256 lane-loads (1024 cells); a step touches roughly half of the
-  // maps over a third of their cells.  Up to 1024 per env: with per-episode comm ranges (config 5) the envs' lists differ fifty-fold
+  // maps over a third of their cells.  Up to 2048 per env: with per-episode comm ranges (config 5) the envs' lists differ fifty-fold
   // in length (484 .. 21 611 items at 64 envs x 16 UAVs x 1024^2) and the wavefronts of a long list are the launch's tail --
   // 256 / 1024 / 2048 per env: 962 / 853 / 850 us there; a wavefront whose env has nothing left for it costs a scalar load.
+  // (Since an env's wavefronts go round all XCDs -- `rot` below -- 2048 is worth 3 %: 772 -> 748 us at 64 envs, 934 -> 906 on 256
+  // envs of mixed teams; the estimate gives config 5's shape 1844.)
   // (Dealing the wavefronts out in proportion to the lists -- ceil(count / 8 .. 64) per env from a taller grid -- was 6 - 15 % SLOWER
   // than 1024 for everybody -- measured while each env's list still ran on one XCD (see `rot` below), which is what held those
   // launches up, not their longest chains; profiles/r05/c5_wave_distribution.txt)
   const double est_items = 0.5 * (c.n_agents + 1) * (double)c.grid_x * c.grid_y / 3.0 / (256.0 * ippm_tile_slots(max_ops));
-  int per_env = ctx->knob_tile_waves > 0 ? ctx->knob_tile_waves : (int)std::max(4.0, std::min(1024.0, est_items / 3.0));
+  int per_env = ctx->knob_tile_waves > 0 ? ctx->knob_tile_waves : (int)std::max(4.0, std::min(2048.0, est_items / 3.0));
   per_env = std::max(1, std::min(per_env, env_cap));
   // a launch smaller than the chip's wave slots leaves CUs idle: small batches take more wavefronts per env
   while ((long long)per_env * n_envs < 16384 && per_env * 2 <= env_cap && per_env < 256) per_env *= 2;
