@@ -268,7 +268,10 @@ def main():
     split = args.streams > 1 and not args.graphs and not args.terrain_prefetch
     if split:   # the batch as sub-batches on their own streams (same envs, same episodes, same results)
         env = SplitVecEnv(params, args.envs, parts=args.streams, device=device, philox_seed=3, terrain=args.terrain, team_sizes=teams)
+        # (streams that shared a hardware queue with an earlier one and were swapped; the last side-by-side ratios measured)
+        stream_check = {"redraws": env.stream_redraws, "side_by_side": env.stream_probe}
     else:
+        stream_check = None
         env = VecEnv(params, args.envs, device=device, philox_seed=3, terrain=args.terrain, track_area=False, team_sizes=teams)
     # The roofline leg measures the kernels ONE LAUNCH AT A TIME at the full batch: with sub-batches on several streams that is a
     # second, whole-batch VecEnv (same config, same library, its own placement search), stepped on one stream after the timed loops.
@@ -648,7 +651,8 @@ def main():
                        "envs_per_gpu": E, "n_agents": N, "grid": grid,
                        "episode_steps": T, "terrain": args.terrain, "parallelism": f"env-sharded x{world} (no data-path collective)",
                        "streams": args.streams if split else 1, "envs_per_launch": sub_envs,
-                       "launches_per_step": 3 * (args.streams if split else 1), "hip_graphs": bool(args.graphs), "roofline_steps": args.roofline_steps,
+                       "launches_per_step": 3 * (args.streams if split else 1), "stream_check": stream_check, "hip_graphs": bool(args.graphs),
+                       "roofline_steps": args.roofline_steps,
                        "terrain_prefetch": bool(args.terrain_prefetch and args.terrain == "random_field")},
             "ranks": world,
             "resets_timed": resets_timed,

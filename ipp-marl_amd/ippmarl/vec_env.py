@@ -16,9 +16,10 @@ Philox4x32-10 keyed by (philox_seed; episode, agent, step) -- independent of how
 """
 from __future__ import annotations
 
-from typing import Dict, Optional
+from typing import Dict, Optional, Tuple
 
 import os
+import time
 
 import numpy as np
 import torch
@@ -607,6 +608,7 @@ class SplitVecEnv:
         self.sizes = [base + (1 if k < extra else 0) for k in range(parts)]
         self.offsets = [sum(self.sizes[:k]) for k in range(parts)]
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(parts)]
+        self.stream_redraws, self.stream_probe = self._spread_streams()
         ts = None if team_sizes is None else [int(v) for v in team_sizes]
         self.parts = []
         for k, (n, off) in enumerate(zip(self.sizes, self.offsets)):
@@ -618,6 +620,51 @@ class SplitVecEnv:
         self.params = params
 
     # -- stream plumbing ------------------------------------------------------------------------------
+    @staticmethod
+    def _side_by_side(a, b, cycles: int) -> Tuple[float, float]:
+        """(wall time of one spin kernel on each of two streams) / (two on one stream), and the latter in seconds: about 0.5 when
+        the two streams run side by side, about 1 when the runtime serves both from one hardware queue."""
+        def run(s0, s1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with torch.cuda.stream(s0):
+                torch.cuda._sleep(cycles)
+            with torch.cuda.stream(s1):
+                torch.cuda._sleep(cycles)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+        run(a, b)
+        serial = run(a, a)
+        return run(a, b) / max(serial, 1e-9), serial
+
+    def _spread_streams(self, tries: int = 8):
+        """HIP serves a process's streams from a handful of hardware queues (GPU_MAX_HW_QUEUES, 4 by default) and torch hands streams
+        out of a pool of 32: two sub-batches' streams can land on ONE queue, where their kernels run one after the other and the
+        split buys nothing (one process in eight of profiles/r05/two_streams_probe.txt; a config 5 line at the one-stream figure).
+        Two spin kernels tell: a stream that does not run beside every earlier one is swapped for the pool's next.
+        -> (streams swapped, the last ratios measured); skipped where the spin kernel is not to be had."""
+        if len(self.streams) < 2 or not hasattr(torch.cuda, "_sleep"):
+            return 0, []
+        redraws, ratios = 0, []
+        try:
+            cycles = 1 << 20
+            for _ in range(4):          # a spin long enough to time from the host (>= 0.4 ms for the pair)
+                if self._side_by_side(self.streams[0], self.streams[0], cycles)[1] >= 4e-4:
+                    break
+                cycles <<= 2
+            else:
+                return 0, []
+            for k in range(1, len(self.streams)):
+                for _ in range(tries):
+                    ratios = [round(self._side_by_side(self.streams[j], self.streams[k], cycles)[0], 2) for j in range(k)]
+                    if max(ratios) < 0.8:
+                        break
+                    self.streams[k] = torch.cuda.Stream(device=self.device)
+                    redraws += 1
+        except Exception:               # the check is an optimisation: never in the way of the env
+            return redraws, ratios
+        return redraws, ratios
+
     def _each(self):
         """(part, its slice of the batch) with the part's stream current and ordered behind the caller's stream."""
         cur = torch.cuda.current_stream(self.device)

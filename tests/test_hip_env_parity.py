@@ -689,6 +689,23 @@ def test_tile_fusion_xcd_rotation_changes_nothing(prior):
     assert want["fuse_local_cells"] > 0 and want["work_list_rejects"] == 0
 
 
+def test_split_streams_run_side_by_side():
+    """SplitVecEnv checks that its streams do not share a hardware queue (HIP serves a process's streams from four; two torch
+    streams in eleven did on the box of tools/stream_queue_probe.py) and swaps the ones that do: afterwards a spin kernel on each of two
+    parts' streams takes about the time of one, not of two."""
+    from ippmarl.vec_env import SplitVecEnv
+    if not hasattr(torch.cuda, "_sleep"):
+        pytest.skip("no spin kernel in this torch build")
+    keep = [torch.cuda.Stream() for _ in range(9)]     # a process with other streams alive, as bench.py's is
+    split = SplitVecEnv(make_params("small"), 6, parts=3, terrain="random_field")
+    assert len(split.stream_probe) == 2 and max(split.stream_probe) < 0.8, (split.stream_redraws, split.stream_probe)
+    for j in range(3):
+        for k in range(j + 1, 3):
+            ratio, serial = SplitVecEnv._side_by_side(split.streams[j], split.streams[k], 1 << 20)
+            assert serial < 4e-4 or ratio < 0.8, (j, k, ratio, serial)
+    del keep
+
+
 def test_fused_comm_and_plan_equals_separate_calls():
     """ippm_comm_fuse_local == ippm_comm_matrix + ippm_fuse_local (bitwise), incl. link failures and per-episode ranges."""
     from ippmarl.vec_env import POLICY_UNIFORM
