@@ -196,6 +196,50 @@ def test_fusion_rotation_rule_spreads_every_env_over_all_xcds():
                 if per_env >= 16:
                     assert all(min(v) > 0 for v in share.values()), (E, per_env, rot)
 
+def test_split_env_swaps_streams_that_share_a_queue(monkeypatch):
+    """SplitVecEnv._spread_streams (vec_env.py) with the device replaced by a model of it: streams are numbered as the pool hands
+    them out, stream i is served by hardware queue i % 4, and two streams on one queue take twice as long as side by side.  The parts'
+    streams must end up on pairwise different queues, with as few swaps as that takes."""
+    torch = pytest.importorskip("torch")
+    from ippmarl import vec_env
+
+    class FakeStream:
+        count = 0
+
+        def __init__(self, device=None):
+            self.idx = FakeStream.count
+            FakeStream.count += 1
+
+    def side_by_side(a, b, cycles):
+        return (1.0 if a.idx % 4 == b.idx % 4 else 0.53), 1e-3
+
+    monkeypatch.setattr(vec_env.torch.cuda, "Stream", FakeStream)
+    monkeypatch.setattr(vec_env.torch.cuda, "_sleep", lambda cycles: None, raising=False)
+    monkeypatch.setattr(vec_env.SplitVecEnv, "_side_by_side", staticmethod(side_by_side))
+    for first, parts, want_redraws in ((0, 2, 0), (0, 3, 0), (3, 2, 0), (0, 4, 0)):
+        FakeStream.count = first
+        env = object.__new__(vec_env.SplitVecEnv)
+        env.device = "cpu"
+        env.streams = [FakeStream() for _ in range(parts)]
+        redraws, ratios = env._spread_streams()
+        assert redraws == want_redraws and max(ratios) < 0.8
+        assert len({st.idx % 4 for st in env.streams}) == parts
+    # the pool hands out 0, 4 (the same queue): the second is swapped once, for 5
+    env = object.__new__(vec_env.SplitVecEnv)
+    env.device = "cpu"
+    a, b = FakeStream(), FakeStream()
+    a.idx, b.idx, FakeStream.count = 0, 4, 5
+    env.streams = [a, b]
+    assert env._spread_streams() == (1, [0.53]) and [st.idx for st in env.streams] == [0, 5]
+    # three parts on queues 0, 1, 1: the third moves on until it is beside both
+    env = object.__new__(vec_env.SplitVecEnv)
+    env.device = "cpu"
+    env.streams = [FakeStream(), FakeStream(), FakeStream()]
+    env.streams[0].idx, env.streams[1].idx, env.streams[2].idx, FakeStream.count = 0, 1, 5, 8
+    redraws, ratios = env._spread_streams()
+    assert redraws == 3 and [st.idx for st in env.streams] == [0, 1, 10] and ratios == [0.53, 0.53]   # 8 -> queue 0, 9 -> 1, 10 -> 2
+
+
 def test_placement_search_stop_rule():
     """VecEnv.tune_placement's early exit: stops on a clear fast draw whether fast draws are the minority or the
     majority, never on a slow outlier among slow draws, and gives up on a box with one kind only after twelve draws."""
