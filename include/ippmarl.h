@@ -68,6 +68,10 @@ extern "C" {
 #define IPPM_STEP_GLOBAL 2 /* global-fusion plan */
 #define IPPM_STEP_MOVE 4   /* K1 mask/act/move (+ footprints of the new positions) */
 #define IPPM_STEP_TILES 8  /* accepted, implied: the work list's form follows the context (ippm_tile_form), see ippm_plan_step */
+/* fault[e] (ippm_plan_step): bits 0..n_agents-1 = agents whose action mask became empty at the LAST step; this bit is sticky
+ * (the caller clears it): the env's tile work list did not fit its slice at some step (ruled out by the capacity bound of the
+ * list; an env that shows it is no longer fused: ippm_fuse_step skips an overflowed list and counts it in counters.reserved[0]) */
+#define IPPM_FAULT_WORK_OVERFLOW 0x40000000
 #define IPPM_SENSE_REC_WORDS 8  /* words per agent of ippm_plan_step's rect_next / ippm_sense_step's rect_in */
 
 /* Derived constants, computed on the host in float64 with the reference's expression order
@@ -250,7 +254,7 @@ int ippm_fuse_global_reward(ippm_ctx* ctx, float* global, const uint8_t* code, c
  *   on all others.  ippm_fuse_step of the same context consumes whichever form ippm_plan_step wrote, with or without area
  *   sums.  IPPM_STEP_TILES is accepted for source compatibility and changes nothing (it is implied where the tile form exists
  *   and ignored where it does not).  A list that a kernel cannot read (written by another context's plan step, or overflowed)
- *   fuses nothing and is counted in ippm_counters.reserved[0].
+ *   fuses nothing and is counted in ippm_counters.reserved[0]; an overflowed one also sets IPPM_FAULT_WORK_OVERFLOW in fault[e].
  * ippm_fuse_step: K4 for all local maps and K5 for all global maps from the plans above, in one launch; keeps `area`
  *   (optional) up to date; leaves the reward sums open (ippm_sense_step or ippm_reward_finalize completes them).  With the
  *   `work` list of the same step's ippm_plan_step a fixed number of resident wavefronts strides over exactly the non-empty
@@ -261,8 +265,10 @@ int ippm_fuse_global_reward(ippm_ctx* ctx, float* global, const uint8_t* code, c
  * UAVs: it then evolves exactly like a run of the reference with n_agents = n_active[e] (same episode number): agents
  * >= n_active[e] are heard by nobody, hear nobody, do not move, sense or publish, and the agent-id plane of the network inputs is
  * (i + 1) / n_active[e].  n_active: DEVICE int32 [n_envs], caller-owned, read at every launch of the batched step
- * (ippm_plan_step, ippm_fuse_step, ippm_sense_step, ippm_reset_maps, ippm_actor_features, ippm_critic_features); NULL (the
- * default): every env flies n_agents.  Arrays keep their [E, n_agents, ...] strides; rows of inactive agents are not meaningful.
+ * (ippm_plan_step, ippm_sense_step, ippm_reset_maps, ippm_actor_features, ippm_critic_features; ippm_fuse_step does not read it:
+ * it executes the plans ippm_plan_step wrote, and an agent that does not fly gets an EMPTY plan at every plan step, so team sizes
+ * may change between any two steps); NULL (the default): every env flies n_agents.  Arrays keep their [E, n_agents, ...] strides;
+ * rows of inactive agents are zero (observations, critic states) or not meaningful.
  * The single-purpose entry points (ippm_comm_matrix, ippm_fuse_local, ippm_ig_*, ...) do not look at it. */
 int ippm_set_team_sizes(ippm_ctx* ctx, const int32_t* n_active);
 int ippm_plan_step(ippm_ctx* ctx, const int64_t* episode, int32_t* pos, const float* comm_range, const double* draws,
@@ -291,7 +297,8 @@ int ippm_reward_from_maps(ippm_ctx* ctx, const float* before, const float* after
  * Sequential over the agents of an env (agent i is masked against the already-moved j < i).
  * policy: 0 = explicit `action_in`; 1 = uniform over the valid mask (Philox); 2 = sample from
  * probs*mask (Philox, "train"); 3 = argmax of probs*mask ("eval").  probs float [E,N,A] (policy 2/3).
- * fault[e] != 0 when an agent's mask became empty (the reference's torch.multinomial raises there). */
+ * fault[e] != 0 when an agent's mask became empty (the reference's torch.multinomial raises there): bit i = agent i, this step's
+ * bits replace the last step's (IPPM_FAULT_WORK_OVERFLOW is kept). */
 /* AgentActionSpace.get_action_mask (mask_in == NULL) / apply_collision_mask (mask_in = the mask to refine) for a batch
  * of single agents: pos int32 [B,3]; others int32 [B,max_others,3] = positions of already-moved agents, n_others
  * int32 [B] (NULL: none); masks uint8 [B,A] (agent/action_space.py:25-196,309-589). */

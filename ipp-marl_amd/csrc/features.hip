@@ -342,6 +342,10 @@ k_critic_features(const ippm_config* __restrict__ c, const double* __restrict__ 
     dst[10] = s_F[o];
     dst[11] = am_;
   }
+  // agents that do not fly: an all-zero state, like their observation (k_actor_features) -- the rows travel through the target
+  // critic with everyone else's in COMATrainer.td_targets and must not hold whatever the allocation held
+  for (int w = na * FEAT2 * IPPM_CRITIC_PLANES + tid; w < n * FEAT2 * IPPM_CRITIC_PLANES; w += blockDim.x)
+    state[(size_t)e * n * FEAT2 * IPPM_CRITIC_PLANES + w] = 0.f;
 }
 
 // ------------------------------------------------------------------------------------------------------

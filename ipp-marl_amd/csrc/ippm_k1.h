@@ -158,7 +158,12 @@ __device__ void k1_env(const ippm_config* __restrict__ c, int64_t ep, int32_t* s
     if (lane < A) mask_e[(size_t)i * A + lane] = (m >> lane) & 1u;
     wave_sync_lds();
   }
-  if (fault_e && lane == 0) *fault_e = flt;
+  // this step's empty-mask bits replace the last step's; IPPM_FAULT_WORK_OVERFLOW (set by a builder wavefront of the same launch,
+  // possibly at this very moment) is sticky
+  if (fault_e && lane == 0) {
+    atomicAnd(fault_e, IPPM_FAULT_WORK_OVERFLOW);
+    if (flt) atomicOr(fault_e, flt);
+  }
 }
 
 

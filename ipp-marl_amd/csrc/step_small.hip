@@ -499,6 +499,10 @@ k_plan_step(int32_t* __restrict__ pos, const int32_t* __restrict__ rect, int32_t
       if ((flags & IPPM_STEP_GLOBAL) && lane == n)
         hull_rows = plan_map(c, s_rect, s_pos, 0u, ws, 1, e, n, st, nullptr, nullptr, na);
     }
+    // an agent that does not fly (any more: team sizes may change between steps) gets an EMPTY plan, so that a fusion which
+    // enumerates every map's plan from ws (no work list) never re-applies the plan it was left with when it last flew
+    if ((flags & IPPM_STEP_COMM) && lane >= na && lane < n && agent_sel < 0)
+      ws[(size_t)(e * (n + 1) + lane) * IPPM_WS_WORDS + WS_PLAN + PL_NOPS] = 0;
     // the map's fused-cells box takes in this step's plan hull (ippm_reset_maps fills only the boxes at the next reset)
     if (lane <= n && hull_rows > 0) {
       int32_t* wm = ws + (size_t)(e * (n + 1) + lane) * IPPM_WS_WORDS;
@@ -551,6 +555,8 @@ k_plan_step(int32_t* __restrict__ pos, const int32_t* __restrict__ rect, int32_t
       // (the capacity bound of ippm_tile_env_cap covers every plan; a list that would not fit is cut and reported)
       const int total = atomicAdd(&s_items, 0);
       work[e] = min(total, env_cap) | IPPM_WORK_TILED | (total > env_cap ? IPPM_WORK_OVERFLOW : 0);
+      // the fusion skips an overflowed list (and counts it); the env says so too, stickily: its maps are no longer fused
+      if (total > env_cap && fault) atomicOr(fault + e, IPPM_FAULT_WORK_OVERFLOW);
     }
   }
   if (wv != k1_wave) return;

@@ -22,13 +22,13 @@ from .vec_env import VecEnv, POLICY_ARGMAX, POLICY_SAMPLE
 class COMATrainer:
     def __init__(self, params: Dict, n_envs: int, device: str = "cuda:0", philox_seed: int = 3, waves_per_update: int = 1,
                  quirks: str = "reference", rank: int = 0, world: int = 1, first_episode: int = 1,
-                 terrain: str = "split", graphs: bool = False, placement_draws: int = 24, team_sizes=None):
+                 terrain: str = "split", graphs: bool = False, placement_draws: int = 0, team_sizes=None):
         self.params = params
         # team_sizes: mixed team sizes in one batch (VecEnv): the transitions of agents that do not fly never enter a minibatch
         self.env = VecEnv(params, n_envs, device=device, philox_seed=philox_seed, terrain=terrain, team_sizes=team_sizes)
         # Large batches: where the allocator put the maps decides ~10 % of the rollout's map kernels (VecEnv.tune_placement).  The
-        # default is bench.py's: the search stops at the first fast allocation (~10 ms a draw at config 2), returns None without
-        # drawing for batches below 2^24 cells, keeps its rejected candidates within half of the free memory; <= 1: no search.
+        # search is OPT-IN (placement_draws > 1; bench.py passes its own --placement-draws): it steps the env for ~10 ms a draw and
+        # holds candidate arenas within half of the free memory while it runs, which a caller should ask for, not find out about.
         self.placement = self.env.tune_placement(placement_draws) if placement_draws > 1 else None
         self.device = self.env.device
         self.rank, self.world = rank, world
@@ -216,9 +216,17 @@ class COMATrainer:
                     "adam_steps": 2 * self.data_passes * self.batch_number, "train_step": self.train_step}
         closs, aloss = self._update_compute(None, self.eps_dev if self.graphs else self.eps, diagnostics)
         self.filled = 0
+        total = n * self.world
         if self.env.n_active is not None:
-            n = int(self.env.n_active.sum()) * W * T
-        return {"critic_loss": float(closs), "actor_loss": float(aloss), "transitions": n * self.world,
+            # mixed team sizes: every rank counts its own flying agents (the ranks' teams differ), summed over the ranks
+            mine = torch.tensor([int(self.env.n_active.sum()) * W * T], dtype=torch.int64, device=self.device)
+            if self.world > 1:
+                import torch.distributed as dist
+                if dist.get_backend() == "gloo":
+                    mine = mine.cpu()
+                dist.all_reduce(mine)
+            total = int(mine[0])
+        return {"critic_loss": float(closs), "actor_loss": float(aloss), "transitions": total,
                 "adam_steps": 2 * self.data_passes * self.batch_number, "train_step": self.train_step}
 
     def valid_transitions(self, waves: int) -> Optional[torch.Tensor]:

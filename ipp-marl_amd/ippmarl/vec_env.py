@@ -55,9 +55,9 @@ def placement_stop_reason(scores) -> Optional[str]:
     The two kinds of allocation are 7-8 % apart and each is sharp to ~1 %:
       * a draw well below the MEDIAN of the draws is a fast one among slow ones (below the worst is not enough: a slow outlier among
         slow draws -- 121, 121, 126 -- would end the search on a slow one);
-      * when fast draws are the majority the median is a fast score and that rule cannot fire: two draws within 2 % of the best and
-        a third more than 6 % above it show both kinds, the best is a fast one (113, 114, 122: stop at the third draw; 121, 121, 126 is
-        a slow outlier among slow draws again: go on);
+      * when fast draws are the majority the median is a fast score and that rule cannot fire: then BOTH kinds must have shown twice --
+        two draws within 2 % of the best, and two draws more than 6 % above it that agree with each other to 2 % (113, 114, 122, 122.5:
+        stop at the fourth draw; 121, 121.5, 129 is one slow outlier among slow draws, not a second kind: go on);
       * twelve draws in a row within 2 % of each other: the box has one kind only, nothing to search for."""
     k = len(scores)
     if k < 2:
@@ -65,7 +65,8 @@ def placement_stop_reason(scores) -> Optional[str]:
     best = min(scores)
     if best < 0.96 * float(np.median(scores)):
         return "a fast allocation found"
-    if sum(1 for v in scores if v <= 1.02 * best) >= 2 and max(scores) > 1.06 * best:
+    slow = sorted(v for v in scores if v > 1.06 * best)
+    if sum(1 for v in scores if v <= 1.02 * best) >= 2 and any(b <= 1.02 * a for a, b in zip(slow, slow[1:])):
         return "a fast allocation found"
     if k >= 12 and max(scores) < 1.02 * best:
         return "no spread between the first draws"

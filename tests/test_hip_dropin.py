@@ -171,8 +171,8 @@ def test_batch_memory_td_targets(golden):
     bm.build_td_targets(TableCritic(table))
     td = np.array([[float(bm.transitions[a][i].td_target) for i in range(L)] for a in range(n)])
     dr = np.array([[float(bm.transitions[a][i].discounted_return) for i in range(L)] for a in range(n)])
-    np.testing.assert_allclose(td, fx["td"], rtol=2e-5, atol=2e-6)
-    np.testing.assert_allclose(dr, fx["dr"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(td, fx["td"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(dr, fx["dr"], rtol=1e-5, atol=2e-6)
     batches = bm.build_batches()
     assert len(batches) == (n * L) // 60 and all(len(b) == 60 for b in batches)
 

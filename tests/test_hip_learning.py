@@ -516,20 +516,18 @@ def test_recorded_round_equals_eager_round():
             bufs.append({k: getattr(tr, k).clone() for k in ("buf_obs", "buf_state", "buf_action", "buf_mask", "buf_reward")})
             stats = tr.update()
             assert stats["adam_steps"] == 50 and np.isfinite(stats["critic_loss"]) and np.isfinite(stats["actor_loss"])
-        if True:
-            # the replayed rollout took the same actions over the same maps; network inputs and rewards agree to the summation
-            # order of the float64 atomics behind the tracked area sums / reward sums
-            for k in ("buf_action", "buf_mask"):
-                assert torch.equal(bufs[0][k], bufs[2][k]), k
-            for k in ("buf_obs", "buf_state", "buf_reward"):
-                torch.testing.assert_close(bufs[0][k], bufs[2][k], rtol=1e-5, atol=2e-6, msg=k)
-            assert torch.equal(eager.env.local, rec.env.local) and torch.equal(eager.env.glob, rec.env.glob)
+        # the replayed rollout took the same actions over the same maps; network inputs and rewards agree to the summation
+        # order of the float64 atomics behind the tracked area sums / reward sums
+        for k in ("buf_action", "buf_mask"):
+            assert torch.equal(bufs[0][k], bufs[2][k]), k
+        for k in ("buf_obs", "buf_state", "buf_reward"):
+            torch.testing.assert_close(bufs[0][k], bufs[2][k], rtol=1e-5, atol=2e-6, msg=k)
+        assert torch.equal(eager.env.local, rec.env.local) and torch.equal(eager.env.glob, rec.env.glob)
         for net, b in (("actor", before[0]), ("critic", before[1])):
             e1, e2, r = flat(getattr(eager, net)), flat(getattr(eager2, net)), flat(getattr(rec, net))
             moved = float((e1 - b).norm())
             assert moved > 0
             d_ee, d_er = float((e1 - e2).norm()), float((e1 - r).norm())
-            print(f"round {rnd} {net}: moved {moved:.4f}  eager vs eager {d_ee:.3e}  eager vs recorded {d_er:.3e}")
             # (a wrong permutation, a missed step or a stale buffer would put d_er at the size of `moved` itself)
             assert d_er <= max(10.0 * d_ee, 5e-2 * moved), (rnd, net, d_er, d_ee, moved)
     assert eager.train_step == rec.train_step == 3

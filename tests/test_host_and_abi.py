@@ -247,9 +247,13 @@ def test_placement_search_stop_rule():
     assert stop([121.5]) is None and stop([121.5, 122.0]) is None
     assert stop([121.5, 122.0, 113.4]) == "a fast allocation found"            # slow, slow, fast
     assert stop([113.4, 121.9]) is None                                         # one of each: which is the outlier?
-    assert stop([113.4, 121.9, 113.9]) == "a fast allocation found"            # fast, slow, fast (the median is a fast score)
-    assert stop([113.4, 113.9, 114.1, 122.3]) == "a fast allocation found"     # fast draws in the majority
+    assert stop([113.4, 121.9, 113.9]) is None                                  # fast, slow, fast looks exactly like slow, outlier, slow
+    assert stop([113.4, 121.9, 113.9, 122.4]) == "a fast allocation found"     # both kinds seen twice
+    assert stop([113.4, 113.9, 114.1, 122.3]) is None                           # fast draws in the majority: one slow draw may be an outlier
+    assert stop([113.4, 113.9, 114.1, 122.3, 121.8]) == "a fast allocation found"   # ... two that agree are the other kind
     assert stop([121.0, 121.2, 126.0]) is None                                  # a slow outlier among slow draws
+    assert stop([121.0, 121.5, 129.0]) is None                                  # (more than 6 % above, still one outlier)
+    assert stop([121.0, 121.5, 129.0, 134.0]) is None                           # two outliers that do not agree are not a kind either
     assert stop([121.0, 121.2, 126.0, 121.4, 120.9]) is None
     assert stop([121.0 + 0.1 * k for k in range(11)]) is None
     assert stop([121.0 + 0.1 * k for k in range(12)]) == "no spread between the first draws"

@@ -187,12 +187,12 @@ def test_td_lambda(golden):
     g, lam = float(fx["gamma"]), float(fx["lam"])
     for a in range(fx["rewards"].shape[0]):
         td, dr = O.td_lambda_targets(fx["rewards"][a], fx["dones"][a], fx["qsel"][a], g, lam)
-        np.testing.assert_allclose(td, fx["td"][a], rtol=2e-5, atol=1e-6)
-        np.testing.assert_allclose(dr, fx["dr"][a], rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(td, fx["td"][a], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(dr, fx["dr"][a], rtol=1e-5, atol=1e-6)
         assert td[15] == 0.0 and td[30] == 0.0 and dr[15] == 0.0  # first step of later episodes
     td, dr = O.td_lambda_targets(fx["rewards"][0][:15], fx["dones"][0][:15], fx["qsel"][0][:15], g, lam)
-    np.testing.assert_allclose(td, fx["td_single"], rtol=2e-5, atol=1e-6)
-    np.testing.assert_allclose(dr, fx["dr_single"], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(td, fx["td_single"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dr, fx["dr_single"], rtol=1e-5, atol=1e-6)
 
 
 def test_philox_known_answer():
