@@ -25,8 +25,9 @@ The JSON line also carries
                      step / ms_per_step / peak
   roofline_kernels : the same for the fusion launch (K4+K5: 8 B per cell of the union + 1 B per (cell, message)), the small
                      plan kernel, the reset kernels and, when training is on, the K6 feature builders
-  resets_timed, steady_state : how many episode resets the timed window held, and the same loop's rate over three whole episodes
-                     right after it (exactly one reset per episode): the figure to quote for sustained throughput
+  resets_timed, steady_state : how many episode resets the timed window held, and the same loop's rate over --steady-episodes (20)
+                     whole episodes right after it (exactly one reset per episode): the figure to quote for sustained throughput
+                     (also under roofline.steady_state, which the driver's record keeps)
   per_rank         : every rank's own ms_per_step / rate / placement-search outcome; value_sum_of_ranks next to value_from_max_time
   ranks, rank_devices, collective : who took part (one entry per rank) and the gradient all-reduces RCCL carried in the
                      COMA leg (backend, calls, bytes)
@@ -49,6 +50,8 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 K3_BYTES_PER_CELL = 10
+# what the kernels' own layout moves per footprint cell: 4 R + 4 W belief, truth bit-packed (1/8 B), codes one byte per 4-cell group
+K3_LAYOUT_BYTES_PER_CELL = 8.375
 # the unmodified reference, measured in the build container on 8 host cores; it cannot travel to the GPU box
 REFERENCE_PROBE = {"agent_env_steps_per_s": 10.0, "coma_updates_per_s": 0.164, "cores": 8,
                    "source": "SURVEY.md section 6: /root/reference run in the build container (default params, 493x493)"}
@@ -103,6 +106,73 @@ def cpu_baseline(args, seconds=10.0):
                          "sample": f"{stepsN} agent-env steps of {per * procs} envs in {dtN:.1f}s, {procs} oracle processes "
                                    f"({per} envs each, one core each)"},
             "reference_probe": REFERENCE_PROBE}
+
+
+def dropin_seam(device, episodes=3):
+    """Throughput of the drop-in seam itself: EpisodeGenerator.execute over the reference-shaped objects (COMAWrapper / Agent /
+    Mapping / CommunicationLog / BatchMemory: one env, NumPy at the boundary, the calls of missions/episode_generator.py:38-88 and
+    coma_wrapper.py:73-183 one by one), which is what a user who only swaps the imports of INTEGRATION.md section A runs.  Timed
+    for BASELINE config 2's parameters and for the reference's default 493 x 493 grid; with the host-side breakdown per agent-env
+    step: calls into libippmarl.so and device-to-host reads (Tensor.cpu / item / tolist / int() / float() on device tensors)."""
+    import numpy as np
+    from ippmarl import _ffi
+    from ippmarl.batch_memory import BatchMemory
+    from ippmarl.coma_wrapper import COMAWrapper
+    from ippmarl.mapping.grid_maps import GridMap
+    from ippmarl.missions.episode_generator import EpisodeGenerator
+    from ippmarl.params import default_params, grid256_params
+    from ippmarl.sensors import Sensor
+    from ippmarl.sensors.models import SensorModel
+    count = {"lib": 0, "d2h": 0}
+    real_call = _ffi.Context.call
+
+    def counted_call(self, name, *a):
+        count["lib"] += 1
+        return real_call(self, name, *a)
+
+    readers = ("cpu", "item", "tolist", "__int__", "__float__", "__bool__", "__index__")
+    real = {k: getattr(torch.Tensor, k) for k in readers}
+
+    def counting(k):
+        def f(self, *a, **kw):
+            if self.is_cuda:
+                count["d2h"] += 1
+            return real[k](self, *a, **kw)
+        return f
+
+    out = {}
+    _ffi.Context.call = counted_call
+    for k in readers:
+        setattr(torch.Tensor, k, counting(k))
+    try:
+        for tag, params in (("config2_256x256", grid256_params(experiment__missions__n_agents=4)), ("default_493x493", default_params())):
+            n = params["experiment"]["missions"]["n_agents"]
+            T = params["experiment"]["constraints"]["budget"] + 1
+            np.random.seed(7)
+            torch.manual_seed(7)
+            wrapper = COMAWrapper(params, None, device=device)
+            grid_map = GridMap(params)
+            gen = EpisodeGenerator(params, None, grid_map, Sensor(SensorModel(), grid_map))
+            gen.execute(1, BatchMemory(params, wrapper), wrapper, "train")      # warm-up: library / MIOpen first use
+            torch.cuda.synchronize()
+            count["lib"] = count["d2h"] = 0
+            t0 = time.perf_counter()
+            for ep in range(2, 2 + episodes):
+                memory = BatchMemory(params, wrapper)
+                gen.execute(ep, memory, wrapper, "train")
+                assert memory.size() == T * n
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            steps = episodes * T * n
+            out[tag] = {"agent_env_steps_per_s": steps / dt, "s_per_episode": dt / episodes, "episodes": episodes, "n_agents": n,
+                        "library_calls_per_agent_step": count["lib"] / steps, "device_to_host_reads_per_agent_step": count["d2h"] / steps}
+    finally:
+        _ffi.Context.call = real_call
+        for k in readers:
+            setattr(torch.Tensor, k, real[k])
+    out["what"] = ("EpisodeGenerator.execute through the reference-shaped objects, one env, 'train' mode (actor forward at batch 1 per agent, "
+                   "transitions into BatchMemory); reference: ~10 agent-env steps/s (SURVEY section 6). For throughput use VecEnv / COMATrainer.")
+    return out
 
 
 def spawn_ranks(n: int, ipc_mode: str = "keep", retry: bool = True) -> int:
@@ -207,6 +277,9 @@ def main():
                     "started by `--gpus N` run under: keep = the environment's own value (this image exports 0: the host driver only "
                     "supports dmabuf IPC); if the ranks fail they are started ONCE more with the other setting (--no-ipc-retry: not)")
     ap.add_argument("--no-ipc-retry", dest="ipc_retry", action="store_false")
+    ap.add_argument("--steady-episodes", type=int, default=20, help="whole episodes of the steady-state leg that follows the timed region "
+                    "(exactly one reset per episode; 20 episodes = 300 steps, ~45 ms at config 2)")
+    ap.add_argument("--no-dropin-seam", action="store_true", help="skip the timing of the drop-in object surface (EpisodeGenerator.execute, one env)")
     ap.add_argument("--calib", action="store_true", help="PMC calibration: 3 device-to-device copies of the local maps (known "
                     "bytes read and written by a 16 B/lane streaming kernel) before the timed loop")
     args = ap.parse_args()
@@ -269,7 +342,7 @@ def main():
     if split:   # the batch as sub-batches on their own streams (same envs, same episodes, same results)
         env = SplitVecEnv(params, args.envs, parts=args.streams, device=device, philox_seed=3, terrain=args.terrain, team_sizes=teams)
         # (streams that shared a hardware queue with an earlier one and were swapped; the last side-by-side ratios measured)
-        stream_check = {"redraws": env.stream_redraws, "side_by_side": env.stream_probe}
+        stream_check = {"redraws": env.stream_redraws, "side_by_side": env.stream_probe, "error": env.stream_check_error}
     else:
         stream_check = None
         env = VecEnv(params, args.envs, device=device, philox_seed=3, terrain=args.terrain, track_area=False, team_sizes=teams)
@@ -350,8 +423,8 @@ def main():
     counters = env.counters()
     # Steady state: the timed region above holds however many resets --steps happens to span (the driver's 20 steps: one, i.e. one
     # per 20 steps where an episode has one per 16); any window of whole episodes holds exactly one reset per episode whatever its
-    # phase, so the loop simply goes on for three more episodes' worth of steps under the same barrier / max-over-ranks clock.
-    ss_steps, ss_resets = 3 * T, 0
+    # phase, so the loop simply goes on for --steady-episodes (20) more episodes' worth of steps under the same barrier / max-over-ranks clock.
+    ss_steps, ss_resets = args.steady_episodes * T, 0
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -373,6 +446,8 @@ def main():
         tt = torch.tensor([ss_dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         ss_dt = float(tt[0])
+    after_ss = env.counters()
+    ss_counters = {k: after_ss[k] - counters[k] for k in counters}      # the steady-state leg's own cells
     faults = int(env.fault.abs().sum())        # (SplitVecEnv: joins its streams first)
     grid = [env.d.grid_x, env.d.grid_y]
 
@@ -452,12 +527,18 @@ def main():
     TIMING = ("HIP start/stop events bound to each dispatch (hipExtLaunchKernelGGL): the kernel's own begin-to-end duration, as "
               "rocprofv3's kernel trace reports it; no bracket overhead to subtract, so frac_raw == frac")
 
-    def roofline_entry(pmc_key, what, bytes_per_launch, timed, extra=None):
+    def roofline_entry(pmc_key, what, bytes_per_launch, timed, extra=None, layout_bytes=None):
         if timed is None or not timed["launches"]:
             return None
         us = timed["avg_us"]
         achieved = bytes_per_launch / (us * 1e-6) / 1e9
         traffic = pmc.get(pmc_key, {}).get("hbm_bytes_per_launch") if pmc_ok else None
+        if layout_bytes is not None:
+            # SURVEY 8d's storage model (1 B truth, 1 B code per cell) is the contract `frac` is quoted on; the kernels store truth as
+            # 1 bit per cell and codes as 1 byte per 4-cell group, so what a launch MUST move is less: the honest yardstick for the
+            # kernel's own efficiency and for the PMC traffic (traffic_over_layout_bytes > 1 = re-reads / partial lines)
+            extra = dict(extra or {}, layout_bytes_per_launch=layout_bytes, frac_of_layout_bytes=layout_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                         traffic_over_layout_bytes=(traffic / layout_bytes) if traffic else None)
         out = {"bound": "hbm", "kernel": timed["kernel"], "what": what, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                "frac": achieved / HBM_PEAK_GBS, "frac_raw": achieved / HBM_PEAK_GBS, "traffic": traffic,
                "traffic_source": f"{pmc_path} (static: separate rocprofv3 --pmc passes of this command, not measured in this run)"
@@ -484,7 +565,9 @@ def main():
                                                "the timed region" + (f": the whole batch of {launch_envs} envs per launch on one stream, every launch alone "
                                                f"on the device (a second VecEnv of the same config); the timed region steps {args.streams} sub-batches of "
                                                f"{sub_envs} envs on {args.streams} streams, whose kernels run side by side: overlapped_us = their "
-                                               "durations there, whole_step = what the device as a whole made of the HBM peak" if split else "")})
+                                               "durations there, whole_step = what the device as a whole made of the HBM peak" if split else ""),
+                                   "layout_bytes_per_cell": K3_LAYOUT_BYTES_PER_CELL},
+                                  layout_bytes=K3_LAYOUT_BYTES_PER_CELL * cells)
         if overlapped:
             roofline["overlapped_us"] = {k: round(v["avg_us"], 2) for k, v in overlapped.items() if k in ("sense", "fuse", "plan", "reset_maps", "terrain")}
         # every algorithmic byte of a step of the TIMED region (K3 + fusion; the small plan kernel's ~2.4 MB left out) against
@@ -493,6 +576,12 @@ def main():
         roofline["whole_step"] = {"algorithmic_bytes_per_step": step_bytes, "ms_per_step": 1e3 * dt / args.steps,
                                   "achieved": step_bytes / (dt / args.steps) / 1e9,
                                   "frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS}
+        # (kept under `roofline` as well: the driver's record keeps this object whole, top-level extras only by name)
+        roofline["resets_timed"] = resets_timed
+        roofline["steady_state"] = {"value": flying * ss_steps * world / ss_dt, "unit": "agent-env steps/s", "ms_per_step": 1e3 * ss_dt / ss_steps,
+                                    "steps": ss_steps, "episodes": ss_steps // T, "resets": ss_resets,
+                                    "whole_step_frac": (K3_BYTES_PER_CELL * ss_counters["sense_cells"] + fusion_bytes(ss_counters)) / ss_dt / 1e9 / HBM_PEAK_GBS,
+                                    "note": "the timed loop continued for whole episodes (one reset per episode): the sustained rate"}
         roofline_kernels = [roofline]
     if fuse:
         by = fusion_bytes(rl_counters) / fuse["launches"]
@@ -501,7 +590,9 @@ def main():
             {"algorithmic_bytes": "8 B per cell of the union (R+W once) + 1 B per (cell, message) code read",
              "local_cells_per_launch": rl_counters["fuse_local_cells"] / fuse["launches"],
              "global_cells_per_launch": rl_counters["fuse_global_cells"] / fuse["launches"],
-             "message_cells_per_launch": (rl_counters["fuse_local_ops"] + rl_counters["fuse_global_ops"]) / fuse["launches"]}))
+             "message_cells_per_launch": (rl_counters["fuse_local_ops"] + rl_counters["fuse_global_ops"]) / fuse["launches"]},
+            layout_bytes=(8 * (rl_counters["fuse_local_cells"] + rl_counters["fuse_global_cells"])
+                          + 0.25 * (rl_counters["fuse_local_ops"] + rl_counters["fuse_global_ops"])) / fuse["launches"]))
     if roofline_kernels is not None:
         for cls, what in (("plan", "comm matrix + fusion plans + work list + K1, one wavefront per env"),
                           ("reset", "episode reset: device MT19937 scalars (and, with tracked area sums, the prior fills) per kernel launch"),
@@ -625,6 +716,11 @@ def main():
                                              "transitions_per_update": stats["transitions"], "envs": ref_envs,
                                              "adam_steps_per_update": stats["adam_steps"],
                                              "hip_graphs": "16 rollout-step graphs + 1 update graph per round (COMATrainer.capture_graphs)"}
+    seam = None
+    if rank == 0 and not args.no_dropin_seam and not teams:
+        env = roof_env = first = None
+        torch.cuda.empty_cache()
+        seam = dropin_seam(device)
     # per-rank audit trail: each rank's own clock around the timed region and how its placement search ended, so that a multi-GPU
     # line can be checked rank by rank (value = the units all ranks processed / the slowest rank's time)
     mine = {"rank": rank, "device": torch.cuda.current_device(), "ms_per_step": 1e3 * dt_rank / args.steps,
@@ -657,7 +753,7 @@ def main():
             "ranks": world,
             "resets_timed": resets_timed,
             "steady_state": {"ms_per_step": 1e3 * ss_dt / ss_steps, "value": flying * ss_steps * world / ss_dt, "steps": ss_steps, "resets": ss_resets,
-                             "note": f"the same loop continued for {ss_steps} steps = 3 whole episodes (exactly one reset per {T} steps, as in an "
+                             "note": f"the same loop continued for {ss_steps} steps = {ss_steps // T} whole episodes (exactly one reset per {T} steps, as in an "
                                      f"endless run); `value` above is the driver's window of --steps {args.steps}, which held {resets_timed} reset(s), "
                                      f"i.e. one per {args.steps / max(resets_timed, 1):.1f} steps" + ("" if resets_timed else " (none at all)")
                                      + ": quote steady_state for sustained throughput"},
@@ -671,6 +767,7 @@ def main():
             "roofline_kernels": roofline_kernels,
             "placement": placement, "roofline_leg_placement": roof_placement,
             "coma_training": coma,
+            "dropin_seam": seam,
         }
     if dist:   # every collective is done: the other ranks may leave while rank 0 times the CPU baseline on the host cores
         dist.barrier()

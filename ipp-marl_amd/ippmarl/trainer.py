@@ -385,6 +385,41 @@ class COMATrainer:
         mean = lambda rows: [sum(c) / len(c) for c in zip(*rows)]  # noqa: E731
         return {"episode_return": sum(returns) / len(returns), "target_entropy": mean(ent_curves), "f1": mean(f1_curves)}
 
+    def returns_on(self, episodes, policy: str = "actor") -> Dict[str, float]:
+        """Mean return of ``policy`` over the FIXED ``episodes`` (E ids: same truth, start cells and sensor noise whoever flies them --
+        every random stream is keyed by the episode number), the yardstick of the reference's own comparison (coma_test.py:84-97,
+        random_baseline.py:91-96, IG_baseline.py:127-148):
+          "actor"   the current actor, greedy (argmax of probs * mask: ActorNetwork in "eval" mode, actor/network.py:63-66)
+          "random"  uniform over the valid actions
+          "ig"      the greedy expected-information-gain planner on the agents' local maps (one team size per context)
+        Does not touch the training buffer, the wave counter or epsilon.
+        -> mean relative return ("episode_return": what COMA's reward is made of, utils/reward.py:25-40), mean absolute return, and
+        the final global maps' mean target-region entropy and F1."""
+        from .vec_env import POLICY_EXPLICIT, POLICY_UNIFORM
+        if policy not in ("actor", "random", "ig"):
+            raise ValueError(f"unknown policy {policy!r}")
+        env = self.env
+        env.reset(torch.as_tensor(episodes, dtype=torch.int64).reshape(self.E))
+        ret = torch.zeros(self.E, device=self.device)
+        abs_ret = torch.zeros(self.E, device=self.device)
+        for t in range(self.T):
+            if policy == "actor":
+                obs = env.build_observations(t)
+                with torch.no_grad():
+                    probs, _ = self.actor(obs.view(self.E * self.N, 11, 11, 7), self.eps_dev if self.graphs else self.eps)
+                reward, _, _ = env.steps(t, policy=POLICY_ARGMAX, probs=probs.view(self.E, self.N, self.A), features=False)
+            elif policy == "ig":
+                env.build_observations(t, features=False)
+                reward, _, _ = env.steps(t, policy=POLICY_EXPLICIT, actions=env.ig_actions(communication=True), features=False)
+            else:
+                env.build_observations(t, features=False)
+                reward, _, _ = env.steps(t, policy=POLICY_UNIFORM, features=False)
+            ret += reward[:, 0]
+            abs_ret += reward[:, 1]
+        ent, f1 = self.map_metrics(self.global_map_with_pending())
+        return {"episode_return": float(ret.mean()), "absolute_return": float(abs_ret.mean()), "return_std": float(ret.std()),
+                "final_target_entropy": float(ent.mean()), "final_f1": float(f1.mean()), "faults": int(env.fault.ne(0).sum())}
+
     def save_actor(self, path: str):
         """Whole-module pickle of the actor, the reference's checkpoint format (coma_mission.py:425-451)."""
         from .checkpoint import save_actor

@@ -609,6 +609,7 @@ class SplitVecEnv:
         self.sizes = [base + (1 if k < extra else 0) for k in range(parts)]
         self.offsets = [sum(self.sizes[:k]) for k in range(parts)]
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(parts)]
+        self.stream_check_error = None     # why the side-by-side check of the streams could not run (None: it ran, or was not needed)
         self.stream_redraws, self.stream_probe = self._spread_streams()
         ts = None if team_sizes is None else [int(v) for v in team_sizes]
         self.parts = []
@@ -662,8 +663,8 @@ class SplitVecEnv:
                         break
                     self.streams[k] = torch.cuda.Stream(device=self.device)
                     redraws += 1
-        except Exception:               # the check is an optimisation: never in the way of the env
-            return redraws, ratios
+        except RuntimeError as exc:     # a HIP error of the spin kernel / the timing: the env works without the check, but says so --
+            self.stream_check_error = f"{type(exc).__name__}: {exc}"   # its streams may share a queue (bench: config.stream_check.error)
         return redraws, ratios
 
     def _each(self):
