@@ -250,6 +250,8 @@ def main():
                     "kernels of the other -- 0.1526 -> 0.141 ms per step at config 2; 1 = one stream, one launch per kernel and step; "
                     "0 (default) = 2, or 3 where the envs' work differs many-fold (--episode-comm-range, --team-sizes: 1.09 / 1.13 / 1.32 M "
                     "agent-env steps/s on 1 / 2 / 3 streams at config 5's shape)")
+    ap.add_argument("--no-stagger", dest="stagger", action="store_false", help="sub-batches in lock step (round 5's loop) instead of each in its "
+                    "own phase of the episode (part k runs k * T / parts steps ahead, so that at most one part resets at any step)")
     ap.add_argument("--team-sizes", default=None, help="comma-separated team sizes dealt out to the envs in turn (BASELINE config 5's mixed teams, "
                     "e.g. 2,4,8,16 with --agents 16): env e flies team_sizes[e %% len] of the --agents UAVs; agent-env steps count the flying ones")
     ap.add_argument("--comm-range", type=float, default=None, help="experiment.uav.communication_range in metres (default: params.yaml's 25)")
@@ -294,6 +296,7 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks (WORLD_SIZE)")
     dist = None
+    placement_note = None
     if args.rendezvous_only:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -325,6 +328,11 @@ def main():
                                  "relaunch with the other setting (`python bench.py --gpus N` does that by itself, once)")
         else:
             dist.init_process_group(args.dist_backend)
+        if world > n_dev and args.placement_draws > 1:
+            # ranks share a device (a gloo dry run of the control flow): their placement searches would time each other's kernels
+            # and hold candidate arenas side by side on one card -- no search, the allocator's first arena is kept
+            args.placement_draws = 1
+            placement_note = f"skipped: {world} ranks share {n_dev} device(s)"
         local_rank %= n_dev
     device = f"cuda:{local_rank}"
     torch.cuda.set_device(device)
@@ -368,15 +376,35 @@ def main():
             # region: every reset of the timed loop is followed by one synthesis); the reset then copies 8 MB of packed truth
             env.prefetch_terrain(episode_ids(1, wave[0], E, rank, world))
 
-    def one_step(t):
-        if args.graphs:
-            env.step_graphed(t)
-        elif split:
-            env.steps(t, policy=POLICY_UNIFORM)
-        else:
-            env.steps(t, policy=POLICY_UNIFORM, features=False)
+    state = {"t": 0}
 
-    reset()
+    def run(n):
+        """n env steps of the whole batch, resets included; -> resets of the whole batch among them (a sub-batch's reset counts as
+        its share: with staggered sub-batches the parts reset at different steps)."""
+        if split:        # SplitVecEnv owns the episode loop: every part in its own phase of the episode
+            r0 = env.part_resets
+            for _ in range(n):
+                env.advance(POLICY_UNIFORM)
+            return (env.part_resets - r0) / args.streams
+        resets = 0
+        for _ in range(n):
+            if args.graphs:
+                env.step_graphed(state["t"])
+            else:
+                env.steps(state["t"], policy=POLICY_UNIFORM, features=False)
+            state["t"] += 1
+            if state["t"] == T:
+                resets += 1
+                reset()
+                state["t"] = 0
+        return resets
+
+    if split:
+        # part k flies its slice of every wave; staggered (default): part k starts k * T / parts steps ahead, so that at most one
+        # sub-batch resets at any step (the steps taken ahead are part of the untimed start)
+        env.start(lambda w: episode_ids(1, w, E, rank, world), stagger=args.stagger)
+    else:
+        reset()
     if args.graphs:
         env.capture_step_graphs(POLICY_UNIFORM)
     scratch = torch.empty_like(first.local)
@@ -389,27 +417,14 @@ def main():
         for _ in range(3):
             stream_copy()
         torch.cuda.synchronize()
-    t_in_ep = 0
-    for _ in range(args.warmup):
-        one_step(t_in_ep)
-        t_in_ep += 1
-        if t_in_ep == T:
-            reset()
-            t_in_ep = 0
+    run(args.warmup)
     env.counters(reset=True)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    resets_timed = 0
-    for _ in range(args.steps):
-        one_step(t_in_ep)
-        t_in_ep += 1
-        if t_in_ep == T:
-            resets_timed += 1
-            reset()
-            t_in_ep = 0
+    resets_timed = run(args.steps)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -430,13 +445,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     s0 = time.perf_counter()
-    for _ in range(ss_steps):
-        one_step(t_in_ep)
-        t_in_ep += 1
-        if t_in_ep == T:
-            ss_resets += 1
-            reset()
-            t_in_ep = 0
+    ss_resets = run(ss_steps)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -464,22 +473,17 @@ def main():
             # on one stream (roof_env), every launch alone on the device -- the kernel's own rate, the figure rocprofv3 reports for
             # the same launches (tools/loop_stats.py and tools/pmc_summary.py tell the stretches apart by the marker copies of --calib).
             env.profile = True
-            for _ in range(2 * T):
-                one_step(t_in_ep)
-                t_in_ep += 1
-                if t_in_ep == T:
-                    reset()
-                    t_in_ep = 0
+            run(2 * T)
             env.profile = False
             ov = env.event_times_us()
             overlapped = {k: {"avg_us": v["avg_us"], "launches": v["launches"]} for k, v in ov.items()}
             torch.cuda.synchronize()
         # the leg itself: whole episodes of the whole batch on ONE stream (roof_env is env itself with --streams 1)
-        t_leg = t_in_ep if roof_env is env else 0
+        leg_wave = [1 << 16]       # (the leg's own episodes, far from the waves the loops above flew)
 
         def leg_reset():
-            roof_env.reset(episode_ids(1, wave[0], E, rank, world))
-            wave[0] += 1
+            roof_env.reset(episode_ids(1, leg_wave[0], E, rank, world))
+            leg_wave[0] += 1
 
         if roof_env is not env:
             leg_reset()
@@ -493,19 +497,17 @@ def main():
                 torch.cuda.synchronize()
         roof_env.counters(reset=True)
         roof_env.profile = True
-        for _ in range(args.roofline_steps):
-            if roof_env is env:
-                one_step(t_leg)
-            else:
+        if roof_env is env:
+            rl_resets = run(args.roofline_steps)
+        else:
+            t_leg = 0
+            for _ in range(args.roofline_steps):
                 roof_env.steps(t_leg, policy=POLICY_UNIFORM, features=False)
-            t_leg += 1
-            if t_leg == T:
-                rl_resets += 1
-                if roof_env is env:
-                    reset()
-                else:
+                t_leg += 1
+                if t_leg == T:
+                    rl_resets += 1
                     leg_reset()
-                t_leg = 0
+                    t_leg = 0
         roof_env.profile = False
         times = roof_env.event_times_us()
         rl_counters = roof_env.counters()
@@ -723,7 +725,10 @@ def main():
         seam = dropin_seam(device)
     # per-rank audit trail: each rank's own clock around the timed region and how its placement search ended, so that a multi-GPU
     # line can be checked rank by rank (value = the units all ranks processed / the slowest rank's time)
-    mine = {"rank": rank, "device": torch.cuda.current_device(), "ms_per_step": 1e3 * dt_rank / args.steps,
+    free_b, total_b = torch.cuda.mem_get_info()
+    mine = {"rank": rank, "device": torch.cuda.current_device(), "peak_allocated_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 3),
+            "device_memory_in_use_GB": round((total_b - free_b) / 2 ** 30, 2), "placement_note": placement_note,
+            "ms_per_step": 1e3 * dt_rank / args.steps,
             "agent_env_steps_per_s": flying * args.steps / dt_rank,
             "placement_stopped": [(p or {}).get("stopped") for p in (placement if isinstance(placement, list) else [placement])],
             "placement_draws": [(p or {}).get("draws") for p in (placement if isinstance(placement, list) else [placement])]}
@@ -746,7 +751,7 @@ def main():
             "config": {"workload": ("BASELINE.json configs[1]: " if is_c1 else "NOT the metric's config (a parity-test shape): ") + shape,
                        "envs_per_gpu": E, "n_agents": N, "grid": grid,
                        "episode_steps": T, "terrain": args.terrain, "parallelism": f"env-sharded x{world} (no data-path collective)",
-                       "streams": args.streams if split else 1, "envs_per_launch": sub_envs,
+                       "streams": args.streams if split else 1, "staggered_episodes": bool(split and args.stagger), "envs_per_launch": sub_envs,
                        "launches_per_step": 3 * (args.streams if split else 1), "stream_check": stream_check, "hip_graphs": bool(args.graphs),
                        "roofline_steps": args.roofline_steps,
                        "terrain_prefetch": bool(args.terrain_prefetch and args.terrain == "random_field")},

@@ -667,13 +667,15 @@ class SplitVecEnv:
             self.stream_check_error = f"{type(exc).__name__}: {exc}"   # its streams may share a queue (bench: config.stream_check.error)
         return redraws, ratios
 
-    def _each(self):
-        """(part, its slice of the batch) with the part's stream current and ordered behind the caller's stream."""
-        cur = torch.cuda.current_stream(self.device)
-        entered = torch.cuda.Event()
-        entered.record(cur)
+    def _each(self, ordered: bool = True):
+        """(part, its slice of the batch) with the part's stream current and (``ordered``) behind the caller's stream."""
+        if ordered:
+            cur = torch.cuda.current_stream(self.device)
+            entered = torch.cuda.Event()
+            entered.record(cur)
         for k, env in enumerate(self.parts):
-            self.streams[k].wait_event(entered)
+            if ordered:
+                self.streams[k].wait_event(entered)
             with torch.cuda.stream(self.streams[k]):
                 yield env, slice(self.offsets[k], self.offsets[k] + self.sizes[k])
 
@@ -695,6 +697,41 @@ class SplitVecEnv:
         """One env step of every part (plan -> fusion -> K3 on its stream); nothing is returned: ``join()``, then read ``reward``."""
         for env, sl in self._each():
             env.steps(t, policy=policy, actions=None if actions is None else actions[sl], features=False)
+
+    # -- the episode loop, owned by the split: every part in its own phase of the episode -----------------------------
+    def start(self, episodes_of_wave, stagger: bool = True, policy: int = POLICY_UNIFORM):
+        """Begins an endless run of whole episodes: ``episodes_of_wave(w)`` -> the E episode ids of wave w (part k flies its slice of
+        every wave), then ``advance()`` steps every part once and resets a part that has finished its episode to its next wave.
+        ``stagger``: part k starts k * T / parts steps AHEAD of part 0 (those steps are taken here), so that from then on at most one
+        part resets at any step and its reset -- a write-only fill and the issue-bound terrain passes, 387 us at config 2 -- runs
+        beside the other parts' map kernels instead of beside the other parts' resets.  Every episode is the same episode as in any
+        other batching (the streams of an episode are keyed by its number): only WHEN it is flown changes."""
+        T = self.d.budget + 1
+        self._episodes_of_wave = episodes_of_wave
+        self._phase = [0] * len(self.parts)        # the step each part takes next
+        self._wave = [0] * len(self.parts)         # the wave each part is flying
+        self.part_resets = 0                       # resets of single parts so far (the whole batch has reset part_resets / parts times)
+        for k, (env, sl) in enumerate(self._each()):
+            env.reset(torch.as_tensor(episodes_of_wave(0), dtype=torch.int64).reshape(self.E)[sl])
+            self.part_resets += 1
+            if stagger:
+                for _ in range(k * T // len(self.parts)):
+                    env.steps(self._phase[k], policy=policy, features=False)
+                    self._phase[k] += 1
+
+    def advance(self, policy: int = POLICY_UNIFORM):
+        """One env step of every part at its own step of the episode; a part whose episode is over starts its next wave."""
+        T = self.d.budget + 1
+        # (not ordered behind the caller's stream again at every step: start() was, and nothing but the parts' own streams touches
+        #  their state in between -- an event and a wait per part and step are barrier packets in front of every plan kernel)
+        for k, (env, sl) in enumerate(self._each(ordered=False)):
+            env.steps(self._phase[k], policy=policy, features=False)
+            self._phase[k] += 1
+            if self._phase[k] == T:
+                self._wave[k] += 1
+                env.reset(torch.as_tensor(self._episodes_of_wave(self._wave[k]), dtype=torch.int64).reshape(self.E)[sl])
+                self._phase[k] = 0
+                self.part_resets += 1
 
     def tune_placement(self, draws: int = 24):
         return [env.tune_placement(draws) for env, _ in self._each()]

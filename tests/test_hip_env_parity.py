@@ -650,6 +650,44 @@ def test_split_batch_on_two_streams_equals_the_batch():
         assert int(split.fault.abs().sum()) == 0
 
 
+@pytest.mark.parametrize("parts", [2, 3])
+def test_staggered_sub_batches_fly_the_same_episodes(parts):
+    """SplitVecEnv.start / advance (bench.py's default loop): every part in its own phase of the episode -- part k runs k * T / parts
+    steps ahead, so that at most one part resets at any step -- flies, bit for bit, the episodes one VecEnv flies: after any number
+    of advances, part k's envs hold wave w_k of their episodes at step t_k, exactly as a whole-batch VecEnv reset to wave w_k and
+    stepped t_k times holds them (maps, positions, actions, rewards; uneven split, mixed team sizes, resets in the middle)."""
+    from ippmarl.vec_env import SplitVecEnv, POLICY_UNIFORM
+    params = make_params("small", experiment__uav__fix_range=False, experiment__uav__failure_rate=0.2)
+    teams = [4, 2, 3, 4, 1, 4, 2]
+    E = len(teams)
+    ids = lambda wave: np.arange(5, 5 + E) + 50 * wave      # noqa: E731
+    one = _env(params, E, track_area=False, terrain="random_field", team_sizes=teams)
+    split = SplitVecEnv(params, E, parts=parts, terrain="random_field", team_sizes=teams)
+    T = one.d.budget + 1
+    split.start(ids, stagger=True)
+    assert split._phase == [k * T // parts for k in range(parts)] and split.part_resets == parts
+    done = 0
+    for advances in (1, T // 2, T):                  # looked at after 1, T/2 + 1 and 3T/2 + 1 advances: every part passes a reset
+        for _ in range(advances):
+            split.advance()
+        done += advances
+        split.join()
+        for k, (env, off, n) in enumerate(zip(split.parts, split.offsets, split.sizes)):
+            ahead = k * T // parts + done
+            assert (split._wave[k], split._phase[k]) == (ahead // T, ahead % T)
+            one.reset(ids(split._wave[k]))
+            r1 = None
+            for t in range(split._phase[k]):
+                r1, _, _ = one.steps(t, policy=POLICY_UNIFORM, features=False)
+            sl = slice(off, off + n)
+            assert torch.equal(env.pos, one.pos[sl]) and torch.equal(env.local, one.local[sl]) and torch.equal(env.glob, one.glob[sl]), (k, done)
+            assert torch.equal(env.code, one.code[sl]) and torch.equal(env.episode, one.episode[sl]), (k, done)
+            if r1 is not None:
+                assert torch.equal(env.action, one.action[sl]) and torch.equal(env.reward, r1[sl]), (k, done)
+    assert split.part_resets == parts + sum(split._wave)
+    assert int(split.fault.abs().sum()) == 0
+
+
 @pytest.mark.parametrize("prior", [0.5, 0.3])
 def test_tile_fusion_xcd_rotation_changes_nothing(prior):
     """The tile fusion deals an env's wavefronts out over the eight XCDs by rotating the env index with the wavefront index when the

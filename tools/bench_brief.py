@@ -15,6 +15,8 @@ try:
         print("whole_step", d["roofline"].get("whole_step"))
     print("coma", d.get("coma_training"))
     print("collective", d.get("collective"))
+    print("dropin_seam", d.get("dropin_seam"))
+    print("placement", [(p or {}).get("map_kernels_us_per_step") for p in (d.get("placement") if isinstance(d.get("placement"), list) else [d.get("placement")])])
     print("cpu_baseline", (d.get("cpu_baseline") or {}).get("value"))
 except Exception as e:   # noqa: BLE001
     print("bench parse failed:", e)

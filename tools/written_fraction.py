@@ -29,3 +29,13 @@ l=loc.view(1024,4,16,16,8,32).any(dim=3).any(dim=-1); g=glo.view(1024,16,16,8,32
 print("16x32 blocks dirty: local", float(l.float().mean()), "global", float(g.float().mean()))
 l=loc.view(1024,4,256,4,64).any(dim=-1); g=glo.view(1024,256,4,64).any(dim=-1)
 print("row x 64-col segments dirty: local", float(l.float().mean()), "global", float(g.float().mean()))
+# round 6: what a fill by (map, slab of R rows, ONE column interval) would write -- the hull of the written columns per slab
+def slab_interval_fraction(w, R):
+    # w: bool [..., 256, 256]
+    s = w.reshape(*w.shape[:-2], 256 // R, R, 256).any(dim=-2)            # [..., slabs, cols]
+    cols = torch.arange(256, device=w.device)
+    lo = torch.where(s, cols, torch.full_like(cols, 1 << 20)).amin(dim=-1)
+    hi = torch.where(s, cols + 1, torch.zeros_like(cols)).amax(dim=-1)
+    return float((hi - lo).clamp_min(0).float().mean() / 256.0)
+for R in (64, 32, 16, 8):
+    print(f"{R}-row slab x one column interval: local", slab_interval_fraction(loc, R), "global", slab_interval_fraction(glo, R))
