@@ -253,6 +253,12 @@ __device__ __forceinline__ void ippm_footprint_rect(const ippm_config* c, int px
   clipped[1] = min(max(yd, 0), gy1);
   clipped[2] = min(max(xl, 0), gx1);
   clipped[3] = min(max(xr, 0), gx1);
+#ifdef IPPM_X_ALIGN_FOOTPRINTS   // measurement-only variant (make VARIANT=alignfp EXTRA=-DIPPM_X_ALIGN_FOOTPRINTS=32): every footprint is
+  {                              // shifted left onto a multiple of that many cells (32 cells = one 128-byte line), same size -- what the
+    const int sh = clipped[0] % IPPM_X_ALIGN_FOOTPRINTS;   // map kernels would take if footprint rows started on line boundaries
+    clipped[0] -= sh; clipped[1] -= sh;
+  }
+#endif
 }
 
 
