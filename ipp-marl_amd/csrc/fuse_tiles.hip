@@ -31,6 +31,18 @@ typedef unsigned ippm_t_u4 __attribute__((ext_vector_type(4)));
 #define IPPM_T_STORE_AUX 0
 #endif
 #define IPPM_T_FAR (-(1 << 20))   // column of a lane-load past the item's end: no op covers it
+// measurement-only variants (make VARIANT=... EXTRA=-DIPPM_X_...; results are wrong on purpose): what the launch takes without the
+// reward arithmetic (IPPM_X_NOREWARD), without the per-op clip-and-add (IPPM_X_NOCHAIN), without the code-byte loads (IPPM_X_NOCODE)
+#ifdef IPPM_X_NOREWARD
+#define IPPM_X_REWARD false
+#else
+#define IPPM_X_REWARD true
+#endif
+#ifdef IPPM_X_NOCODE
+#define IPPM_X_CODE(load) 0u
+#else
+#define IPPM_X_CODE(load) (load)
+#endif
 
 __device__ __forceinline__ int t_lane_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ float t_lane_f(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
@@ -162,7 +174,7 @@ __device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e,
 #pragma unroll
   for (int q = 0; q < SLOTS; ++q)
 #pragma unroll
-    for (int k = 0; k < NA; ++k) cw[q][k] = __builtin_amdgcn_raw_buffer_load_b8(rcode, coff[q] + cs[k], 0, 0);
+    for (int k = 0; k < NA; ++k) cw[q][k] = IPPM_X_CODE(__builtin_amdgcn_raw_buffer_load_b8(rcode, coff[q] + cs[k], 0, 0));
   // ---- the ordered clamp/add chain (mappings.py:80-124 in log-odds): every op clips its input over the whole grid
   // (mappings.py:110-111), then adds the measurement's log-odds inside its footprint; the outputs of the plan's last op stay
   // unclamped (its rectangle is remembered as possibly out of range), every other cell was clipped again by a later op.
@@ -185,11 +197,15 @@ __device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e,
       keepm = k == keep_slot ? cm : keepm;
       opcells += (lm0 != 0.f || lm1 != 0.f) ? __popc(cm) : 0;
       const uint32_t cwk = cw[q][k];
+#ifndef IPPM_X_NOCHAIN
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float lm = ippm_masked(ippm_bitmask(cm, j), ippm_blend(ippm_bitmask(cwk, j), lm1, lm0));
         L[j] = ippm_clampl(L[j], w.lc) + lm;
       }
+#else
+      L[0] += __uint_as_float(cwk & 1u);   // (the code byte stays live)
+#endif
     }
     cells += __popc(touched);
     float out[4];
@@ -218,7 +234,7 @@ __device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e,
       }
     }
     if (TRACK) tile_area_slot<MIS>(w, x0 + ippm_div_small(gs + q * 64 + w.lane, inv_w), ycol[q] == IPPM_T_FAR ? 0 : ycol[q], mv[q].v, out);
-    if (is_global) {
+    if (IPPM_X_REWARD && is_global) {
       // information-gain terms (utils/reward.py:68-82) of the cells the step changed; an untouched cell contributes exact zeros
       // (same weight, same entropy).  Slots whose touched cells all have weight 0 before and after (believed free, still
       // believed free) skip the entropies: wave-uniform on spatially coherent terrain.
@@ -299,7 +315,7 @@ __device__ __forceinline__ void tile_item_long(const TileCtx& w, TileAcc& acc, i
     o.lm1 = isf ? __int_as_float(b.w) : 0.f;
     const int cs = isf ? (e * w.n + a.y) * w.TB - b.y * w.row_bytes - (a.w >> 2) : 0;
 #pragma unroll
-    for (int q = 0; q < SLOTS; ++q) o.cw[q] = __builtin_amdgcn_raw_buffer_load_b8(rcode, coff[q] + cs, 0, 0);
+    for (int q = 0; q < SLOTS; ++q) o.cw[q] = IPPM_X_CODE(__builtin_amdgcn_raw_buffer_load_b8(rcode, coff[q] + cs, 0, 0));
   };
   OpIn cur, nxt;
   fetch(cur);
@@ -321,11 +337,15 @@ __device__ __forceinline__ void tile_item_long(const TileCtx& w, TileAcc& acc, i
       touched[q] |= cm;
       keepm[q] = is_last ? cm : keepm[q];
       opcells += (cur.lm0 != 0.f || cur.lm1 != 0.f) ? __popc(cm) : 0;
+#ifndef IPPM_X_NOCHAIN
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float lm = ippm_masked(ippm_bitmask(cm, j), ippm_blend(ippm_bitmask(cur.cw[q], j), cur.lm1, cur.lm0));
         L[q][j] = ippm_clampl(L[q][j], w.lc) + lm;
       }
+#else
+      L[q][0] += __uint_as_float(cur.cw[q] & 1u);
+#endif
     }
     if (!more) break;
     cur = nxt;
@@ -352,7 +372,7 @@ __device__ __forceinline__ void tile_item_long(const TileCtx& w, TileAcc& acc, i
       }
     }
     if (TRACK) tile_area_slot<MIS>(w, x0 + ippm_div_small(gs + q * 64 + w.lane, inv_w), ycol[q] == IPPM_T_FAR ? 0 : ycol[q], mv[q].v, out);
-    if (is_global) {   // the reward terms, as in tile_item
+    if (IPPM_X_REWARD && is_global) {   // the reward terms, as in tile_item
       float wa[4], wb[4], wsum = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {

@@ -198,13 +198,18 @@ __global__ __launch_bounds__((FourStep<N1, N2, Q>::THREADS)) void k_terrain_fft_
                                                                                const float2* __restrict__ spec,
                                                                                float2* __restrict__ work,
                                                                                uint32_t* __restrict__ range_keys,
-                                                                               const float2* __restrict__ roots1024) {
+                                                                               const float2* __restrict__ roots1024, int key_stride) {
   __shared__ FourStep<N1, N2, Q> fs;
   const int e = blockIdx.y, gx = N1 * N2, gy = c->grid_y, hy = gy / 2 + 1, tid = threadIdx.x;
   const bool edge_wg = blockIdx.x == gridDim.x - 1;
   if (range_keys && blockIdx.x == 0 && tid == 0) {   // pass Y accumulates the field's (min, max) here
-    range_keys[2 * e] = 0xFFFFFFFFu;
-    range_keys[2 * e + 1] = 0u;
+    range_keys[key_stride * e] = 0xFFFFFFFFu;
+    range_keys[key_stride * e + 1] = 0u;
+    if (key_stride == 4) {    // the one-launch form of pass Y (MODE 3): its workgroups' arrivals per env, the env's fault word, and
+      range_keys[4 * e + 2] = 0u;                    // (behind the last env's record) the launch's ticket counter
+      range_keys[4 * e + 3] = 0u;
+      if (e == 0) range_keys[4 * gridDim.y] = 0u;
+    }
   }
   fs.init_twiddles(roots1024);
   const int q_in = tid % Q, i2 = tid / Q, k1 = tid % N1, q_out = tid / N1;
@@ -260,10 +265,26 @@ __global__ __launch_bounds__((FourStep<N1, N2, Q>::THREADS)) void k_terrain_fft_
                                                                                float* __restrict__ field,
                                                                                uint32_t* __restrict__ range_keys,
                                                                                const float2* __restrict__ roots1024,
-                                                                               uint32_t* __restrict__ truth32, int truth_words) {
+                                                                               uint32_t* __restrict__ truth32, int truth_words, int key_stride) {
   __shared__ FourStep<N1, N2, Q> fs;
-  const int e = blockIdx.y, gx = c->grid_x, gy = N1 * N2, hy = gy / 2 + 1, x0 = blockIdx.x * 2 * Q, tid = threadIdx.x;
-  fs.init_twiddles(roots1024);
+  const int tid = threadIdx.x, gx = c->grid_x, gy = N1 * N2, hy = gy / 2 + 1;
+  int e = blockIdx.y, part = blockIdx.x;
+  __shared__ uint32_t s_ticket;
+  if (MODE == 3) {
+    // One launch for (min, max) AND the threshold bits: the workgroups of an env meet at a counter once their rows are in
+    // registers.  Waiting for a workgroup that has not started yet would hang the device, so which (env, rows) a workgroup takes
+    // follows the ORDER IN WHICH WORKGROUPS START (a ticket), not its index: the tickets taken so far are exactly the workgroups
+    // that have started, every env below the one in progress is complete and leaves, and its slots go to the next tickets --
+    // whatever order the hardware dispatches in.  (The ticket's round trip runs beside the twiddle loads below.)
+    if (tid == 0) s_ticket = atomicAdd(range_keys + 4 * gridDim.y, 1u);
+  }
+  fs.init_twiddles(roots1024);     // (ends with a workgroup barrier)
+  if (MODE == 3) {
+    const uint32_t tk = s_ticket;
+    e = (int)(tk / gridDim.x);
+    part = (int)(tk - (uint32_t)e * gridDim.x);
+  }
+  const int x0 = part * 2 * Q;
   const int q_in = tid % Q, i2 = tid / Q, k1 = tid % N1, q_out = tid / N1;
   const bool in_active = i2 < N2, out_active = q_out < Q;
   float2 v[N1], o[N2];
@@ -280,11 +301,62 @@ __global__ __launch_bounds__((FourStep<N1, N2, Q>::THREADS)) void k_terrain_fft_
     }
   }
   fs.run(v, o, q_in, i2, in_active, q_out, k1, out_active);
-  if (MODE == 2) {
+  if (MODE != 2) {
+    float lo = INFINITY, hi = -INFINITY;
+    if (out_active) {
+      float* dst = field + ((size_t)e * gx + x0 + 2 * q_out) * gy + k1;
+#pragma unroll
+      for (int k2 = 0; k2 < N2; ++k2) {
+        if (MODE == 0) {
+          dst[N1 * k2] = o[k2].x;
+          dst[(size_t)gy + N1 * k2] = o[k2].y;
+        }
+        lo = fminf(lo, fminf(o[k2].x, o[k2].y));
+        hi = fmaxf(hi, fmaxf(o[k2].x, o[k2].y));
+      }
+    }
+    if (range_keys) {   // wavefront, then workgroup reduction; one atomic pair per workgroup
+#pragma unroll
+      for (int m = 32; m > 0; m >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, m, 64));
+        hi = fmaxf(hi, __shfl_xor(hi, m, 64));
+      }
+      __shared__ float s_lo[8], s_hi[8];
+      constexpr int NW = FourStep<N1, N2, Q>::THREADS / 64;
+      if ((tid & 63) == 0) { s_lo[tid >> 6] = lo; s_hi[tid >> 6] = hi; }
+      __syncthreads();
+      if (tid == 0) {
+        for (int w = 1; w < NW; ++w) { lo = fminf(lo, s_lo[w]); hi = fmaxf(hi, s_hi[w]); }
+        atomicMin(range_keys + key_stride * e, order_key(lo));
+        atomicMax(range_keys + key_stride * e + 1, order_key(hi));
+        if (MODE == 3) {
+          // my (min, max) are in before my arrival is; then wait for the env's other workgroups (all of them have started: ticket
+          // order).  The spin is bounded all the same: a wait that long means the premise broke -- word 3 of the env's record then
+          // says so (0xDEADxxxx; tests and VecEnv.check_faults look at it) and the workgroup goes on with what there is.
+          __threadfence();
+          __hip_atomic_fetch_add(range_keys + 4 * e + 2, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+          unsigned spins = 0;
+          while (__hip_atomic_load(range_keys + 4 * e + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1u << 24)) {
+              __hip_atomic_store(range_keys + 4 * e + 3, 0xDEAD0000u | (unsigned)part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              break;
+            }
+          }
+        }
+      }
+    }
+    if (MODE != 3) return;
+    __syncthreads();     // the env's (min, max) are final
+  }
+  {
     // threshold and pack: for one k2 a wavefront holds columns k1 + N1 k2 of 64 / N1 rows, i.e. N1 consecutive bits of each of
     // those rows' bit strings; lane L < 64 / N1 collects row L's chunks into 32-bit words and stores every completed word
     static_assert(N1 == 8 || N1 == 16 || N1 == 32, "a chunk must not straddle a 32-bit word");
-    const float lo = key_value(range_keys[2 * e]), span = key_value(range_keys[2 * e + 1]) - lo;
+    // (MODE 3: written by other workgroups of this launch, possibly on other XCDs -- read at device scope, not from a stale line)
+    const uint32_t key_lo = MODE == 3 ? __hip_atomic_load(range_keys + key_stride * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : range_keys[key_stride * e];
+    const uint32_t key_hi = MODE == 3 ? __hip_atomic_load(range_keys + key_stride * e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : range_keys[key_stride * e + 1];
+    const float lo = key_value(key_lo), span = key_value(key_hi) - lo;
     const int lane = tid & 63, rows_per_wave = 64 / N1;
     const int my_q = (tid >> 6) * rows_per_wave + lane;          // the row (slot) this lane stores for, if lane < rows_per_wave
     const bool storer = lane < rows_per_wave && my_q < Q;
@@ -303,36 +375,6 @@ __global__ __launch_bounds__((FourStep<N1, N2, Q>::THREADS)) void k_terrain_fft_
         if (storer) { out[row_a + ((k2 * N1) >> 5)] = wa; out[row_b + ((k2 * N1) >> 5)] = wb; }
         wa = 0; wb = 0;
       }
-    }
-    return;
-  }
-  float lo = INFINITY, hi = -INFINITY;
-  if (out_active) {
-    float* dst = field + ((size_t)e * gx + x0 + 2 * q_out) * gy + k1;
-#pragma unroll
-    for (int k2 = 0; k2 < N2; ++k2) {
-      if (MODE == 0) {
-        dst[N1 * k2] = o[k2].x;
-        dst[(size_t)gy + N1 * k2] = o[k2].y;
-      }
-      lo = fminf(lo, fminf(o[k2].x, o[k2].y));
-      hi = fmaxf(hi, fmaxf(o[k2].x, o[k2].y));
-    }
-  }
-  if (range_keys) {   // wavefront, then workgroup reduction; one atomic pair per workgroup
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) {
-      lo = fminf(lo, __shfl_xor(lo, m, 64));
-      hi = fmaxf(hi, __shfl_xor(hi, m, 64));
-    }
-    __shared__ float s_lo[8], s_hi[8];
-    constexpr int NW = FourStep<N1, N2, Q>::THREADS / 64;
-    if ((tid & 63) == 0) { s_lo[tid >> 6] = lo; s_hi[tid >> 6] = hi; }
-    __syncthreads();
-    if (tid == 0) {
-      for (int w = 1; w < NW; ++w) { lo = fminf(lo, s_lo[w]); hi = fmaxf(hi, s_hi[w]); }
-      atomicMin(range_keys + 2 * e, order_key(lo));
-      atomicMax(range_keys + 2 * e + 1, order_key(hi));
     }
   }
 }
@@ -501,16 +543,16 @@ extern "C" int ippm_terrain_spectrum(ippm_ctx* ctx, const int64_t* episode, cons
 }
 
 static int terrain_launch_x(ippm_ctx* ctx, const int64_t* episode, const float* amp, const float2* spec2, float2* work2,
-                            uint32_t* range_keys, int n_envs, hipStream_t st) {
+                            uint32_t* range_keys, int n_envs, hipStream_t st, int key_stride = 2) {
   const int gx = ctx->cfg.grid_x, gy = ctx->cfg.grid_y;
   // generic columns 1 .. gy/2 - 1 in workgroups of Q, then one workgroup for the self-mirrored columns 0 and gy/2
 #define LAUNCH_X(N1, N2, Q)                                                                                                  \
   {                                                                                                                          \
     const dim3 grid((gy / 2 - 1 + Q - 1) / Q + 1, n_envs), block(FourStep<N1, N2, Q>::THREADS);                              \
     if (spec2) IPPM_LAUNCH(ctx, IPPM_T_TERRAIN, (k_terrain_fft_x<N1, N2, Q, false>), grid, block, st, ctx->dcfg, episode, amp, spec2, work2, \
-                           range_keys, ctx->d_roots);                                                                        \
+                           range_keys, ctx->d_roots, key_stride);                                                            \
     else IPPM_LAUNCH(ctx, IPPM_T_TERRAIN, (k_terrain_fft_x<N1, N2, Q, true>), grid, block, st, ctx->dcfg, episode, amp, spec2, work2,        \
-                     range_keys, ctx->d_roots);                                                                              \
+                     range_keys, ctx->d_roots, key_stride);                                                                  \
   }
   TERRAIN_DISPATCH(gx, LAUNCH_X)
 #undef LAUNCH_X
@@ -520,11 +562,12 @@ static int terrain_launch_x(ippm_ctx* ctx, const int64_t* episode, const float* 
 
 template <int MODE>
 static int terrain_launch_y(ippm_ctx* ctx, const float2* work2, float* field, uint32_t* range_keys, uint8_t* truth, int n_envs,
-                            hipStream_t st) {
+                            hipStream_t st, int key_stride = 2) {
   const int gx = ctx->cfg.grid_x, gy = ctx->cfg.grid_y;
 #define LAUNCH_Y(N1, N2, Q)                                                                                                  \
   IPPM_LAUNCH(ctx, IPPM_T_TERRAIN, (k_terrain_fft_y<N1, N2, Q, MODE>), dim3(gx / (2 * Q), n_envs), dim3(FourStep<N1, N2, Q>::THREADS), st, \
-              ctx->dcfg, work2, field, range_keys, ctx->d_roots, reinterpret_cast<uint32_t*>(truth), (int)(ippm_truth_bytes(gx, gy) >> 2))
+              ctx->dcfg, work2, field, range_keys, ctx->d_roots, reinterpret_cast<uint32_t*>(truth), (int)(ippm_truth_bytes(gx, gy) >> 2),       \
+              MODE == 3 ? 4 : key_stride)
   TERRAIN_DISPATCH(gy, LAUNCH_Y)
 #undef LAUNCH_Y
   IPPM_LAUNCH_CHECK("terrain_fft_y");
@@ -542,14 +585,18 @@ extern "C" int ippm_terrain_field(ippm_ctx* ctx, const int64_t* episode, const f
   return terrain_launch_y<0>(ctx, reinterpret_cast<const float2*>(work), field, range_keys, nullptr, n_envs, S_(stream));
 }
 
-// The episode reset's form: spectrum drawn in pass X, pass Y once for the field's (min, max) and once more for the threshold
-// bits -- the field itself is never stored.
+// The episode reset's form: spectrum drawn in pass X; the field itself is never stored.  Its threshold bits need its (min, max)
+// first: pass Y computes every row ONCE -- the workgroups of an env put their (min, max) in, meet at a counter with their rows in
+// registers, and threshold them (MODE 3; rounds 4-5 ran the pass twice, re-reading 270 MB of half spectrum per 1024 fields of 256^2
+// and repeating the transforms: IPPM_TERRAIN_TWO_PASSES=1 still does, bit for bit the same truth).
 extern "C" int ippm_terrain_truth(ippm_ctx* ctx, const int64_t* episode, const float* amp, float* work, uint32_t* range_keys,
                                   uint8_t* truth, int32_t n_envs, void* stream) {
   if (!ctx || !episode || !amp || !work || !range_keys || !truth) { ippm_set_error("ippm_terrain_truth: null argument"); return -1; }
   if (terrain_pow2_check(ctx, "ippm_terrain_truth")) return -1;
   if (n_envs <= 0) return 0;
-  if (int rc = terrain_launch_x(ctx, episode, amp, nullptr, reinterpret_cast<float2*>(work), range_keys, n_envs, S_(stream))) return rc;
-  if (int rc = terrain_launch_y<1>(ctx, reinterpret_cast<const float2*>(work), nullptr, range_keys, nullptr, n_envs, S_(stream))) return rc;
-  return terrain_launch_y<2>(ctx, reinterpret_cast<const float2*>(work), nullptr, range_keys, truth, n_envs, S_(stream));
+  if (int rc = terrain_launch_x(ctx, episode, amp, nullptr, reinterpret_cast<float2*>(work), range_keys, n_envs, S_(stream), 4)) return rc;
+  if (!ctx->knob_terrain_two_passes)
+    return terrain_launch_y<3>(ctx, reinterpret_cast<const float2*>(work), nullptr, range_keys, truth, n_envs, S_(stream), 4);
+  if (int rc = terrain_launch_y<1>(ctx, reinterpret_cast<const float2*>(work), nullptr, range_keys, nullptr, n_envs, S_(stream), 4)) return rc;
+  return terrain_launch_y<2>(ctx, reinterpret_cast<const float2*>(work), nullptr, range_keys, truth, n_envs, S_(stream), 4);
 }

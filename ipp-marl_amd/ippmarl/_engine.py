@@ -57,6 +57,7 @@ class EpisodeEngine:
         def sense(stage, flips=None, agent=-1, close_step=False):
             raw_sense(stage, flips, agent, close_step)
             rects = env.rect[0].cpu().numpy()
+            self._rects = rects          # (measurement_views of the agents just sensed reads them here: one copy, not two)
             for i in (range(self.d.n_agents) if agent < 0 else [agent]):
                 yu, yd, xl, xr = (int(v) for v in rects[i])
                 self.observed[xl:xr, yu:yd] = True
@@ -97,11 +98,14 @@ class EpisodeEngine:
         env.sums[0, 2] = out[0]
 
     # ---- measurements -----------------------------------------------------------------------------------
-    def measurement_views(self, i: int):
-        """(map2communicate [gx,gy] float32 Measurement, footprint_img [2r,2r] float64, clipped rect, cell_update view)."""
+    def measurement_views(self, i: int, position=None):
+        """(map2communicate [gx,gy] float32 Measurement, footprint_img [2r,2r] float64, clipped rect, cell_update view).
+        ``position``: the agent's position if the caller holds it on the host (else read back from the device)."""
         d, env = self.d, self.env
-        yu, yd, xl, xr = (int(v) for v in env.rect[0, i].cpu())
-        pos = env.pos[0, i].cpu().numpy()
+        rects = getattr(self, "_rects", None)
+        self._rects = None               # (valid for the sensing that has just run only)
+        yu, yd, xl, xr = (int(v) for v in (rects[i] if rects is not None else env.rect[0, i].cpu()))
+        pos = np.asarray(position, dtype=np.int64) if position is not None else env.pos[0, i].cpu().numpy()
         k = min(max((int(pos[2]) - d.min_altitude) // d.spacing, 0), d.space_z - 1)
         codes = d.unpack_tile([yu, yd, xl, xr], env.code[0, i].cpu().numpy())
         meas = np.where(codes > 0, d.meas_value[k, 1], d.meas_value[k, 0]).astype(np.float32)

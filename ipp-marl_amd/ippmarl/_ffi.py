@@ -15,6 +15,7 @@ from .derived import DerivedConstants, MAX_LATTICE, MAX_Z, CLIP_LO, CLIP_HI
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("IPPMARL_LIB", os.path.join(_HERE, "..", "lib", "libippmarl.so"))
 WS_WORDS = 160
+FAULT_WORK_OVERFLOW = 0x40000000   # IPPM_FAULT_WORK_OVERFLOW (ippmarl.h): sticky bit of fault[e]
 FEAT, ACTOR_PLANES, CRITIC_PLANES = 11, 7, 12
 STEP_COMM, STEP_GLOBAL, STEP_MOVE, STEP_TILES = 1, 2, 4, 8   # ippm_plan_step flags
 SENSE_REC_WORDS = 8   # words per agent of ippm_plan_step's rect_next / ippm_sense_step's rect_in (IPPM_SENSE_REC_WORDS)

@@ -66,7 +66,7 @@ class Agent:
         stage = eng.stage[i]
         eng.stage[i] += 1
         env.sense(stage=stage, flips=flips, agent=i)
-        self.map2communicate, self.footprint_img, fc = eng.measurement_views(i)
+        self.map2communicate, self.footprint_img, fc = eng.measurement_views(i, self.position)
         self.map_footprint = LazyMap(lambda: self.engine.get_local(i)[fc[2]:fc[3], fc[0]:fc[1]])
         return fc
 

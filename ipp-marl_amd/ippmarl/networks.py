@@ -37,6 +37,13 @@ def epsilon_schedule(params: Dict, num_episode: int) -> float:
     return m["eps_max"] - num_episode / m["eps_anneal_phase"] * (m["eps_max"] - m["eps_min"])
 
 
+# ActorNetwork.get_action_index: the team's action probabilities of the sweep in progress, per network object (kept out of the
+# module's __dict__: whole-module pickles are the reference's checkpoint format)
+import weakref  # noqa: E402
+
+_TEAM_PROBS: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
 class _ConvDataGradAsGemm(torch.autograd.Function):
     """conv2d whose INPUT gradient is a GEMM + col2im instead of the library's implicit-GEMM backward-data kernel.
 
@@ -211,14 +218,33 @@ class ActorNetwork(_ConvTrunk):
 
     def get_action_index(self, batch_memory, action_mask_1d, agent_id, t, num_episode: int, mode: str):
         """Single-agent action choice of the drop-in Agent.step (actor/network.py:41-68,90-96): masked eps-softmax,
-        torch.multinomial in training, argmax in evaluation."""
-        device = next(self.parameters()).device
-        obs = batch_memory.get(-1, agent_id, "observation").unsqueeze(0).to(device).float()
-        mask = torch.as_tensor(action_mask_1d).to(device)
+        torch.multinomial in training, argmax in evaluation.
+        The agents of a team are served one after the other within a step (coma_wrapper.py:97-104) and their observations are all
+        in the memory before the first one acts (coma_wrapper.py:37-71), so the first call of a sweep runs ONE forward pass for the
+        whole team and the following agents take their row of it (a batch-1 pass per agent was a quarter of the seam's step)."""
+        device = self.conv1.weight.device
         eps = epsilon_schedule(self.params, num_episode)
-        with torch.no_grad():
-            probs, _ = self.forward(obs, eps)
-        probs = probs.squeeze() * mask
+        team = _TEAM_PROBS.get(self)
+        key = (id(batch_memory), t, eps)
+        if team is None or team[0] != key or agent_id <= team[1] or agent_id >= team[2].shape[0]:
+            lens = {len(batch_memory.transitions[j]) for j in range(self.n_agents)} if hasattr(batch_memory, "transitions") else set()
+            if len(lens) == 1 and agent_id == 0:       # every agent holds an observation of this step: the whole team at once
+                obs = torch.stack([batch_memory.get(-1, j, "observation") for j in range(self.n_agents)]).to(device).float()
+            else:
+                obs = batch_memory.get(-1, agent_id, "observation").unsqueeze(0).to(device).float()
+            with torch.no_grad():
+                probs_all, _ = self.forward(obs, eps)
+            team = [key, agent_id, probs_all if obs.shape[0] > 1 else None]
+            row = probs_all[agent_id if obs.shape[0] > 1 else 0]
+            if team[2] is None:
+                team = None
+        else:
+            row = team[2][agent_id]
+        if team is not None:
+            team[1] = agent_id
+        _TEAM_PROBS[self] = team
+        mask = torch.as_tensor(action_mask_1d).to(device)
+        probs = row * mask
         chosen = torch.argmax(probs) if mode == "eval" else torch.multinomial(probs, 1, replacement=True)
         return probs, chosen, mask, eps
 

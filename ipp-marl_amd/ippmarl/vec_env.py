@@ -571,6 +571,21 @@ class VecEnv:
     def counters(self, reset: bool = False) -> dict:
         return self.ctx.counters(self.stream, reset)
 
+    def check_faults(self) -> None:
+        """Raises if the device has flagged something that "cannot happen" (synchronises): an env whose tile work list did not fit
+        its slice (IPPM_FAULT_WORK_OVERFLOW: that env's maps are no longer fused), a fusion launch that rejected a work list, or a
+        terrain workgroup whose in-launch wait for its env's (min, max) gave up."""
+        bad = (self.fault & _ffi.FAULT_WORK_OVERFLOW).ne(0).nonzero().view(-1)
+        if bad.numel():
+            raise _ffi.IppmError(f"work list overflow in envs {bad[:8].tolist()} (of {bad.numel()}): the tile list's capacity bound is wrong")
+        rejects = self.counters()["work_list_rejects"]
+        if rejects:
+            raise _ffi.IppmError(f"{rejects} fusion launches were handed a work list they could not read")
+        if self._field is not None and getattr(self._field, "_keys", None) is not None:
+            words = self._field._keys.view(-1)[:-4].view(-1, 4)[:, 3]
+            if bool(words.ne(0).any()):
+                raise _ffi.IppmError("terrain synthesis: a workgroup gave up waiting for its env's (min, max) -- truth planes are wrong")
+
     def pack_flips(self, tiles, rects: np.ndarray) -> torch.Tensor:
         """tiles[e][i]: uint8 [h,w] (1 = flipped) for clipped rect rects[e,i] = [yu,yd,xl,xr] -> device tile layout."""
         N = self.d.n_agents
@@ -744,6 +759,10 @@ class SplitVecEnv:
     def profile(self, on: bool):
         for env in self.parts:
             env.profile = on
+
+    def check_faults(self) -> None:
+        for env, _ in self._each():
+            env.check_faults()
 
     def counters(self, reset: bool = False) -> dict:
         total: Dict[str, int] = {}

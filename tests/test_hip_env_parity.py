@@ -387,6 +387,36 @@ def test_random_field_terrain_native_path(name):
     assert not np.array_equal(got[0], got[2])
 
 
+@pytest.mark.parametrize("name,n_envs", [("c2", 3000), ("c4", 700), ("c5", 150), ("c2", 7)])
+def test_one_launch_terrain_equals_the_two_pass_form(name, n_envs):
+    """ippm_terrain_truth's second transform pass as ONE launch -- the workgroups of an env exchange the field's (min, max) inside
+    the launch (arrival counter, workgroups numbered by a start-order ticket) and threshold the rows they hold in registers --
+    against rounds 4-5's two launches (IPPM_TERRAIN_TWO_PASSES=1: min / max, then the same transforms again for the bits): the same
+    truth bit for bit, at batches far larger than the device holds workgroups at once (3000 x 8 workgroups of 256 threads at 256^2),
+    twice in a row on the same scratch (the counters are re-armed by pass X), and no workgroup's wait gave up (fault words 0)."""
+    params = make_params(name, experiment__missions__n_agents=2)
+    eps = np.arange(1, n_envs + 1) * 7919
+    one = _env(params, n_envs, track_area=False, terrain="random_field")
+    saved = os.environ.get("IPPM_TERRAIN_TWO_PASSES")
+    os.environ["IPPM_TERRAIN_TWO_PASSES"] = "1"        # (read at ippm_ctx_create)
+    try:
+        two = _env(params, n_envs, track_area=False, terrain="random_field")
+    finally:
+        if saved is None:
+            os.environ.pop("IPPM_TERRAIN_TWO_PASSES", None)
+        else:
+            os.environ["IPPM_TERRAIN_TWO_PASSES"] = saved
+    for rep in range(2):
+        ids = eps + rep
+        one.reset(ids)
+        two.reset(ids)
+        assert torch.equal(one.truth, two.truth), (name, n_envs, rep)
+        one.check_faults()
+        keys = env_terrain(one)._keys.view(-1)[: 4 * n_envs].view(n_envs, 4)
+        assert int(keys[:, 2].min()) == int(keys[:, 2].max()) == one.d.grid_x // {256: 32, 512: 16, 1024: 8}[one.d.grid_x]   # every workgroup arrived
+    assert int(one.truth.max()) > 0 and int(one.truth.min()) < 255      # (fields, not constants)
+
+
 def test_terrain_prefetch_is_the_inline_terrain():
     """VecEnv.prefetch_terrain: the field of the next episodes synthesised on a side stream beside the current episodes' steps is
     bit for bit the field reset() synthesises in line; a reset with other ids than the prefetched ones ignores the prefetch."""
@@ -680,8 +710,10 @@ def test_staggered_sub_batches_fly_the_same_episodes(parts):
             for t in range(split._phase[k]):
                 r1, _, _ = one.steps(t, policy=POLICY_UNIFORM, features=False)
             sl = slice(off, off + n)
-            assert torch.equal(env.pos, one.pos[sl]) and torch.equal(env.local, one.local[sl]) and torch.equal(env.glob, one.glob[sl]), (k, done)
-            assert torch.equal(env.code, one.code[sl]) and torch.equal(env.episode, one.episode[sl]), (k, done)
+            assert torch.equal(env.episode, one.episode[sl]) and torch.equal(env.pos, one.pos[sl]), (k, done)
+            assert torch.equal(env.local, one.local[sl]), (k, done)
+            assert torch.equal(env.glob, one.glob[sl]), (k, done)
+            assert torch.equal(env.rect, one.rect[sl]), (k, done)      # (the code plane keeps stale bytes outside the current footprints)
             if r1 is not None:
                 assert torch.equal(env.action, one.action[sl]) and torch.equal(env.reward, r1[sl]), (k, done)
     assert split.part_resets == parts + sum(split._wave)
