@@ -400,10 +400,10 @@ int ippm_terrain_field(ippm_ctx* ctx, const int64_t* episode, const float* amp, 
                        uint32_t* range_keys, int32_t n_envs, void* stream);
 int ippm_terrain_pack(ippm_ctx* ctx, const float* field, const uint32_t* range_keys, uint8_t* truth, int32_t n_envs, void* stream);
 /* ippm_terrain_truth = ippm_terrain_field(spec = NULL) + ippm_terrain_pack without ever storing the field: the second transform
- * pass computes every row once, the workgroups of an env exchange the field's min / max through `range_keys` inside the launch
- * and threshold the rows they hold in registers.  work: complex64 [E,gy/2+1,gx] scratch; range_keys: uint32 [4*E + 4] scratch
- * (per env: min key, max key, arrivals, fault word -- 0 unless the in-launch wait gave up, which never happens by construction --
- * then the launch's ticket counter). */
+ * pass runs twice (once for the field's min / max, once more for the threshold bits, same arithmetic), which moves half the bytes
+ * of writing the field and reading it back.  work: complex64 [E,gy/2+1,gx] scratch; range_keys: uint32 [4*E + 4] scratch (per env:
+ * min key, max key, and two words + a trailing record for the one-launch form of the pass, IPPM_TERRAIN_ONE_LAUNCH=1: arrivals, a
+ * fault word that stays 0 unless an in-launch wait gave up, the launch's ticket counter). */
 int ippm_terrain_truth(ippm_ctx* ctx, const int64_t* episode, const float* amp, float* work, uint32_t* range_keys, uint8_t* truth,
                        int32_t n_envs, void* stream);
 

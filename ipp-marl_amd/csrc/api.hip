@@ -115,7 +115,9 @@ extern "C" int ippm_ctx_create(const ippm_config* cfg, ippm_ctx** out) {
     // 1024^2 91.3 -> 96.6: the parts of a footprint first there
     ctx->k3_go = knob("IPPM_K3_GO", wmax <= 32 ? 1 : 0);
   }
-  ctx->knob_terrain_two_passes = knob("IPPM_TERRAIN_TWO_PASSES", 0);   // 1: rounds 4-5's form of ippm_terrain_truth (A/B, and the parity test of the one-launch form)
+  ctx->knob_reset_align = knob("IPPM_RESET_ALIGN", 32);   // cells the reset's fill boxes are rounded outwards to (32 = a 128-byte line; 0: not)
+  if (ctx->knob_reset_align & (ctx->knob_reset_align - 1)) ctx->knob_reset_align = 32;
+  ctx->knob_terrain_one_launch = knob("IPPM_TERRAIN_ONE_LAUNCH", 0);   // 1: ippm_terrain_truth's second pass as one launch (terrain.hip: measured, no gain)
   ctx->knob_k3_dense = knob("IPPM_K3_DENSE", 1);   // 0: the power-of-two lane layout of round 3 (A/B: tools/ab_knobs.py)
   ctx->tiles = (ctx->vec == 4 && c.logit_prior == 0.f && c.grid_x < 32768 && c.grid_y <= 1024 && !knob("IPPM_NO_TILES", 0)) ? 1 : 0;
   int rc = ippm_check_hip(hipMalloc(&ctx->dcfg, sizeof(ippm_config)), "hipMalloc(cfg)");

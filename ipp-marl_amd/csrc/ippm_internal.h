@@ -62,7 +62,7 @@ struct ippm_ctx {
   int vec;                   // 4: 16-byte lane groups (grid_y >= 44), else 1
   // tuning knobs, resolved ONCE at ippm_ctx_create (the work buffer's size, the plan kernel's item layout and the fusion launch
   // all derive from them and must agree for the context's lifetime)
-  int knob_wave_rows, knob_persist, knob_nowork, knob_split, knob_tile_waves, knob_tile_rotate, knob_plan_builders, knob_k3_dense, knob_terrain_two_passes;
+  int knob_wave_rows, knob_persist, knob_nowork, knob_split, knob_tile_waves, knob_tile_rotate, knob_plan_builders, knob_k3_dense, knob_terrain_one_launch, knob_reset_align;
   const int32_t* n_active;   // device int32 [E] or nullptr: agents flying in each env (ippm_set_team_sizes)
   int k3_wpg, k3_chn, k3_go;        // workgroup shape of the env-only step's K3 (wavefronts per workgroup, loads in flight per lane)
   float2* d_roots;           // e^{2 pi i k / 1024}, k = 0..1023: the twiddle table of the terrain transforms (terrain.hip)

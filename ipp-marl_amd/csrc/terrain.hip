@@ -54,7 +54,15 @@ __global__ __launch_bounds__(256) void k_terrain_noise(const ippm_config* __rest
 //           (bit-reversed ky) -> radix-2 DIT along y -> real part -> field[e, x, y]
 // Only the half spectrum ky in [0, gy/2] is ever stored (the real field's other half is its conjugate mirror).
 
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// Complex product with the contraction FIXED (one product rounded on its own, the other fused into the sum): left to the compiler,
+// which of the two products of a component goes into the fma differed between instantiations of one kernel -- pass Y's (min, max)
+// launch and its threshold launch disagreed in the last bit of a row now and then (one truth bit in a few hundred fields, found when
+// the one-launch form was compared with them in round 6).  Every form of the passes now computes the same bits.
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+#pragma clang fp contract(off)
+  const float p = a.y * b.y, q = a.y * b.x;
+  return make_float2(__builtin_fmaf(a.x, b.x, -p), __builtin_fmaf(a.x, b.y, q));
+}
 __device__ __forceinline__ uint32_t bitrev(uint32_t v, int bits) { return __brev(v) >> (32 - bits); }
 
 // Bin (kx, ky) of the half spectrum of N(0,1) white noise, up to a common factor: generic bins are a + ib with
@@ -269,7 +277,7 @@ __global__ __launch_bounds__((FourStep<N1, N2, Q>::THREADS)) void k_terrain_fft_
   __shared__ FourStep<N1, N2, Q> fs;
   const int tid = threadIdx.x, gx = c->grid_x, gy = N1 * N2, hy = gy / 2 + 1;
   int e = blockIdx.y, part = blockIdx.x;
-  __shared__ uint32_t s_ticket;
+  __shared__ uint32_t s_ticket, s_keys[2];
   if (MODE == 3) {
     // One launch for (min, max) AND the threshold bits: the workgroups of an env meet at a counter once their rows are in
     // registers.  Waiting for a workgroup that has not started yet would hang the device, so which (env, rows) a workgroup takes
@@ -327,22 +335,36 @@ __global__ __launch_bounds__((FourStep<N1, N2, Q>::THREADS)) void k_terrain_fft_
       __syncthreads();
       if (tid == 0) {
         for (int w = 1; w < NW; ++w) { lo = fminf(lo, s_lo[w]); hi = fmaxf(hi, s_hi[w]); }
-        atomicMin(range_keys + key_stride * e, order_key(lo));
-        atomicMax(range_keys + key_stride * e + 1, order_key(hi));
-        if (MODE == 3) {
-          // my (min, max) are in before my arrival is; then wait for the env's other workgroups (all of them have started: ticket
-          // order).  The spin is bounded all the same: a wait that long means the premise broke -- word 3 of the env's record then
-          // says so (0xDEADxxxx; tests and VecEnv.check_faults look at it) and the workgroup goes on with what there is.
-          __threadfence();
-          __hip_atomic_fetch_add(range_keys + 4 * e + 2, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (MODE != 3) {
+          atomicMin(range_keys + key_stride * e, order_key(lo));
+          atomicMax(range_keys + key_stride * e + 1, order_key(hi));
+        } else {
+          // My (min, max) go in BEFORE my arrival does, and everything that crosses workgroups here is a device-scope atomic
+          // read-modify-write, carried out where all XCDs see it -- no fence: an agent-scope release / acquire writes back and
+          // invalidates the whole L2 of the XCD on gfx950, which made this launch 850 us instead of 80.  The two RETURNING atomics
+          // are waited for (their results are operands of the wait) before the arrival is issued.
+          uint32_t* rec = range_keys + 4 * e;
+          const uint32_t o1 = __hip_atomic_fetch_min(rec, order_key(lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint32_t o2 = __hip_atomic_fetch_max(rec + 1, order_key(hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          asm volatile("s_waitcnt vmcnt(0)" : : "v"(o1), "v"(o2) : "memory");
+          __hip_atomic_fetch_add(rec + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // wait for the env's other workgroups (all of them have started: ticket order).  The spin is bounded all the same: a wait
+          // that long means the premise broke -- word 3 of the env's record then says so (VecEnv.check_faults and the tests look at
+          // it) and the workgroup goes on with what there is.
+          // The counter is READ by a read-modify-write too (a compare-and-swap that never succeeds): an atomic LOAD at agent scope
+          // (global_load sc1) can be served from a stale line of this XCD's L2 -- measured: a workgroup at 1024^2 waited out the
+          // whole bound while its env's counter stood at 128 of 128, and at 256^2 the launch took 210 us for wake-ups that late.
           unsigned spins = 0;
-          while (__hip_atomic_load(range_keys + 4 * e + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1u << 24)) {
-              __hip_atomic_store(range_keys + 4 * e + 3, 0xDEAD0000u | (unsigned)part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          while (atomicCAS(rec + 2, 0xFFFFFFFFu, 0xFFFFFFFEu) < gridDim.x) {
+            __builtin_amdgcn_s_sleep(16);
+            if (++spins > (1u << 22)) {
+              atomicExch(rec + 3, 0xDEAD0000u | (unsigned)part);
               break;
             }
           }
+          // the final keys, read where they were written (neither key can be all ones: that is a NaN's key)
+          s_keys[0] = atomicCAS(rec, 0xFFFFFFFFu, 0xFFFFFFFEu);
+          s_keys[1] = atomicCAS(rec + 1, 0xFFFFFFFFu, 0xFFFFFFFEu);
         }
       }
     }
@@ -353,9 +375,9 @@ __global__ __launch_bounds__((FourStep<N1, N2, Q>::THREADS)) void k_terrain_fft_
     // threshold and pack: for one k2 a wavefront holds columns k1 + N1 k2 of 64 / N1 rows, i.e. N1 consecutive bits of each of
     // those rows' bit strings; lane L < 64 / N1 collects row L's chunks into 32-bit words and stores every completed word
     static_assert(N1 == 8 || N1 == 16 || N1 == 32, "a chunk must not straddle a 32-bit word");
-    // (MODE 3: written by other workgroups of this launch, possibly on other XCDs -- read at device scope, not from a stale line)
-    const uint32_t key_lo = MODE == 3 ? __hip_atomic_load(range_keys + key_stride * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : range_keys[key_stride * e];
-    const uint32_t key_hi = MODE == 3 ? __hip_atomic_load(range_keys + key_stride * e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : range_keys[key_stride * e + 1];
+    // (MODE 3: written by other workgroups of this launch, possibly on other XCDs -- thread 0 fetched them at device scope)
+    const uint32_t key_lo = MODE == 3 ? s_keys[0] : range_keys[key_stride * e];
+    const uint32_t key_hi = MODE == 3 ? s_keys[1] : range_keys[key_stride * e + 1];
     const float lo = key_value(key_lo), span = key_value(key_hi) - lo;
     const int lane = tid & 63, rows_per_wave = 64 / N1;
     const int my_q = (tid >> 6) * rows_per_wave + lane;          // the row (slot) this lane stores for, if lane < rows_per_wave
@@ -586,16 +608,19 @@ extern "C" int ippm_terrain_field(ippm_ctx* ctx, const int64_t* episode, const f
 }
 
 // The episode reset's form: spectrum drawn in pass X; the field itself is never stored.  Its threshold bits need its (min, max)
-// first: pass Y computes every row ONCE -- the workgroups of an env put their (min, max) in, meet at a counter with their rows in
-// registers, and threshold them (MODE 3; rounds 4-5 ran the pass twice, re-reading 270 MB of half spectrum per 1024 fields of 256^2
-// and repeating the transforms: IPPM_TERRAIN_TWO_PASSES=1 still does, bit for bit the same truth).
+// first, so pass Y runs twice: once for the (min, max), once more (bit for bit the same transforms) for the bits.
+// IPPM_TERRAIN_ONE_LAUNCH=1 (round 6, measured, NOT the default): every row computed ONCE -- the workgroups of an env put their
+// (min, max) in, meet at a counter with their rows in registers and threshold them (MODE 3).  It saves the second read of the half
+// spectrum (270 MB per 1024 fields of 256^2) and the second set of transforms, and gives most of that back to workgroups that sit
+// on their CU waiting for seven peers: 124 us against 67 + 71 for the pass, 212 against 223 us for a whole reset's terrain, and no
+// gain in the step (profiles/r06/terrain_one_launch_ab.txt).  Same truth bit for bit (tested at 3000 x 256^2, 700 x 512^2, 150 x 1024^2).
 extern "C" int ippm_terrain_truth(ippm_ctx* ctx, const int64_t* episode, const float* amp, float* work, uint32_t* range_keys,
                                   uint8_t* truth, int32_t n_envs, void* stream) {
   if (!ctx || !episode || !amp || !work || !range_keys || !truth) { ippm_set_error("ippm_terrain_truth: null argument"); return -1; }
   if (terrain_pow2_check(ctx, "ippm_terrain_truth")) return -1;
   if (n_envs <= 0) return 0;
   if (int rc = terrain_launch_x(ctx, episode, amp, nullptr, reinterpret_cast<float2*>(work), range_keys, n_envs, S_(stream), 4)) return rc;
-  if (!ctx->knob_terrain_two_passes)
+  if (ctx->knob_terrain_one_launch)
     return terrain_launch_y<3>(ctx, reinterpret_cast<const float2*>(work), nullptr, range_keys, truth, n_envs, S_(stream), 4);
   if (int rc = terrain_launch_y<1>(ctx, reinterpret_cast<const float2*>(work), nullptr, range_keys, nullptr, n_envs, S_(stream), 4)) return rc;
   return terrain_launch_y<2>(ctx, reinterpret_cast<const float2*>(work), nullptr, range_keys, truth, n_envs, S_(stream), 4);

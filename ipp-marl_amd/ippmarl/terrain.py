@@ -9,8 +9,8 @@ it actually flies over.  ``VecEnv.reset(..., terrain="random_field")`` flies ove
 discarded — tests that compare against the oracle hand the generated truth to both sides.
 
 Device work (csrc/terrain.hip): power-of-two grids draw the half spectrum directly and invert it in two hand-written
-LDS passes — rocFFT's batched 2-D real transforms were 4x slower on this shape — the second of which exchanges the field's
-min / max inside its launch and thresholds the rows it holds in registers, so that the field is never stored (``ippm_terrain_truth``;
+LDS passes — rocFFT's batched 2-D real transforms were 4x slower on this shape — the second of them run twice, for the
+field's min / max and for its threshold bits, so that the field is never stored (``ippm_terrain_truth``;
 ``ippm_terrain_field`` + ``ippm_terrain_pack`` are the same arithmetic with the field written out); other grid sizes
 (the default 493 x 493) use ``ippm_terrain_noise`` + rocFFT via torch.fft and ``ippm_terrain_pack``.
 """
@@ -67,8 +67,8 @@ class RandomFieldTerrain:
                 if self._work is None or self._work.shape[0] < n:
                     self._work = torch.empty(n, gy // 2 + 1, gx, 2, dtype=torch.float32, device=self.device)
                     self._keys = torch.zeros(4 * n + 4, dtype=torch.int32, device=self.device)
-                # (the field itself is never stored: the second pass exchanges its min / max inside the launch and thresholds the
-                #  rows it holds in registers; _keys = per env (min, max, arrivals, fault word), then the launch's ticket counter)
+                # (the field itself is never stored: second pass once for its min / max, once more for the threshold bits;
+                #  _keys = per env (min, max, and for IPPM_TERRAIN_ONE_LAUNCH=1: arrivals, fault word), then that form's ticket counter)
                 self.ctx.call("ippm_terrain_truth", _ffi.ptr(ep), _ffi.ptr(self.amp), _ffi.ptr(self._work), _ffi.ptr(self._keys), _ffi.ptr(tr),
                               n, stream)
                 continue
