@@ -29,6 +29,14 @@ def test_actor_and_critic_step_match_reference(golden):
     closs, q_new = cl.step(t(state), t(actions), t(td))
     np.testing.assert_allclose(float(closs), float(fx["critic_loss"]), rtol=1e-4)
     np.testing.assert_allclose(q_new.cpu().numpy(), fx["q_new"], rtol=2e-4, atol=2e-6)
+    # ... and against the same step evaluated in float64 (test_learning_cpu.float64_critic_step: within 1e-6 of the reference's
+    # recording, so this deviation is the device path's own -- MIOpen's float32 summation order in three convolutions and their
+    # gradients, then Adam's g / (sqrt(v) + eps), which turns a last-bit difference of a tiny gradient into a step of +-lr)
+    from test_learning_cpu import float64_critic_step, scale_deviation
+    loss64, q64 = float64_critic_step(fx)
+    assert abs(float(closs) - loss64) <= 1e-5 * abs(loss64), (float(closs), loss64)
+    dev_q = scale_deviation(q_new.cpu().numpy(), q64)
+    assert dev_q < 1e-4, dev_q
     aloss, adv = al.step(t(obs, torch.float32), t(actions), t(masks, torch.float32), q_new, float(fx["eps"]))
     np.testing.assert_allclose(float(aloss), float(fx["actor_loss"]), rtol=2e-4, atol=1e-7)
     np.testing.assert_allclose(float(adv.mean()), float(fx["adv_mean"]), rtol=2e-4, atol=1e-6)

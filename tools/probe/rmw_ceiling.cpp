@@ -1,0 +1,105 @@
+// What does a BARE read-modify-write reach on the map kernels' access shapes?  (round 6)  K3 and the tile fusion sit at 0.55-0.59 of
+// the 8 TB/s peak (0.68-0.72 of the streaming-copy rate) at every grid size, and at config 4's shape the fusion loses nothing without
+// its reward arithmetic, 6 % without its whole op chain, 4 % without its code loads -- so what bounds them is the cells' own traffic.
+// This probe times kernels that do NOTHING but load 16 bytes per lane, add one and store them back, over
+//   dense     the whole buffer (every line read once and written once: the streaming-copy mix, in place)
+//   rows<W>   per 1 KiB-row map (256 x 256 float32) or 2 KiB-row map (512 x 512) a footprint of ROWS rows x W lane-loads whose rows
+//             start at a pseudo-random 16-byte phase of a 128-byte line, lane-loads dealt out in row-major runs like K3's -- i.e. K3's
+//             and the fusion's map traffic with no truth / code / Philox / op chain / reward at all
+// and prints GB/s of REQUESTED bytes (read + written) and of the 128-byte lines those requests touch.
+//   hipcc -O3 --offload-arch=gfx950 tools/probe/rmw_ceiling.cpp -o tools/probe/rmw_ceiling
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+__global__ __launch_bounds__(256) void k_dense(float4* __restrict__ buf, size_t n16) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n16) { float4 v = buf[i]; v.x += 1.f; v.y += 1.f; v.z += 1.f; v.w += 1.f; buf[i] = v; }
+}
+
+// grid = (parts, maps): a workgroup of 128 threads takes a run of 128 * 2 consecutive lane-loads of the footprint's row-major order
+template <int G, int ROWS, int W>
+__global__ __launch_bounds__(128) void k_rows(char* __restrict__ buf) {
+  const int m = blockIdx.y;
+  char* map = buf + (size_t)m * G * G * 4;
+  const unsigned h = (unsigned)m * 2654435761u;
+  const int x0 = (h >> 8) % (G - ROWS);
+  const int col0 = ((h >> 20) % ((G * 4 - W * 16) / 16)) * 16;     // any 16-byte phase
+  const int base = blockIdx.x * 256;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int t = base + q * 128 + threadIdx.x;
+    if (t < ROWS * W) {
+      const int row = t / W, g = t - row * W;
+      float4* p = reinterpret_cast<float4*>(map + (size_t)(x0 + row) * (G * 4) + col0 + g * 16);
+      float4 v = *p; v.x += 1.f; v.y += 1.f; v.z += 1.f; v.w += 1.f; *p = v;
+    }
+  }
+}
+
+template <int G, int ROWS, int W>
+static void rows(char* buf, int maps, const char* name) {
+  const dim3 grid((ROWS * W + 255) / 256, maps);
+  hipEvent_t a, b;
+  CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+  hipLaunchKernelGGL((k_rows<G, ROWS, W>), grid, dim3(128), 0, 0, buf);
+  CHECK(hipDeviceSynchronize());
+  float best = 1e30f, sum = 0.f;
+  for (int rep = 0; rep < 10; ++rep) {
+    CHECK(hipEventRecord(a));
+    hipLaunchKernelGGL((k_rows<G, ROWS, W>), grid, dim3(128), 0, 0, buf);
+    CHECK(hipEventRecord(b));
+    CHECK(hipEventSynchronize(b));
+    float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+    best = ms < best ? ms : best; sum += ms;
+  }
+  // lines touched: host count over the same pseudo-random phases
+  double lines = 0;
+  for (int m = 0; m < maps; ++m) {
+    const unsigned h = (unsigned)m * 2654435761u;
+    const int col0 = ((h >> 20) % ((G * 4 - W * 16) / 16)) * 16;
+    lines += (double)ROWS * ((col0 + W * 16 - 1) / 128 - col0 / 128 + 1);
+  }
+  const double req = 2.0 * maps * ROWS * W * 16, touched = 2.0 * lines * 128;
+  printf("{\"kernel\": \"%s\", \"maps\": %d, \"requested_MB\": %.1f, \"lines_MB\": %.1f, \"avg_us\": %.1f, \"min_us\": %.1f, \"requested_GBps\": %.0f, \"lines_GBps\": %.0f}\n",
+         name, maps, req / 1e6, touched / 1e6, sum / 10 * 1e3, best * 1e3, req / (sum / 10 * 1e-3) / 1e9, touched / (sum / 10 * 1e-3) / 1e9);
+}
+
+int main() {
+  const size_t bytes = (size_t)6 << 30;      // 6 GiB: 24576 maps of 256^2 or 6144 of 512^2
+  char* buf = nullptr;
+  CHECK(hipMalloc(&buf, bytes));
+  CHECK(hipMemset(buf, 0, bytes));
+  CHECK(hipDeviceSynchronize());
+  {
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    const size_t n16 = bytes / 16 / 4;       // 1.5 GiB per launch
+    float sum = 0.f, best = 1e30f;
+    for (int rep = 0; rep < 6; ++rep) {
+      CHECK(hipEventRecord(a));
+      hipLaunchKernelGGL(k_dense, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, 0, reinterpret_cast<float4*>(buf) + (size_t)(rep % 4) * n16, n16);
+      CHECK(hipEventRecord(b));
+      CHECK(hipEventSynchronize(b));
+      float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+      if (rep) { sum += ms; best = ms < best ? ms : best; }
+    }
+    printf("{\"kernel\": \"dense read-modify-write in place\", \"requested_MB\": %.1f, \"avg_us\": %.1f, \"min_us\": %.1f, \"requested_GBps\": %.0f}\n",
+           2.0 * n16 * 16 / 1e6, sum / 5 * 1e3, best * 1e3, 2.0 * n16 * 16 / (sum / 5 * 1e-3) / 1e9);
+  }
+  // config 2's shapes: 256^2 maps; footprints 30 / 60 / 90 cells a side (8 / 16 / 23 lane-loads per row), as many maps as K3 touches
+  // per launch (4096) and as the fusion does (~3 x that)
+  rows<256, 90, 23>(buf, 4096, "rows 256^2, 90 x 23 groups (15 m footprint), 4096 maps");
+  rows<256, 90, 23>(buf, 12288, "rows 256^2, 90 x 23 groups, 12288 maps");
+  rows<256, 60, 16>(buf, 12288, "rows 256^2, 60 x 16 groups (10 m), 12288 maps");
+  rows<256, 30, 8>(buf, 24576, "rows 256^2, 30 x 8 groups (5 m), 24576 maps");
+  // config 4's: 512^2 maps, footprints 180 cells a side (46 lane-loads per row)
+  rows<512, 180, 46>(buf, 6144, "rows 512^2, 180 x 46 groups (15 m), 6144 maps");
+  rows<512, 120, 31>(buf, 6144, "rows 512^2, 120 x 31 groups (10 m), 6144 maps");
+  CHECK(hipFree(buf));
+  return 0;
+}
