@@ -250,8 +250,10 @@ def main():
                     "kernels of the other -- 0.1526 -> 0.141 ms per step at config 2; 1 = one stream, one launch per kernel and step; "
                     "0 (default) = 2, or 3 where the envs' work differs many-fold (--episode-comm-range, --team-sizes: 1.09 / 1.13 / 1.32 M "
                     "agent-env steps/s on 1 / 2 / 3 streams at config 5's shape)")
-    ap.add_argument("--no-stagger", dest="stagger", action="store_false", help="sub-batches in lock step (round 5's loop) instead of each in its "
-                    "own phase of the episode (part k runs k * T / parts steps ahead, so that at most one part resets at any step)")
+    ap.add_argument("--stagger", action="store_true", help="every sub-batch in its own phase of the episode (part k runs k * T / parts steps ahead, "
+                    "so that at most one part resets at any step) instead of in lock step.  Off: measured in round 6 it gains nothing -- steady state "
+                    "0.1386-0.1394 ms per step staggered against 0.1369-0.1382 in lock step, alternating processes on one box "
+                    "(profiles/r06/stagger_ab.txt) -- the resets of two halves side by side cost no more than one after the other")
     ap.add_argument("--team-sizes", default=None, help="comma-separated team sizes dealt out to the envs in turn (BASELINE config 5's mixed teams, "
                     "e.g. 2,4,8,16 with --agents 16): env e flies team_sizes[e %% len] of the --agents UAVs; agent-env steps count the flying ones")
     ap.add_argument("--comm-range", type=float, default=None, help="experiment.uav.communication_range in metres (default: params.yaml's 25)")
@@ -400,8 +402,8 @@ def main():
         return resets
 
     if split:
-        # part k flies its slice of every wave; staggered (default): part k starts k * T / parts steps ahead, so that at most one
-        # sub-batch resets at any step (the steps taken ahead are part of the untimed start)
+        # part k flies its slice of every wave, all parts in lock step (--stagger: part k starts k * T / parts steps ahead, so that at
+        # most one sub-batch resets at any step; the steps taken ahead are part of the untimed start)
         env.start(lambda w: episode_ids(1, w, E, rank, world), stagger=args.stagger)
     else:
         reset()

@@ -714,13 +714,16 @@ class SplitVecEnv:
             env.steps(t, policy=policy, actions=None if actions is None else actions[sl], features=False)
 
     # -- the episode loop, owned by the split: every part in its own phase of the episode -----------------------------
-    def start(self, episodes_of_wave, stagger: bool = True, policy: int = POLICY_UNIFORM):
+    def start(self, episodes_of_wave, stagger: bool = False, policy: int = POLICY_UNIFORM):
         """Begins an endless run of whole episodes: ``episodes_of_wave(w)`` -> the E episode ids of wave w (part k flies its slice of
         every wave), then ``advance()`` steps every part once and resets a part that has finished its episode to its next wave.
         ``stagger``: part k starts k * T / parts steps AHEAD of part 0 (those steps are taken here), so that from then on at most one
         part resets at any step and its reset -- a write-only fill and the issue-bound terrain passes, 387 us at config 2 -- runs
         beside the other parts' map kernels instead of beside the other parts' resets.  Every episode is the same episode as in any
-        other batching (the streams of an episode are keyed by its number): only WHEN it is flown changes."""
+        other batching (the streams of an episode are keyed by its number): only WHEN it is flown changes.
+        Measured (round 6, config 2, two and three parts, alternating processes on one box): no gain -- 0.1386-0.1394 ms per step
+        staggered against 0.1369-0.1382 in lock step; the parts' resets side by side cost no more than one after the other, and a
+        short window holds more part-resets than its share.  Hence off by default."""
         T = self.d.budget + 1
         self._episodes_of_wave = episodes_of_wave
         self._phase = [0] * len(self.parts)        # the step each part takes next
