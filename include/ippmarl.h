@@ -271,6 +271,19 @@ int ippm_fuse_global_reward(ippm_ctx* ctx, float* global, const uint8_t* code, c
  * rows of inactive agents are zero (observations, critic states) or not meaningful.
  * The single-purpose entry points (ippm_comm_matrix, ippm_fuse_local, ippm_ig_*, ...) do not look at it. */
 int ippm_set_team_sizes(ippm_ctx* ctx, const int32_t* n_active);
+/* Dirty slabs: what the episode reset has to fill.  Without them (the default) ippm_plan_step keeps ONE bounding box per map of
+ * everything fusions and sensing wrote since the episode's reset (ws words 6-7, 14-15) and ippm_reset_maps writes the prior into that
+ * box: 51 % of a local map and 87 % of the global one for 38 % / 58 % written at BASELINE config 2.  With a registered slab array --
+ * slabs: DEVICE int32 [ippm_dirty_slab_words(n_envs)] = [n_envs, n_agents + 1, 2, ceil(grid_x / 16)], caller-owned, any contents (the
+ * next ippm_reset_maps with full = 1 initialises it) -- the plan kernel marks, per 16-row slab of a map, the column interval the step's
+ * plans and sense records touch (fire-and-forget atomic min / max), and ippm_reset_maps fills every slab's own interval (42 % / 69 %) and
+ * re-arms it with the new episode's start footprint.  Maps written by other entry points (ippm_sense_update, ippm_fuse_local, host
+ * copies) are not tracked either way: pass full = 1 to the next ippm_reset_maps.  NULL: back to the boxes.  Measured (round 6,
+ * BASELINE config 2): the marks cost the plan kernel 3.8 us per step and the fill gains nothing from its fewer bytes, so the Python
+ * host registers a slab array only on request (IPPM_DIRTY_SLABS=1).  Mirrors nothing in the
+ * reference (mapping/mappings.py:126-132 allocates fresh prior maps per episode). */
+int ippm_dirty_slab_words(ippm_ctx* ctx, int32_t n_envs, int64_t* words);
+int ippm_set_dirty_slabs(ippm_ctx* ctx, int32_t* slabs);
 int ippm_plan_step(ippm_ctx* ctx, const int64_t* episode, int32_t* pos, const float* comm_range, const double* draws,
                    uint8_t* comm, const int32_t* rect, int32_t* ws, int32_t t, int32_t flags, const float* probs,
                    const int32_t* action_in, int32_t policy, uint8_t* mask, int32_t* action, int32_t* fault,

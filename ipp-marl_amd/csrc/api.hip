@@ -147,6 +147,19 @@ extern "C" int ippm_set_team_sizes(ippm_ctx* ctx, const int32_t* n_active) {
   return 0;
 }
 
+extern "C" int ippm_dirty_slab_words(ippm_ctx* ctx, int32_t n_envs, int64_t* words) {
+  if (!ctx || !words || n_envs < 0) { ippm_set_error("ippm_dirty_slab_words: bad argument"); return -1; }
+  *words = (int64_t)n_envs * (ctx->cfg.n_agents + 1) * 2 * ippm_slab_count(ctx);
+  return 0;
+}
+
+extern "C" int ippm_set_dirty_slabs(ippm_ctx* ctx, int32_t* slabs) {
+  if (!ctx) { ippm_set_error("ippm_set_dirty_slabs: null context"); return -1; }
+  if (slabs && ctx->cfg.grid_y > 0xFFFF) { ippm_set_error("ippm_set_dirty_slabs: grid too wide"); return -1; }
+  ctx->slabs = slabs;
+  return 0;
+}
+
 extern "C" int ippm_ctx_destroy(ippm_ctx* ctx) {
   if (!ctx) return 0;
   if (ctx->dcfg) (void)hipFree(ctx->dcfg);

@@ -570,7 +570,7 @@ __global__ void __launch_bounds__(256)
 k_reset_maps(const ippm_config* __restrict__ c, const int64_t* __restrict__ episode, const int32_t* __restrict__ pos,
              const uint8_t* __restrict__ truth, float* __restrict__ local, float* __restrict__ global, const uint8_t* __restrict__ flips,
              uint8_t* __restrict__ code, const int32_t* __restrict__ rect, int32_t* __restrict__ ws, int full, int fill_chunks,
-             const int32_t* __restrict__ n_active, int col_align) {
+             const int32_t* __restrict__ n_active, int col_align, int32_t* __restrict__ slabs, int n_slabs) {
   const int n = c->n_agents, gx = c->grid_x, gy = c->grid_y, S = c->tile_stride;
   const int e = blockIdx.z, m = blockIdx.y;
   const bool is_global = m == n;
@@ -606,6 +606,30 @@ k_reset_maps(const ippm_config* __restrict__ c, const int64_t* __restrict__ epis
     if (blockIdx.x == 0 && threadIdx.x == 0) {   // the new episode's box: what this launch writes that is not the prior
       w[WS_BBOX_X] = xl | (xr << 16);
       w[WS_BBOX_Y] = yu | (yd << 16);
+    }
+    if (slabs) {
+      // Dirty slabs (ippm_set_dirty_slabs): instead of the map's one box, every 16-row slab has its own column interval -- what the
+      // plans and the sense records of the finished episode marked in it.  A wavefront (8 rows) reads its slab's interval; after a
+      // workgroup barrier (both wavefronts of a slab have read it) the slab is re-armed for the new episode: the start footprint's
+      // columns if it meets these rows, else empty.  This workgroup is the only one that touches these words in this launch.
+      static_assert(IPPM_RESET_ROWS == 2 * IPPM_SLAB_ROWS && IPPM_RESET_ROWS / 4 * 2 == IPPM_SLAB_ROWS, "two wavefronts of 8 rows per 16-row slab");
+      int32_t* sl = slabs + (size_t)(e * (n + 1) + m) * 2 * n_slabs;
+      const int s_idx = (int)blockIdx.x * 2 + (wv >> 1);
+      int lo = 0, hi = 0;
+      if (s_idx < n_slabs) { lo = sl[s_idx]; hi = sl[n_slabs + s_idx]; }
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(lo), "+v"(hi) : : "memory");
+      __syncthreads();
+      if ((wv & 1) == 0 && lane == 0 && s_idx < n_slabs) {
+        const int r0 = s_idx * IPPM_SLAB_ROWS, r1 = r0 + IPPM_SLAB_ROWS;
+        const bool meets = xr > xl && yd > yu && xl < r1 && xr > r0;
+        sl[s_idx] = meets ? yu : IPPM_SLAB_EMPTY_LO;
+        sl[n_slabs + s_idx] = meets ? yd : 0;
+      }
+      if (!full) {
+        by0 = lo; by1 = hi;
+        if (col_align > 0 && by1 > by0) { by0 &= ~(col_align - 1); by1 = min(gy, (by1 + col_align - 1) & ~(col_align - 1)); }
+        bx0 = 0; bx1 = gx;      // (rows: the slab's own 16, i.e. this wavefront's 8)
+      }
     }
     if (by1 <= by0) return;
     const ippm_k3_u4 t = {__float_as_uint(lp), __float_as_uint(lp), __float_as_uint(lp), __float_as_uint(lp)};
@@ -781,7 +805,7 @@ extern "C" int ippm_reset_maps(ippm_ctx* ctx, const int64_t* episode, const int3
   const int fill_chunks = (c.grid_x + IPPM_RESET_ROWS - 1) / IPPM_RESET_ROWS, sense_parts = (h_max + 31) / 32;
   dim3 grid((unsigned)(fill_chunks + sense_parts), (unsigned)(c.n_agents + 1), (unsigned)n_envs);
   IPPM_LAUNCH(ctx, IPPM_T_RESET_MAPS, k_reset_maps, grid, dim3(256), S_(stream), ctx->dcfg, episode, pos, truth, local, global, flips, code, rect,
-              ws, full ? 1 : 0, fill_chunks, ctx->n_active, (c.grid_y % 32 == 0) ? ctx->knob_reset_align : 0);
+              ws, full ? 1 : 0, fill_chunks, ctx->n_active, (c.grid_y % 32 == 0) ? ctx->knob_reset_align : 0, ctx->slabs, ippm_slab_count(ctx));
   IPPM_LAUNCH_CHECK("reset_maps");
   return 0;
 }

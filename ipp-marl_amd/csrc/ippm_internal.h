@@ -28,6 +28,12 @@
 #define PL_Y1 4
 #define PL_LAST 5     // index of the last op (its outputs stay unclamped)
 #define WS_OPS 16
+// ---- dirty slabs (ippm_set_dirty_slabs): int32 [E, N+1, 2, NS], NS = ceil(grid_x / IPPM_SLAB_ROWS); [.., 0, s] = lowest column written in rows
+// [16 s, 16 s + 16) of the map since the episode's reset, [.., 1, s] = one past the highest; empty: (IPPM_SLAB_EMPTY_LO, 0).  Marked with
+// fire-and-forget atomicMin / atomicMax by the plan kernel (the step's plans: planning wavefront; the footprints K3 will sense: K1 wavefront), consumed
+// and re-armed slab by slab by ippm_reset_maps' FILL workgroups.
+#define IPPM_SLAB_ROWS 16
+#define IPPM_SLAB_EMPTY_LO 0x7FFFFFFF
 #define OP_WORDS 8
 #define OP_TYPE 0     // 0 = clamp only, 1 = fuse measurement
 #define OP_SRC 1      // source agent j of the measurement
@@ -63,6 +69,7 @@ struct ippm_ctx {
   // tuning knobs, resolved ONCE at ippm_ctx_create (the work buffer's size, the plan kernel's item layout and the fusion launch
   // all derive from them and must agree for the context's lifetime)
   int knob_wave_rows, knob_persist, knob_nowork, knob_split, knob_tile_waves, knob_tile_rotate, knob_plan_builders, knob_k3_dense, knob_terrain_one_launch, knob_reset_align;
+  int32_t* slabs = nullptr;    // ippm_set_dirty_slabs: per (env, map, 16-row slab) the column interval written since the episode's reset (device, caller-owned)
   const int32_t* n_active;   // device int32 [E] or nullptr: agents flying in each env (ippm_set_team_sizes)
   int k3_wpg, k3_chn, k3_go;        // workgroup shape of the env-only step's K3 (wavefronts per workgroup, loads in flight per lane)
   float2* d_roots;           // e^{2 pi i k / 1024}, k = 0..1023: the twiddle table of the terrain transforms (terrain.hip)
@@ -97,6 +104,7 @@ int ippm_work_env_cap(const ippm_ctx* ctx, int n_envs);    // items an env's sli
 // [E][cap] items of 4 words {run's first group | lane-loads << 16, first row, region's first group | groups per row << 16,
 // op mask | map slot << 24}, cap = ippm_tile_env_cap().
 int ippm_tile_env_cap(const ippm_ctx* ctx);
+static inline int ippm_slab_count(const ippm_ctx* ctx) { return (ctx->cfg.grid_x + IPPM_SLAB_ROWS - 1) / IPPM_SLAB_ROWS; }   // dirty slabs per map
 int ippm_launch_fuse_tiles(ippm_ctx* ctx, float* local, float* global, const uint8_t* code, int32_t* ws, double* sums, double* area,
                            const int32_t* work, int n_envs, hipStream_t st);   // fuse_tiles.hip (area != nullptr: area sums tracked)
 #define IPPM_WORK_TILED 0x40000000     // tag of a count written in the tile form (a kernel of the other form skips the list)

@@ -178,5 +178,14 @@ __device__ __forceinline__ void box_union(int32_t* wm, int x0, int x1, int y0, i
   wm[wy] = ay0 | (ay1 << 16);
 }
 
+// dirty slabs of a map (ippm_set_dirty_slabs): rows [x0, x1) x columns [y0, y1) have been (or are about to be) written.  sl = the map's
+// [2, ns] record.  No return values are used: the atomics are issued and forgotten.
+__device__ __forceinline__ void slab_mark(int32_t* sl, int ns, int x0, int x1, int y0, int y1) {
+  if (x1 <= x0 || y1 <= y0) return;
+  for (int s = x0 / IPPM_SLAB_ROWS; s <= (x1 - 1) / IPPM_SLAB_ROWS && s < ns; ++s) {
+    atomicMin(sl + s, y0);
+    atomicMax(sl + ns + s, y1);
+  }
+}
 
 #endif  // __HIPCC__

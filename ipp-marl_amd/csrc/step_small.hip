@@ -405,7 +405,8 @@ k_plan_step(int32_t* __restrict__ pos, const int32_t* __restrict__ rect, int32_t
             const float* __restrict__ probs,
             const int32_t* __restrict__ action_in, uint8_t* __restrict__ mask, int32_t* __restrict__ action,
             int32_t* __restrict__ fault, int32_t* __restrict__ rect_next, int agent_sel, int32_t* __restrict__ work,
-            int wave_rows, int env_cap, unsigned long long* __restrict__ stamps, const int32_t* __restrict__ n_active) {
+            int wave_rows, int env_cap, unsigned long long* __restrict__ stamps, const int32_t* __restrict__ n_active,
+            int32_t* __restrict__ slabs, int n_slabs) {
   // (argument order = latency order: what the first loads need -- positions, footprints, the maps' clamp state, the team size --
   // arrives in SGPRs with the wavefront, so the loads go out before anything else has been read)
   // Wavefront 0 plans (comm matrix, fusion plans, written-cells boxes).  With a tile-form work list the workgroup carries more
@@ -508,6 +509,20 @@ k_plan_step(int32_t* __restrict__ pos, const int32_t* __restrict__ rect, int32_t
       int32_t* wm = ws + (size_t)(e * (n + 1) + lane) * IPPM_WS_WORDS;
       const int32_t* hdr = wm + WS_PLAN;
       box_union(wm, hdr[PL_X0], hdr[PL_X1], hdr[PL_Y0], hdr[PL_Y1]);
+      if (slabs) {
+        // ... and, finer, the dirty slabs: per 16-row slab the column interval of the ops that meet it (tile form: the op rectangles are
+        // in LDS; row form: the plan's hull, which is what that fusion walks)
+        int32_t* sl = slabs + (size_t)(e * (n + 1) + lane) * 2 * n_slabs;
+        if (tiled) {
+          const int nops = s_nops[lane];
+          for (int k = 0; k < nops; ++k) {
+            const int4 r = s_ops[lane * IPPM_MAX_OPS + k];      // {yu, yd, xl, xr}
+            slab_mark(sl, n_slabs, r.z, r.w, r.x, r.y);
+          }
+        } else {
+          slab_mark(sl, n_slabs, hdr[PL_X0], hdr[PL_X1], hdr[PL_Y0], hdr[PL_Y1]);
+        }
+      }
     }
     // row-run form of the work list: items of this env's plans into the env's own slice (exclusive scan of the lanes' counts)
     if (work && !tiled) {
@@ -582,6 +597,7 @@ k_plan_step(int32_t* __restrict__ pos, const int32_t* __restrict__ rect, int32_t
     r[0] = make_int4(cl[0], cl[1], cl[2], cl[3]);
     r[1] = make_int4(__float_as_int(c->logit_meas[k][0] - lp), __float_as_int(c->logit_meas[k][1] - lp), (int)c->flip_threshold[k], 0);
     if (ws) box_union(ws + (size_t)(e * (n + 1) + lane) * IPPM_WS_WORDS, cl[2], cl[3], cl[0], cl[1], WS_SBOX_X, WS_SBOX_Y);   // what K3 senses next
+    if (slabs) slab_mark(slabs + (size_t)(e * (n + 1) + lane) * 2 * n_slabs, n_slabs, cl[2], cl[3], cl[0], cl[1]);
   }
   PLAN_STAMP(6);
 }
@@ -681,7 +697,7 @@ extern "C" int ippm_plan_step(ippm_ctx* ctx, const int64_t* episode, int32_t* po
   IPPM_LAUNCH(ctx, IPPM_T_PLAN, k_plan_step, dim3(n_envs), dim3(64 * plan_waves), S_(stream), pos, rect, ws, ctx->cfg.n_agents, flags, t, policy,
                      ctx->dcfg, episode, comm_range, draws, comm, probs, action_in, mask, action, fault, rect_next, -1, plans ? work : nullptr,
                      ippm_fuse_wave_rows(ctx, n_envs), (flags & IPPM_STEP_TILES) ? ippm_tile_env_cap(ctx) : ippm_work_env_cap(ctx, n_envs),
-                     ctx->dcounters, ctx->n_active);
+                     ctx->dcounters, ctx->n_active, ctx->slabs, ippm_slab_count(ctx));
   IPPM_LAUNCH_CHECK("plan_step");
   return 0;
 }

@@ -70,6 +70,8 @@ PROTOTYPES = {
     "ippm_sense_update": [P, P, P, P, P, P, P, P, P, I32, I32, I32, P],
     "ippm_sense_step": [P, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, P],
     "ippm_set_team_sizes": [P, P],
+    "ippm_dirty_slab_words": [P, I32, P],
+    "ippm_set_dirty_slabs": [P, P],
     "ippm_plan_step": [P, P, P, P, P, P, P, P, I32, I32, P, P, I32, P, P, P, P, P, I32, P],
     "ippm_fuse_step": [P, P, P, P, P, P, P, P, I32, P],
     "ippm_reward_finalize": [P, P, P, I32, P],

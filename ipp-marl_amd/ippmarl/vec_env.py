@@ -110,6 +110,18 @@ class VecEnv:
                 raise ValueError(f"team_sizes: {E} values in 1..{N} (params' n_agents is the capacity)")
             self.n_active = ts.to(dev)
             self.ctx.call("ippm_set_team_sizes", self._p(self.n_active))
+        # Dirty slabs (IPPM_DIRTY_SLABS=1; env-only form, 16-byte layout): per 16-row slab of every map the column interval written since
+        # the episode's reset, marked by the plan kernel and consumed by ippm_reset_maps -- a finer account of what the reset has to fill
+        # than one box per map (42 % / 69 % of a local / the global map against 51 % / 87 %; 38 % / 58 % are written).  Built, tested and
+        # measured in round 6, and OFF by default: the marks (~70 fire-and-forget atomics per map and step) cost the plan kernel 3.8 us a
+        # step (14.8 -> 18.5) and the fill did not get faster for its 18 % fewer bytes (161 against 162 us on the box it was timed on:
+        # it issues a store per row and wavefront whatever the interval's width) -- profiles/r06/dirty_slabs_ab.txt.
+        self.slabs = None
+        if not track_area and d.vec == 4 and os.environ.get("IPPM_DIRTY_SLABS", "0") == "1":
+            words = np.zeros(1, dtype=np.int64)
+            self.ctx.call("ippm_dirty_slab_words", E, words.ctypes.data)
+            self.slabs = z(int(words[0]), dtype=torch.int32)
+            self.ctx.call("ippm_set_dirty_slabs", self._p(self.slabs))
         self.comm = z(E, N, N, dtype=torch.uint8)
         self.comm_range = z(E, dtype=torch.float32)
         self.mask = z(E, N, A, dtype=torch.uint8)

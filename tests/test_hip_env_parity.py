@@ -684,6 +684,59 @@ def test_split_batch_on_two_streams_equals_the_batch():
         assert int(split.fault.abs().sum()) == 0
 
 
+@pytest.mark.parametrize("name,over,n_envs,slabs", [("c2", {}, 40, True), ("c2", {}, 40, False), ("small", dict(experiment__missions__n_agents=5, experiment__constraints__num_actions=27), 33, True),
+                                                   ("default", dict(experiment__missions__n_agents=2), 6, True), ("c4", dict(experiment__uav__fix_range=False), 9, True)])
+def test_reset_leaves_nothing_of_the_last_episode(name, over, n_envs, slabs, monkeypatch):
+    """The env-only reset writes the prior only where the finished episode wrote (per 16-row dirty slab of every map, marked by the
+    plan kernel -- ippm_set_dirty_slabs, IPPM_DIRTY_SLABS=1 -- or, the default, one bounding box per map) and senses the start footprints in the same
+    launch.  After every reset of three waves of random-policy episodes: every cell of every local map outside its agent's start
+    footprint is EXACTLY the prior (log-odds 0), every cell of the global maps is, the cells inside the footprints are the two
+    measurement log-odds, and the slab records are re-armed to exactly the start footprints.  (A cell the fill missed would carry the
+    last episode's belief into the next one; the oracle comparisons of the other tests would see it only where a footprint meets it.)"""
+    from ippmarl.vec_env import POLICY_UNIFORM
+    from ippmarl import _ffi
+    monkeypatch.setenv("IPPM_DIRTY_SLABS", "1" if slabs else "0")
+    params = make_params(name, **over)
+    env = _env(params, n_envs, track_area=False, terrain="random_field" if name != "default" else "split")
+    assert (env.slabs is not None) == slabs
+    d = env.d
+    T = d.budget + 1
+    for wave in range(3):
+        env.reset(np.arange(1, n_envs + 1) + 1000 * wave)
+        rect = env.rect.cpu().numpy()                      # [E, N, (yu, yd, xl, xr)] of the start positions
+        local = env.local.cpu().numpy()
+        assert not env.glob.ne(0).any(), wave
+        inside = np.zeros(local.shape, dtype=bool)
+        for e in range(n_envs):
+            for i in range(d.n_agents):
+                yu, yd, xl, xr = rect[e, i]
+                inside[e, i, xl:xr, yu:yd] = True
+        assert not (local[~inside] != 0).any(), (wave, int((local[~inside] != 0).sum()))
+        vals = np.unique(local[inside])
+        assert len(vals) <= 2 and np.all(vals != 0), vals       # (all UAVs start at 15 m: one pair of measurement log-odds)
+        if slabs:
+            ns = (d.grid_x + 15) // 16
+            sl = env.slabs.view(n_envs, d.n_agents + 1, 2, ns).cpu().numpy()
+            assert np.all(sl[:, d.n_agents, 0] == 0x7FFFFFFF) and np.all(sl[:, d.n_agents, 1] == 0)      # global maps: nothing yet
+            for e in range(n_envs):
+                for i in range(d.n_agents):
+                    yu, yd, xl, xr = rect[e, i]
+                    for k in range(ns):
+                        meets = xl < 16 * k + 16 and xr > 16 * k and xr > xl and yd > yu
+                        assert (sl[e, i, 0, k], sl[e, i, 1, k]) == ((yu, yd) if meets else (0x7FFFFFFF, 0)), (wave, e, i, k)
+        for t in range(T):
+            env.steps(t, policy=POLICY_UNIFORM, features=False)
+        if slabs:     # what the episode marked covers what it wrote
+            sl = env.slabs.view(n_envs, d.n_agents + 1, 2, -1).cpu().numpy()
+            maps = np.concatenate([env.local.cpu().numpy(), env.glob.cpu().numpy()[:, None]], axis=1) != 0      # [E, N+1, gx, gy]
+            cols = np.arange(d.grid_y)
+            for k in range(sl.shape[-1]):
+                written = maps[:, :, 16 * k:16 * k + 16].any(axis=2)                                           # [E, N+1, gy]
+                marked = (cols[None, None] >= sl[:, :, 0, k, None]) & (cols[None, None] < sl[:, :, 1, k, None])
+                assert not (written & ~marked).any(), (wave, k)
+        env.check_faults()
+
+
 @pytest.mark.parametrize("parts", [2, 3])
 def test_staggered_sub_batches_fly_the_same_episodes(parts):
     """SplitVecEnv.start / advance (bench.py's default loop): every part in its own phase of the episode -- part k runs k * T / parts
