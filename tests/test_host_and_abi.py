@@ -351,3 +351,22 @@ def test_hot_plane_layout_is_aligned_and_disjoint():
         end = off + n
     assert total % (2 << 20) == 0 and total >= end and total - end < (2 << 20)
 
+
+def test_tools_and_gpu_scripts_parse():
+    """tools/ holds the round's probes and gpurun scripts (not product code, none of it imported by the package): every Python file
+    there compiles and every shell script passes `bash -n`, so that a call on the GPU box does not die on a typo."""
+    import glob
+    import subprocess
+    tools = os.path.join(ROOT, "tools")
+    scripts = sorted(glob.glob(os.path.join(tools, "*.py")))
+    assert len(scripts) > 30
+    for path in scripts:
+        compile(open(path).read(), path, "exec")
+    for path in sorted(glob.glob(os.path.join(tools, "*.sh"))):
+        assert subprocess.run(["bash", "-n", path]).returncode == 0, path
+    # nothing under tools/ or oracle/ is imported by the product package
+    for path in glob.glob(os.path.join(ROOT, "ipp-marl_amd", "ippmarl", "**", "*.py"), recursive=True):
+        text = open(path).read()
+        assert "import oracle" not in text and "from oracle" not in text and "ipp_oracle" not in text.replace("oracle/ipp_oracle.py", ""), path
+        assert "from tools" not in text and "import tools" not in text, path
+
