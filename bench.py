@@ -100,7 +100,9 @@ def cpu_baseline(args, seconds=10.0):
     return {"value": steps1 / dt1, "unit": "agent-env steps/s", "cores": 1, "kind": "port", "host_cores": cores,
             "torch_threads": torch.get_num_threads(), "numpy_threads": 1,
             "form": "the oracle steps ONE env at a time, like the reference (missions/episode_generator.py:39-40); it has no form vectorised "
-                    "over envs, so the many-env figure is processes x one env each, not SURVEY 8d's E=64 vectorised stepper",
+                    "over envs, so the many-env figure is processes x one env each, not SURVEY 8d's E=64 vectorised stepper -- which would not "
+                    "read differently per core: one env step of the oracle already is ~16 full-grid NumPy passes (every fusion clips and updates "
+                    "all 65 536 cells, mappings.py:109-124) of ~0.4 ms each, so batching 64 envs into each pass multiplies cells and time alike",
             "sample": f"{steps1} agent-env steps of 1 env ({shape}) in {dt1:.1f}s of the NumPy oracle on 1 of {cores} host cores",
             "many_env": {"value": stepsN / dtN, "unit": "agent-env steps/s", "cores": procs, "envs": per * procs,
                          "sample": f"{stepsN} agent-env steps of {per * procs} envs in {dtN:.1f}s, {procs} oracle processes "

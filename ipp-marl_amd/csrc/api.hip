@@ -115,6 +115,11 @@ extern "C" int ippm_ctx_create(const ippm_config* cfg, ippm_ctx** out) {
     // 1024^2 91.3 -> 96.6: the parts of a footprint first there
     ctx->k3_go = knob("IPPM_K3_GO", wmax <= 32 ? 1 : 0);
   }
+  // the tile fusion's column intervals rounded outwards to whole 128-byte lines (step_small.hip, tile_build_map): 1 on, 0 off, default: on
+  // for rows of at least 512 cells.  Measured (round 6, profiles/r06/tile_round_ab.txt): 512^2 x 8 UAVs fusion 1045 -> 1024 us and the K3
+  // behind it 286 -> 275; 256^2 x 4 UAVs fusion 74.7 -> 83-87 us (a 90-cell row grows from 3.7 to 4.7 lines' worth of lane-loads there)
+  ctx->knob_tile_round = knob("IPPM_TILE_ROUND", -1);
+  if (ctx->knob_tile_round < 0) ctx->knob_tile_round = ctx->cfg.grid_y >= 512 ? 1 : 0;
   ctx->knob_reset_align = knob("IPPM_RESET_ALIGN", 32);   // cells the reset's fill boxes are rounded outwards to (32 = a 128-byte line; 0: not)
   if (ctx->knob_reset_align & (ctx->knob_reset_align - 1)) ctx->knob_reset_align = 32;
   ctx->knob_terrain_one_launch = knob("IPPM_TERRAIN_ONE_LAUNCH", 0);   // 1: ippm_terrain_truth's second pass as one launch (terrain.hip: measured, no gain)

@@ -285,8 +285,12 @@ __device__ __forceinline__ void tile_emit_region(int4* items, int env_cap, int32
 // every lane writing its own slab's items one by one the wave ran as long as its longest slab at every step of the walk -- at
 // config 5's shape (17 plans of up to 17 rectangles on 1024^2, thousands of items per map) that was most of the plan kernel's
 // 144 us.  The order of an env's items in its list is whatever the atomics make it; no result depends on it.
+// round_mask / G: column intervals are rounded OUTWARDS to multiples of round_mask + 1 groups (7: whole 128-byte lines; 0: not), capped at the
+// G groups of a row, before they are merged -- so that a row segment of an item starts and ends on line boundaries and every line
+// it touches is written whole.  The cells this adds are met by no op: the fusion clips them (as the reference clips EVERY cell of a map
+// at every fusion, mappings.py:110-111) and writes them back; intervals whose rounded ranges touch are merged, so no cell is in two items.
 __device__ __forceinline__ void tile_build_map(const int4* s_ops, int nops, int env, int slot, int4* items, int env_cap, int32_t* s_items,
-                                               int lane) {
+                                               int lane, int round_mask, int G) {
   const int n_edges = 2 * nops;
   int4 rc = make_int4(0, 0, 0, 0);
   if (lane < nops) rc = s_ops[lane];
@@ -322,7 +326,7 @@ __device__ __forceinline__ void tile_build_map(const int4* s_ops, int nops, int 
       o = tb_lane_i(order, r);  // op with the r-th smallest first column
       const int yu = tb_lane_i(r_yu, o), yd = tb_lane_i(r_yd, o), xl = tb_lane_i(r_xl, o), xr = tb_lane_i(r_xr, o);
       in = slab_on && xl <= xa && xa < xr;
-      lo = yu >> 2; hi = (yd + 3) >> 2;
+      lo = (yu >> 2) & ~round_mask; hi = min(G, (((yd + 3) >> 2) + round_mask) & ~round_mask);
       done = in && mask != 0 && lo > g1;  // a gap of at least one group: the interval so far is complete
     }
     // finished intervals go out now.  A small region (config 2: three items on average) is written by its own lane, all lanes
@@ -406,7 +410,7 @@ k_plan_step(int32_t* __restrict__ pos, const int32_t* __restrict__ rect, int32_t
             const int32_t* __restrict__ action_in, uint8_t* __restrict__ mask, int32_t* __restrict__ action,
             int32_t* __restrict__ fault, int32_t* __restrict__ rect_next, int agent_sel, int32_t* __restrict__ work,
             int wave_rows, int env_cap, unsigned long long* __restrict__ stamps, const int32_t* __restrict__ n_active,
-            int32_t* __restrict__ slabs, int n_slabs) {
+            int32_t* __restrict__ slabs, int n_slabs, int tile_round) {
   // (argument order = latency order: what the first loads need -- positions, footprints, the maps' clamp state, the team size --
   // arrives in SGPRs with the wavefront, so the loads go out before anything else has been read)
   // Wavefront 0 plans (comm matrix, fusion plans, written-cells boxes).  With a tile-form work list the workgroup carries more
@@ -560,7 +564,7 @@ k_plan_step(int32_t* __restrict__ pos, const int32_t* __restrict__ rect, int32_t
       if (owner != b) continue;
       const int m = mm == 0 ? n : mm - 1;   // the global map's items come early: they carry the reward arithmetic
       const int nops = __builtin_amdgcn_readfirstlane(s_nops[m]);
-      if (nops > 0) tile_build_map(s_ops + m * IPPM_MAX_OPS, nops, e, m, items, env_cap, &s_items, lane);
+      if (nops > 0) tile_build_map(s_ops + m * IPPM_MAX_OPS, nops, e, m, items, env_cap, &s_items, lane, tile_round, (c->grid_y + 3) >> 2);
     }
     PLAN_STAMP(4);
     int last = 0;
@@ -697,7 +701,8 @@ extern "C" int ippm_plan_step(ippm_ctx* ctx, const int64_t* episode, int32_t* po
   IPPM_LAUNCH(ctx, IPPM_T_PLAN, k_plan_step, dim3(n_envs), dim3(64 * plan_waves), S_(stream), pos, rect, ws, ctx->cfg.n_agents, flags, t, policy,
                      ctx->dcfg, episode, comm_range, draws, comm, probs, action_in, mask, action, fault, rect_next, -1, plans ? work : nullptr,
                      ippm_fuse_wave_rows(ctx, n_envs), (flags & IPPM_STEP_TILES) ? ippm_tile_env_cap(ctx) : ippm_work_env_cap(ctx, n_envs),
-                     ctx->dcounters, ctx->n_active, ctx->slabs, ippm_slab_count(ctx));
+                     ctx->dcounters, ctx->n_active, ctx->slabs, ippm_slab_count(ctx),
+                     (ctx->cfg.grid_y % 32 == 0 && ctx->knob_tile_round > 0) ? 7 : 0);
   IPPM_LAUNCH_CHECK("plan_step");
   return 0;
 }

@@ -356,8 +356,8 @@ __global__ __launch_bounds__((FourStep<N1, N2, Q>::THREADS)) void k_terrain_fft_
           // whole bound while its env's counter stood at 128 of 128, and at 256^2 the launch took 210 us for wake-ups that late.
           unsigned spins = 0;
           while (atomicCAS(rec + 2, 0xFFFFFFFFu, 0xFFFFFFFEu) < gridDim.x) {
-            __builtin_amdgcn_s_sleep(16);
-            if (++spins > (1u << 22)) {
+            __builtin_amdgcn_s_sleep(64);      // (~1.7 us between two looks: the counter's address is shared with every peer)
+            if (++spins > (1u << 21)) {
               atomicExch(rec + 3, 0xDEAD0000u | (unsigned)part);
               break;
             }
@@ -613,14 +613,16 @@ extern "C" int ippm_terrain_field(ippm_ctx* ctx, const int64_t* episode, const f
 // (min, max) in, meet at a counter with their rows in registers and threshold them (MODE 3).  It saves the second read of the half
 // spectrum (270 MB per 1024 fields of 256^2) and the second set of transforms, and gives most of that back to workgroups that sit
 // on their CU waiting for seven peers: 124 us against 67 + 71 for the pass, 212 against 223 us for a whole reset's terrain, and no
-// gain in the step (profiles/r06/terrain_one_launch_ab.txt).  Same truth bit for bit (tested at 3000 x 256^2, 700 x 512^2, 150 x 1024^2).
+// gain in the step (profiles/r06/terrain_one_launch_ab.txt).  Same truth bit for bit (tested at 3000 x 256^2, 700 x 512^2, 501 x 128^2).
 extern "C" int ippm_terrain_truth(ippm_ctx* ctx, const int64_t* episode, const float* amp, float* work, uint32_t* range_keys,
                                   uint8_t* truth, int32_t n_envs, void* stream) {
   if (!ctx || !episode || !amp || !work || !range_keys || !truth) { ippm_set_error("ippm_terrain_truth: null argument"); return -1; }
   if (terrain_pow2_check(ctx, "ippm_terrain_truth")) return -1;
   if (n_envs <= 0) return 0;
   if (int rc = terrain_launch_x(ctx, episode, amp, nullptr, reinterpret_cast<float2*>(work), range_keys, n_envs, S_(stream), 4)) return rc;
-  if (ctx->knob_terrain_one_launch)
+  // (at most 32 workgroups per env, i.e. fields up to 512 cells a side: with the 128 of a 1024^2 field the waiters' compare-and-swaps on
+  // one counter come close to what one address takes (~12 ns each) and a wait was seen to run into its bound once in a few runs)
+  if (ctx->knob_terrain_one_launch && ctx->cfg.grid_x <= 512)
     return terrain_launch_y<3>(ctx, reinterpret_cast<const float2*>(work), nullptr, range_keys, truth, n_envs, S_(stream), 4);
   if (int rc = terrain_launch_y<1>(ctx, reinterpret_cast<const float2*>(work), nullptr, range_keys, nullptr, n_envs, S_(stream), 4)) return rc;
   return terrain_launch_y<2>(ctx, reinterpret_cast<const float2*>(work), nullptr, range_keys, truth, n_envs, S_(stream), 4);

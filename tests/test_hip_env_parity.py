@@ -387,15 +387,16 @@ def test_random_field_terrain_native_path(name):
     assert not np.array_equal(got[0], got[2])
 
 
-@pytest.mark.parametrize("name,n_envs", [("c2", 3000), ("c4", 700), ("c5", 150), ("c2", 7)])
+@pytest.mark.parametrize("name,n_envs", [("c2", 3000), ("c4", 700), ("small", 501), ("c2", 7)])
 def test_one_launch_terrain_equals_the_two_pass_form(name, n_envs):
     """ippm_terrain_truth's second transform pass as ONE launch (IPPM_TERRAIN_ONE_LAUNCH=1: the workgroups of an env exchange the
     field's (min, max) inside the launch -- arrival counter, workgroups numbered by a start-order ticket, every cross-workgroup word
     moved by device-scope read-modify-writes -- and threshold the rows they hold in registers) against the default two launches
     (min / max, then the same transforms again for the bits): the same truth bit for bit, at batches far larger than the device holds
-    workgroups at once (3000 x 8 workgroups of 256 threads at 256^2; 128 workgroups per env at 1024^2), twice in a row on the same
+    workgroups at once (3000 x 8 workgroups of 256 threads at 256^2; 32 workgroups per env at 512^2), twice in a row on the same
     scratch (the counters are re-armed by pass X), every workgroup arrived and no wait gave up (fault words 0).
-    (The form is not the default: measured, it gains nothing in the step -- DESIGN.md section 8; what it found is kept: the passes'
+    (1024^2 fields keep the two launches: with 128 workgroups per env spinning on one counter a wait ran into its bound once in a few runs.
+    The form is not the default: measured, it gains nothing in the step -- DESIGN.md section 8; what it found is kept: the passes'
     complex products have a fixed contraction now, because the two launches of the default form used to disagree in a row's last
     bit once in a few hundred fields.)"""
     params = make_params(name, experiment__missions__n_agents=2)
@@ -417,7 +418,7 @@ def test_one_launch_terrain_equals_the_two_pass_form(name, n_envs):
         assert torch.equal(one.truth, two.truth), (name, n_envs, rep)
         one.check_faults()
         keys = env_terrain(one)._keys.view(-1)[: 4 * n_envs].view(n_envs, 4)
-        assert int(keys[:, 2].min()) == int(keys[:, 2].max()) == one.d.grid_x // {256: 32, 512: 16, 1024: 8}[one.d.grid_x]   # every workgroup arrived
+        assert int(keys[:, 2].min()) == int(keys[:, 2].max()) == one.d.grid_x // {128: 32, 256: 32, 512: 16}[one.d.grid_x]   # every workgroup arrived
     assert int(one.truth.max()) > 0 and int(one.truth.min()) < 255      # (fields, not constants)
 
 

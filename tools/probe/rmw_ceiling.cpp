@@ -41,6 +41,57 @@ __global__ __launch_bounds__(128) void k_rows(char* __restrict__ buf) {
   }
 }
 
+// The same footprints as k_rows, but every row segment ROUNDED OUTWARDS to whole 128-byte lines: the lanes of the partial lines at a row's
+// ends also load and store the cells next to the footprint (unchanged) -- more bytes requested, the same lines fetched, and every line written
+// whole instead of in part.  WL = lane-loads per row after rounding at most (W + 14 for a 16-byte phase: up to 7 groups at either end).
+template <int G, int ROWS, int W>
+__global__ __launch_bounds__(128) void k_rows_rounded(char* __restrict__ buf) {
+  constexpr int WL = ((W * 16 + 127 + 112) / 128) * 8;
+  const int m = blockIdx.y;
+  char* map = buf + (size_t)m * G * G * 4;
+  const unsigned h = (unsigned)m * 2654435761u;
+  const int x0 = (h >> 8) % (G - ROWS);
+  const int col0 = ((h >> 20) % ((G * 4 - W * 16) / 16)) * 16;
+  const int c0 = col0 & ~127, c1 = (col0 + W * 16 + 127) & ~127;       // the rounded byte range of a row
+  const int wl = (c1 - c0) / 16;
+  const int base = blockIdx.x * 256;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int t = base + q * 128 + threadIdx.x;
+    if (t < ROWS * wl) {
+      const int row = t / wl, g = t - row * wl;
+      float4* p = reinterpret_cast<float4*>(map + (size_t)(x0 + row) * (G * 4) + c0 + g * 16);
+      float4 v = *p;
+      const bool in = c0 + g * 16 >= col0 && c0 + g * 16 < col0 + W * 16;
+      if (in) { v.x += 1.f; v.y += 1.f; v.z += 1.f; v.w += 1.f; }
+      *p = v;
+    }
+  }
+  (void)WL;
+}
+
+template <int G, int ROWS, int W>
+static void rows_rounded(char* buf, int maps, const char* name) {
+  constexpr int WL = ((W * 16 + 127 + 112) / 128) * 8;
+  const dim3 grid((ROWS * WL + 255) / 256, maps);
+  hipEvent_t a, b;
+  CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+  hipLaunchKernelGGL((k_rows_rounded<G, ROWS, W>), grid, dim3(128), 0, 0, buf);
+  CHECK(hipDeviceSynchronize());
+  float best = 1e30f, sum = 0.f;
+  for (int rep = 0; rep < 10; ++rep) {
+    CHECK(hipEventRecord(a));
+    hipLaunchKernelGGL((k_rows_rounded<G, ROWS, W>), grid, dim3(128), 0, 0, buf);
+    CHECK(hipEventRecord(b));
+    CHECK(hipEventSynchronize(b));
+    float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+    best = ms < best ? ms : best; sum += ms;
+  }
+  const double useful = 2.0 * maps * ROWS * W * 16;
+  printf("{\"kernel\": \"%s\", \"maps\": %d, \"useful_MB\": %.1f, \"avg_us\": %.1f, \"min_us\": %.1f, \"useful_GBps\": %.0f}\n", name, maps, useful / 1e6,
+         sum / 10 * 1e3, best * 1e3, useful / (sum / 10 * 1e-3) / 1e9);
+}
+
 template <int G, int ROWS, int W>
 static void rows(char* buf, int maps, const char* name) {
   const dim3 grid((ROWS * W + 255) / 256, maps);
@@ -67,6 +118,52 @@ static void rows(char* buf, int maps, const char* name) {
   const double req = 2.0 * maps * ROWS * W * 16, touched = 2.0 * lines * 128;
   printf("{\"kernel\": \"%s\", \"maps\": %d, \"requested_MB\": %.1f, \"lines_MB\": %.1f, \"avg_us\": %.1f, \"min_us\": %.1f, \"requested_GBps\": %.0f, \"lines_GBps\": %.0f}\n",
          name, maps, req / 1e6, touched / 1e6, sum / 10 * 1e3, best * 1e3, req / (sum / 10 * 1e-3) / 1e9, touched / (sum / 10 * 1e-3) / 1e9);
+}
+
+// The same bare read-modify-write over RUNS of contiguous bytes: per 256 KiB map NRUNS runs of RUN bytes, PITCH bytes apart, the first one
+// at a pseudo-random multiple of ALIGN bytes.  Rows of a row-major map are runs of 368 B at a pitch of 1 KiB; a map stored as 128-byte tiles of
+// 8 rows x 4 cells (tile rows of 64 tiles = 8 KiB) gives a 90 x 90 footprint 12 runs of 23 tiles = 2944 B; as tiles of 4 rows x 8 cells (tile
+// rows of 32 tiles = 4 KiB) 23 runs of 12 tiles = 1536 B -- what a blocked layout of the maps could reach at best.
+template <int RUN, int PITCH, int NRUNS, int ALIGN>
+__global__ __launch_bounds__(128) void k_runs(char* __restrict__ buf) {
+  constexpr int W = RUN / 16;
+  const int m = blockIdx.y;
+  char* map = buf + (size_t)m * 262144;
+  const unsigned h = (unsigned)m * 2654435761u;
+  const int span = 262144 - (NRUNS - 1) * PITCH - RUN;
+  const int start = (int)((h >> 8) % (unsigned)(span / ALIGN)) * ALIGN;
+  const int base = blockIdx.x * 256;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int t = base + q * 128 + threadIdx.x;
+    if (t < NRUNS * W) {
+      const int r = t / W, g = t - r * W;
+      float4* p = reinterpret_cast<float4*>(map + start + (size_t)r * PITCH + g * 16);
+      float4 v = *p; v.x += 1.f; v.y += 1.f; v.z += 1.f; v.w += 1.f; *p = v;
+    }
+  }
+}
+
+template <int RUN, int PITCH, int NRUNS, int ALIGN>
+static void runs(char* buf, int maps, const char* name) {
+  constexpr int W = RUN / 16;
+  const dim3 grid((NRUNS * W + 255) / 256, maps);
+  hipEvent_t a, b;
+  CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+  hipLaunchKernelGGL((k_runs<RUN, PITCH, NRUNS, ALIGN>), grid, dim3(128), 0, 0, buf);
+  CHECK(hipDeviceSynchronize());
+  float best = 1e30f, sum = 0.f;
+  for (int rep = 0; rep < 10; ++rep) {
+    CHECK(hipEventRecord(a));
+    hipLaunchKernelGGL((k_runs<RUN, PITCH, NRUNS, ALIGN>), grid, dim3(128), 0, 0, buf);
+    CHECK(hipEventRecord(b));
+    CHECK(hipEventSynchronize(b));
+    float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+    best = ms < best ? ms : best; sum += ms;
+  }
+  const double req = 2.0 * maps * NRUNS * RUN;
+  printf("{\"kernel\": \"%s\", \"maps\": %d, \"requested_MB\": %.1f, \"avg_us\": %.1f, \"min_us\": %.1f, \"requested_GBps\": %.0f}\n", name, maps, req / 1e6,
+         sum / 10 * 1e3, best * 1e3, req / (sum / 10 * 1e-3) / 1e9);
 }
 
 int main() {
@@ -100,6 +197,19 @@ int main() {
   // config 4's: 512^2 maps, footprints 180 cells a side (46 lane-loads per row)
   rows<512, 180, 46>(buf, 6144, "rows 512^2, 180 x 46 groups (15 m), 6144 maps");
   rows<512, 120, 31>(buf, 6144, "rows 512^2, 120 x 31 groups (10 m), 6144 maps");
+  // the same footprints with every row segment rounded outwards to whole lines (compare avg_us with the rows above: same useful bytes)
+  rows_rounded<256, 90, 23>(buf, 4096, "rows ROUNDED to whole lines 256^2, 90 x 23 groups, 4096 maps");
+  rows_rounded<256, 90, 23>(buf, 12288, "rows ROUNDED to whole lines 256^2, 90 x 23 groups, 12288 maps");
+  rows_rounded<256, 60, 16>(buf, 12288, "rows ROUNDED to whole lines 256^2, 60 x 16 groups, 12288 maps");
+  rows_rounded<256, 30, 8>(buf, 24576, "rows ROUNDED to whole lines 256^2, 30 x 8 groups, 24576 maps");
+  rows_rounded<512, 180, 46>(buf, 6144, "rows ROUNDED to whole lines 512^2, 180 x 46 groups, 6144 maps");
+  // what a blocked layout of the 256^2 maps could reach: the 90 x 90 footprint as runs of whole 128-byte tiles
+  runs<368, 1024, 90, 16>(buf, 12288, "runs: 90 x 368 B at 1 KiB pitch, 16-byte phase (= rows 256^2 above), 12288 maps");
+  runs<384, 1024, 90, 128>(buf, 12288, "runs: 90 x 384 B at 1 KiB pitch, line-aligned (rows forced onto line boundaries), 12288 maps");
+  runs<1536, 4096, 23, 128>(buf, 12288, "runs: 23 x 1536 B at 4 KiB pitch (tiles of 4 rows x 8 cells), 12288 maps");
+  runs<2944, 8192, 12, 128>(buf, 12288, "runs: 12 x 2944 B at 8 KiB pitch (tiles of 8 rows x 4 cells), 12288 maps");
+  runs<11776, 32768, 3, 128>(buf, 12288, "runs: 3 x 11776 B at 32 KiB pitch (tiles of 32 rows x 1 cell-group... i.e. column-blocked), 12288 maps");
+  runs<35328, 65536, 1, 128>(buf, 12288, "runs: 1 x 35328 B (a footprint stored contiguously), 12288 maps");
   CHECK(hipFree(buf));
   return 0;
 }
