@@ -120,6 +120,8 @@ extern "C" int ippm_ctx_create(const ippm_config* cfg, ippm_ctx** out) {
   // behind it 286 -> 275; 256^2 x 4 UAVs fusion 74.7 -> 83-87 us (a 90-cell row grows from 3.7 to 4.7 lines' worth of lane-loads there)
   ctx->knob_tile_round = knob("IPPM_TILE_ROUND", -1);
   if (ctx->knob_tile_round < 0) ctx->knob_tile_round = ctx->cfg.grid_y >= 512 ? 1 : 0;
+  ctx->knob_k3_round = knob("IPPM_K3_ROUND", -1);        // the same for K3's row segments (env_step.hip)
+  if (ctx->knob_k3_round < 0) ctx->knob_k3_round = ctx->cfg.grid_y >= 512 ? 1 : 0;
   ctx->knob_reset_align = knob("IPPM_RESET_ALIGN", 32);   // cells the reset's fill boxes are rounded outwards to (32 = a 128-byte line; 0: not)
   if (ctx->knob_reset_align & (ctx->knob_reset_align - 1)) ctx->knob_reset_align = 32;
   ctx->knob_terrain_one_launch = knob("IPPM_TERRAIN_ONE_LAUNCH", 0);   // 1: ippm_terrain_truth's second pass as one launch (terrain.hip: measured, no gain)

@@ -329,7 +329,7 @@ k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int sta
               const ippm_config* __restrict__ c, const int32_t* __restrict__ pos,
               const uint8_t* __restrict__ flips, int32_t* __restrict__ rect_out, int32_t* __restrict__ ws,
               double* __restrict__ sums, float* __restrict__ reward, unsigned long long* __restrict__ counters,
-              double* __restrict__ area, const int32_t* __restrict__ n_active) {
+              double* __restrict__ area, const int32_t* __restrict__ n_active, int col_round) {
   // Argument order = latency order.  A workgroup lives for one trip, so what stands in front of its map loads is paid by every
   // wavefront: with the config fields behind the config pointer behind the kernel-argument load, the footprint came in three
   // dependent scalar round trips.  The first 14 argument words arrive in SGPRs with the wavefront (kernel-argument preload,
@@ -381,8 +381,12 @@ k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int sta
   const int yu = r[0], yd = r[1], xl = r[2], xr = r[3];
   if (rect_out && part == 0 && threadIdx.x < 4) rect_out[(size_t)(e * n + i) * 4 + threadIdx.x] = r[threadIdx.x];
   const int h = xr - xl, w = yd - yu;
-  const int y0 = yu & ~(VEC - 1), tile_y0 = yu & ~3;
-  const int groups = (yd - y0 + VEC - 1) / VEC;
+  // col_round (cells; VEC = off, 32 = a 128-byte line; dense 16-byte form only): the row segments the workgroups walk are rounded
+  // OUTWARDS to whole lines.  The groups this adds lie outside the footprint's columns: loaded, left as they are (`inm` below is 0 for
+  // their cells) and stored back, so that every line of the footprint is written whole -- no truth, no code byte, no flag for them.
+  const int cr = (DENSE && VEC == 4 && !MIS) ? col_round : VEC;
+  const int y0 = yu & ~(cr - 1), tile_y0 = yu & ~3;
+  const int groups = (min(gy, (yd + cr - 1) & ~(cr - 1)) - y0 + VEC - 1) / VEC;
   // DENSE: the footprint's 4-cell groups in ROW-MAJOR order, T = row * W + group (W = groups per row), are dealt out in runs: a
   // wavefront takes CH * 64 consecutive ones, its lane's loads are T = base + q * 64 + lane -- a load instruction covers 64
   // consecutive groups (2.7 whole 368-byte row segments of a 15 m footprint at 256^2) and every wavefront but a footprint's last
@@ -533,7 +537,8 @@ k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int sta
         } else {
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m[q].v[0]), rmap, off, 0, IPPM_K3_STORE_AUX);
         }
-        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)obs, rcode, on[q] ? (int)tile_index<VEC>(row, y - tile_y0, S) : IPPM_K3_OOB, 0, 0);
+        // (a group outside the footprint's columns -- rounded row segments -- has no byte in the code tile)
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)obs, rcode, on[q] && inm != 0 ? (int)tile_index<VEC>(row, y - tile_y0, S) : IPPM_K3_OOB, 0, 0);
       }
       if (DENSE) break;   // (a part is exactly one trip of its four wavefronts)
     }
@@ -887,10 +892,14 @@ extern "C" int ippm_sense_step(ippm_ctx* ctx, const int64_t* episode, const int3
     // dense lane mapping (k_sense_tiles<..., DENSE>): a part is a run of wpg * chn * 64 of the footprint's row-major 4-cell groups
     // (W per row: one more than its width needs when it starts off a group boundary)
     const bool dense = ctx->vec == 4 && ctx->knob_k3_dense != 0;
+    // row segments rounded outwards to whole 128-byte lines (k_sense_tiles): dense form, rows a multiple of 32 cells long; on by default for
+    // rows of at least 512 cells (IPPM_K3_ROUND forces it on / off) -- profiles/r06/tile_round_ab.txt
+    const int col_round = (dense && (c.grid_y % 32) == 0 && ctx->knob_k3_round > 0) ? 32 : 4;
     if (dense) {
       int need = 1;
       for (int k = 0; k < c.space_z; ++k) {
-        const int wmax = (2 * c.radius_y[k] + 3) / 4 + 1;
+        int wmax = (2 * c.radius_y[k] + 3) / 4 + 1;
+        if (col_round > 4) wmax = std::min((c.grid_y + 3) / 4, (wmax + 2 * (col_round / 4 - 1) + col_round / 4 - 1) / (col_round / 4) * (col_round / 4));   // rounded row segments
         need = std::max(need, (2 * c.radius_x[k] * wmax + wpg * chn * 64 - 1) / (wpg * chn * 64));
       }
       parts = need;
@@ -904,7 +913,7 @@ extern "C" int ippm_sense_step(ippm_ctx* ctx, const int64_t* episode, const int3
 #define IPPM_K3T___(V, M, F, R, D, T, ...)                                                                                       \
   IPPM_LAUNCH(ctx, IPPM_T_SENSE, (k_sense_tiles<V, M, F, R, D, T __VA_OPT__(,) __VA_ARGS__>), grid, block, S_(stream), rect_in, c.n_agents, agent_sel, stage, rows_per_part, \
               c.grid_y, c.grid_x, local, truth, episode, code, c.tile_stride, c.logit_clip, (uint32_t)c.philox_seed,                 \
-              (uint32_t)(c.philox_seed >> 32), ctx->dcfg, pos, flips, rect_out, ws, sums, reward, ctx->dcounters, area, ctx->n_active)
+              (uint32_t)(c.philox_seed >> 32), ctx->dcfg, pos, flips, rect_out, ws, sums, reward, ctx->dcounters, area, ctx->n_active, col_round)
 #define IPPM_K3T__(V, M, F, R, D) do { if (area) IPPM_K3T___(V, M, F, R, D, true); else IPPM_K3T___(V, M, F, R, D, false); } while (0)
 #define IPPM_K3T_(V, M, F, R) do { if (dense) IPPM_K3T__(V, M, F, R, true); else IPPM_K3T__(V, M, F, R, false); } while (0)
 #define IPPM_K3T(V, M, F) do { if (rect_in) IPPM_K3T_(V, M, F, true); else IPPM_K3T_(V, M, F, false); } while (0)

@@ -68,7 +68,7 @@ struct ippm_ctx {
   int vec;                   // 4: 16-byte lane groups (grid_y >= 44), else 1
   // tuning knobs, resolved ONCE at ippm_ctx_create (the work buffer's size, the plan kernel's item layout and the fusion launch
   // all derive from them and must agree for the context's lifetime)
-  int knob_wave_rows, knob_persist, knob_nowork, knob_split, knob_tile_waves, knob_tile_rotate, knob_plan_builders, knob_k3_dense, knob_terrain_one_launch, knob_reset_align, knob_tile_round;
+  int knob_wave_rows, knob_persist, knob_nowork, knob_split, knob_tile_waves, knob_tile_rotate, knob_plan_builders, knob_k3_dense, knob_terrain_one_launch, knob_reset_align, knob_tile_round, knob_k3_round;
   int32_t* slabs = nullptr;    // ippm_set_dirty_slabs: per (env, map, 16-row slab) the column interval written since the episode's reset (device, caller-owned)
   const int32_t* n_active;   // device int32 [E] or nullptr: agents flying in each env (ippm_set_team_sizes)
   int k3_wpg, k3_chn, k3_go;        // workgroup shape of the env-only step's K3 (wavefronts per workgroup, loads in flight per lane)
