@@ -894,7 +894,7 @@ extern "C" int ippm_sense_step(ippm_ctx* ctx, const int64_t* episode, const int3
     const bool dense = ctx->vec == 4 && ctx->knob_k3_dense != 0;
     // row segments rounded outwards to whole 128-byte lines (k_sense_tiles): dense form, rows a multiple of 32 cells long; on by default for
     // rows of at least 512 cells (IPPM_K3_ROUND forces it on / off) -- profiles/r06/tile_round_ab.txt
-    const int col_round = (dense && (c.grid_y % 32) == 0 && ctx->knob_k3_round > 0) ? 32 : 4;
+    const int col_round = (dense && (c.grid_y % 32) == 0 && ctx->knob_k3_round > 0) ? ippm_round_cells(ctx->knob_k3_round) : 4;
     if (dense) {
       int need = 1;
       for (int k = 0; k < c.space_z; ++k) {

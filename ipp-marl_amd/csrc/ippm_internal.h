@@ -104,6 +104,8 @@ int ippm_work_env_cap(const ippm_ctx* ctx, int n_envs);    // items an env's sli
 // [E][cap] items of 4 words {run's first group | lane-loads << 16, first row, region's first group | groups per row << 16,
 // op mask | map slot << 24}, cap = ippm_tile_env_cap().
 int ippm_tile_env_cap(const ippm_ctx* ctx);
+// IPPM_TILE_ROUND / IPPM_K3_ROUND: 1 = whole 128-byte lines (32 cells); 8 / 16 / 32 = that many cells (measurement: half and quarter lines)
+static inline int ippm_round_cells(int knob) { return (knob == 8 || knob == 16 || knob == 32) ? knob : 32; }
 static inline int ippm_slab_count(const ippm_ctx* ctx) { return (ctx->cfg.grid_x + IPPM_SLAB_ROWS - 1) / IPPM_SLAB_ROWS; }   // dirty slabs per map
 int ippm_launch_fuse_tiles(ippm_ctx* ctx, float* local, float* global, const uint8_t* code, int32_t* ws, double* sums, double* area,
                            const int32_t* work, int n_envs, hipStream_t st);   // fuse_tiles.hip (area != nullptr: area sums tracked)

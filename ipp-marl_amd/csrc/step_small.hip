@@ -702,7 +702,7 @@ extern "C" int ippm_plan_step(ippm_ctx* ctx, const int64_t* episode, int32_t* po
                      ctx->dcfg, episode, comm_range, draws, comm, probs, action_in, mask, action, fault, rect_next, -1, plans ? work : nullptr,
                      ippm_fuse_wave_rows(ctx, n_envs), (flags & IPPM_STEP_TILES) ? ippm_tile_env_cap(ctx) : ippm_work_env_cap(ctx, n_envs),
                      ctx->dcounters, ctx->n_active, ctx->slabs, ippm_slab_count(ctx),
-                     (ctx->cfg.grid_y % 32 == 0 && ctx->knob_tile_round > 0) ? 7 : 0);
+                     (ctx->cfg.grid_y % 32 == 0 && ctx->knob_tile_round > 0) ? ippm_round_cells(ctx->knob_tile_round) / 4 - 1 : 0);
   IPPM_LAUNCH_CHECK("plan_step");
   return 0;
 }
