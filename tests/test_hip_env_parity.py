@@ -685,8 +685,11 @@ def test_split_batch_on_two_streams_equals_the_batch():
         assert int(split.fault.abs().sum()) == 0
 
 
-@pytest.mark.parametrize("name,over,n_envs,slabs", [("c2", {}, 40, True), ("c2", {}, 40, False), ("small", dict(experiment__missions__n_agents=5, experiment__constraints__num_actions=27), 33, True),
-                                                   ("default", dict(experiment__missions__n_agents=2), 6, True), ("c4", dict(experiment__uav__fix_range=False), 9, True)])
+@pytest.mark.parametrize("name,over,n_envs,slabs", [
+    ("c2", {}, 40, True), ("c2", {}, 40, False),
+    ("small", dict(experiment__missions__n_agents=5, experiment__constraints__num_actions=27), 33, True),
+    ("default", dict(experiment__missions__n_agents=2), 6, True),
+    ("c4", dict(experiment__uav__fix_range=False), 9, True), ("c4", dict(experiment__uav__fix_range=False), 5, False)])
 def test_reset_leaves_nothing_of_the_last_episode(name, over, n_envs, slabs, monkeypatch):
     """The env-only reset writes the prior only where the finished episode wrote (per 16-row dirty slab of every map, marked by the
     plan kernel -- ippm_set_dirty_slabs, IPPM_DIRTY_SLABS=1 -- or, the default, one bounding box per map) and senses the start footprints in the same
