@@ -284,6 +284,22 @@ int ippm_set_team_sizes(ippm_ctx* ctx, const int32_t* n_active);
  * reference (mapping/mappings.py:126-132 allocates fresh prior maps per episode). */
 int ippm_dirty_slab_words(ippm_ctx* ctx, int32_t n_envs, int64_t* words);
 int ippm_set_dirty_slabs(ippm_ctx* ctx, int32_t* slabs);
+/* Storage layout of the belief maps (`local`, `global` of every entry point of this context).  0 (the default): row-major, cell (x, y) at
+ * float x * grid_y + y -- the reference's numpy layout (mapping/mappings.py:18-25).  1: TILE STORAGE -- 128-byte tiles of 4 rows x 8 cells, the
+ * tiles in row-major order: cell (x, y) at float (x >> 2) * 4 grid_y + (y >> 3) * 32 + (x & 3) * 8 + (y & 7).  Same size, same values; every
+ * entry point that takes maps reads and writes them in the context's layout (ippm_maps_relayout converts between the two), everything
+ * else -- truth bits, code tiles, footprints, plans, area sums, features -- is unchanged.  A footprint then touches whole lines only, which
+ * is what the map kernels' HBM traffic is bounded by (DESIGN.md "tile storage").  Needs the tile form (ippm_tile_form) and grid_x % 4 ==
+ * 0, grid_y % 8 == 0: rc -2 otherwise.  Set it BEFORE the maps are first written; switching with live maps needs ippm_maps_relayout. */
+int ippm_set_map_layout(ippm_ctx* ctx, int32_t tiled);
+int ippm_map_layout(ippm_ctx* ctx, int32_t* tiled);
+/* 1 where the configuration can take tile storage AND it has been measured to pay (footprint rows of 129 .. 256 cells: BASELINE config 4's
+ * 512 x 512 grid, env step -16 %; not config 2's 256 x 256 or config 5's 1024 x 1024, where it costs 3 %) -- what the Python host's
+ * map_layout="auto" follows. */
+int ippm_map_layout_advice(ippm_ctx* ctx, int32_t* tiled);
+/* n_maps maps of grid_x * grid_y floats from `src` to `dst` (src != dst): to_tiled = 1 row-major -> tile storage, 0 the other way
+ * (whatever the context's own layout is). */
+int ippm_maps_relayout(ippm_ctx* ctx, const float* src, float* dst, int32_t n_maps, int32_t to_tiled, void* stream);
 int ippm_plan_step(ippm_ctx* ctx, const int64_t* episode, int32_t* pos, const float* comm_range, const double* draws,
                    uint8_t* comm, const int32_t* rect, int32_t* ws, int32_t t, int32_t flags, const float* probs,
                    const int32_t* action_in, int32_t policy, uint8_t* mask, int32_t* action, int32_t* fault,

@@ -127,6 +127,8 @@ extern "C" int ippm_ctx_create(const ippm_config* cfg, ippm_ctx** out) {
   ctx->knob_terrain_one_launch = knob("IPPM_TERRAIN_ONE_LAUNCH", 0);   // 1: ippm_terrain_truth's second pass as one launch (terrain.hip: measured, no gain)
   ctx->knob_k3_dense = knob("IPPM_K3_DENSE", 1);   // 0: the power-of-two lane layout of round 3 (A/B: tools/ab_knobs.py)
   ctx->tiles = (ctx->vec == 4 && c.logit_prior == 0.f && c.grid_x < 32768 && c.grid_y <= 1024 && !knob("IPPM_NO_TILES", 0)) ? 1 : 0;
+  // tile storage of the maps (ippm_set_map_layout); IPPM_MAP_TILED=1 turns it on at creation where the configuration can take it
+  ctx->tl = (knob("IPPM_MAP_TILED", 0) > 0 && ippm_tile_storage_ok(ctx)) ? 1 : 0;
   int rc = ippm_check_hip(hipMalloc(&ctx->dcfg, sizeof(ippm_config)), "hipMalloc(cfg)");
   if (!rc) rc = ippm_check_hip(hipMemcpy(ctx->dcfg, cfg, sizeof(ippm_config), hipMemcpyHostToDevice), "hipMemcpy(cfg)");
   if (!rc) rc = ippm_check_hip(hipMalloc(&ctx->dcounters, IPPM_COUNTER_SLOTS * 8 * sizeof(unsigned long long)), "hipMalloc(counters)");
@@ -145,6 +147,37 @@ extern "C" int ippm_ctx_create(const ippm_config* cfg, ippm_ctx** out) {
   }
   if (rc) { ippm_ctx_destroy(ctx); return rc; }
   *out = ctx;
+  return 0;
+}
+
+extern "C" int ippm_set_map_layout(ippm_ctx* ctx, int32_t tiled) {
+  if (!ctx) { ippm_set_error("ippm_set_map_layout: null context"); return -1; }
+  if (tiled && !ippm_tile_storage_ok(ctx)) {
+    ippm_set_error("ippm_set_map_layout: tile storage needs the tile form of the fusion (prior 0.5, grid_y >= 44) and a grid of whole tiles (grid_x % 4 == 0, grid_y % 8 == 0)");
+    return -2;
+  }
+  ctx->tl = tiled ? 1 : 0;
+  return 0;
+}
+
+// Where tile storage has been measured to pay (profiles/r06/tile_storage_ab.txt; MI355X, env-only step, alternating processes on one box):
+//   256^2 x 4 UAVs x 1024 envs (rows of up to 90 cells)    K3 33.3 -> 36.2 us, fusion 74.3 -> 77.6, reset fill 139 -> 131: step +3 %  -> rows
+//   512^2 x 8 UAVs x 1024 envs (rows of up to 180 cells)   K3 256 -> 243, fusion 970 -> 880, reset fill 1300 -> 1125: step -16 %     -> TILES
+//   1024^2 x 16 UAVs x 64 envs (rows of up to 360 cells)   K3 101.5 -> 100.1, fusion 592 -> 602, reset fill 578 -> 513: step +3 %   -> rows
+// A tile walk takes 8-11 % more lane-loads than a row walk on the small footprints (edge tiles) and the kernels' time follows their lane-loads
+// there, whatever the lines cost; on rows of 12 lines the partial lines at the ends are little to begin with.  In between -- footprint rows of
+// 129 .. 256 cells -- the whole lines win.
+extern "C" int ippm_map_layout_advice(ippm_ctx* ctx, int32_t* tiled) {
+  if (!ctx || !tiled) { ippm_set_error("ippm_map_layout_advice: null argument"); return -1; }
+  int wmax = 0;
+  for (int k = 0; k < ctx->cfg.space_z; ++k) wmax = std::max(wmax, 2 * ctx->cfg.radius_y[k]);
+  *tiled = (ippm_tile_storage_ok(ctx) && wmax > 128 && wmax <= 256) ? 1 : 0;
+  return 0;
+}
+
+extern "C" int ippm_map_layout(ippm_ctx* ctx, int32_t* tiled) {
+  if (!ctx || !tiled) { ippm_set_error("ippm_map_layout: null argument"); return -1; }
+  *tiled = ctx->tl;
   return 0;
 }
 

@@ -60,7 +60,7 @@ __device__ __forceinline__ float ig_cell(float l, float ln, float kp, float km, 
 // K9: one workgroup per (env, agent, action)
 __global__ void __launch_bounds__(256)
 k_ig_candidates(const ippm_config* __restrict__ c, const float* __restrict__ local, const int32_t* __restrict__ pos,
-                const uint8_t* __restrict__ mask, float* __restrict__ gains) {
+                const uint8_t* __restrict__ mask, float* __restrict__ gains, int tl) {
   const int n = c->n_agents, A = c->n_actions;
   const int cand = blockIdx.x;
   const int a = cand % A, i = (cand / A) % n, e = cand / (A * n);
@@ -87,7 +87,8 @@ k_ig_candidates(const ippm_config* __restrict__ c, const float* __restrict__ loc
     const int row = idx / groups, gi = idx - row * groups;
     const int x = xl + row, y = y0 + gi * step;
     float v[4];
-    if (vec && y + 4 <= gy) { const float4 t = *reinterpret_cast<const float4*>(map + (size_t)x * gy + y); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    // (tl: tile storage of the maps, ippm_internal.h -- a grid-aligned group is 16 contiguous bytes there too)
+    if (vec && y + 4 <= gy) { const float4 t = *reinterpret_cast<const float4*>(map + ippm_cell_index(x, y, gy, tl)); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
     else if (vec) { for (int q = 0; q < 4; ++q) v[q] = y + q < gy ? map[(size_t)x * gy + y + q] : 0.f; }
     else v[0] = map[(size_t)x * gy + y];
     for (int q = 0; q < step; ++q) {
@@ -118,7 +119,7 @@ k_ig_candidates(const ippm_config* __restrict__ c, const float* __restrict__ loc
 // there, not enough to pay for the bookkeeping.)  Sums in float64, lane-striped then a fixed tree: deterministic.
 __global__ void __launch_bounds__(256)
 k_ig_union(const ippm_config* __restrict__ c, const float* __restrict__ local, const int32_t* __restrict__ pos,
-           const uint8_t* __restrict__ mask, float* __restrict__ gains) {
+           const uint8_t* __restrict__ mask, float* __restrict__ gains, int tl) {
   const int n = c->n_agents, A = c->n_actions, layers = A / 9;
   const int layer = blockIdx.x % layers, i = (blockIdx.x / layers) % n, e = blockIdx.x / (layers * n);
   const int gx = c->grid_x, gy = c->grid_y, s = c->spacing;
@@ -157,7 +158,7 @@ k_ig_union(const ippm_config* __restrict__ c, const float* __restrict__ local, c
     const int row = idx / groups, gi = idx - row * groups;
     const int x = X0 + row, y = y0 + gi * 4;
     float v[4];
-    if (y + 4 <= gy) { const float4 t = *reinterpret_cast<const float4*>(map + (size_t)x * gy + y); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    if (y + 4 <= gy) { const float4 t = *reinterpret_cast<const float4*>(map + ippm_cell_index(x, y, gy, tl)); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
     else { for (int q = 0; q < 4; ++q) v[q] = y + q < gy ? map[(size_t)x * gy + y + q] : 0.f; }
     bool inx[3];
 #pragma unroll
@@ -251,14 +252,14 @@ k_ig_select(const ippm_config* __restrict__ c, const int32_t* __restrict__ pos, 
 // target-class confusion counts of a map thresholded at L > thr (thr = 0 <=> p > 0.5): out int64 [n_maps,3] = tp, fp, fn
 __global__ void __launch_bounds__(256)
 k_f1_counts(const ippm_config* __restrict__ c, const float* __restrict__ maps, const uint8_t* __restrict__ truth, int maps_per_truth,
-            float thr, unsigned long long* __restrict__ out) {
+            float thr, unsigned long long* __restrict__ out, int tl) {
   const int m = blockIdx.y;
   const size_t total = (size_t)c->grid_x * c->grid_y;
   const float* p = maps + (size_t)m * total;
   const uint8_t* t = truth + (size_t)(m / maps_per_truth) * ippm_truth_bytes(c->grid_x, c->grid_y);
   unsigned tp = 0, fp = 0, fn = 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const bool pred = p[i] > thr, tr = ippm_truth1(t, i) != 0;
+    const bool pred = p[i] > thr, tr = ippm_truth1(t, ippm_stored_cell(i, c->grid_y, tl)) != 0;
     tp += pred && tr; fp += pred && !tr; fn += !pred && tr;
   }
   const float a = ippm_wave_sum((float)tp), b = ippm_wave_sum((float)fp), d = ippm_wave_sum((float)fn);
@@ -278,9 +279,9 @@ extern "C" int ippm_ig_candidates(ippm_ctx* ctx, const float* local, const int32
   if (total <= 0) return 0;
   const int A = ctx->cfg.n_actions;
   if ((A == 9 || A == 27) && ctx->cfg.grid_y >= 4 && !getenv("IPPM_IG_PER_CANDIDATE"))   // 3 x 3 sets: one walk of the hull per layer
-    hipLaunchKernelGGL(k_ig_union, dim3(n_envs * ctx->cfg.n_agents * (A / 9)), dim3(256), 0, S_(stream), ctx->dcfg, local, pos, mask, gains);
+    hipLaunchKernelGGL(k_ig_union, dim3(n_envs * ctx->cfg.n_agents * (A / 9)), dim3(256), 0, S_(stream), ctx->dcfg, local, pos, mask, gains, ctx->tl);
   else
-    hipLaunchKernelGGL(k_ig_candidates, dim3(total), dim3(256), 0, S_(stream), ctx->dcfg, local, pos, mask, gains);
+    hipLaunchKernelGGL(k_ig_candidates, dim3(total), dim3(256), 0, S_(stream), ctx->dcfg, local, pos, mask, gains, ctx->tl);
   IPPM_LAUNCH_CHECK("ig_candidates");
   return 0;
 }
@@ -302,7 +303,7 @@ extern "C" int ippm_f1_counts(ippm_ctx* ctx, const float* maps, const uint8_t* t
   const size_t cells = (size_t)ctx->cfg.grid_x * ctx->cfg.grid_y;
   const int gxb = (int)std::min<size_t>(32, (cells + 255) / 256);
   hipLaunchKernelGGL(k_f1_counts, dim3(gxb, n_maps), dim3(256), 0, S_(stream), ctx->dcfg, maps, truth, maps_per_truth > 0 ? maps_per_truth : 1,
-                     logodds_threshold, reinterpret_cast<unsigned long long*>(out));
+                     logodds_threshold, reinterpret_cast<unsigned long long*>(out), ctx->tl);
   IPPM_LAUNCH_CHECK("f1_counts");
   return 0;
 }

@@ -321,7 +321,11 @@ typedef unsigned ippm_k3_u4 __attribute__((ext_vector_type(4)));
 // v_writelane / v_readlane pair less in its instruction stream).
 // WPG x CH: wavefronts per workgroup and loads in flight per lane (the production shape is chosen per grid width, ippm_sense_step)
 // GO: the launch's fastest-varying workgroup index -- 0: a footprint's parts, 1: the agents of an env (a map's parts n workgroups apart)
-template <int VEC, bool MIS, bool FLIPS, bool REC, bool DENSE, bool TRACK, int WPG = IPPM_K3_WAVES, int CHN = IPPM_K3_CH, int GO = IPPM_K3_GRID_ORDER>
+// TL: the maps are stored as 128-byte TILES of 4 rows x 8 cells (ippm_internal.h "tile storage"; dense 16-byte form only).  The footprint's
+// lane-loads are then dealt out tile by tile -- 8 consecutive lanes take one tile = one line -- over the tiles its rows and columns meet, so
+// every line the footprint touches is read once and written whole; the lanes of an edge tile whose row or cells lie outside the footprint
+// load and store them unchanged (`inm` = 0).  Truth bits, Philox counters and code bytes keep their (row, column) addressing.
+template <int VEC, bool MIS, bool FLIPS, bool REC, bool DENSE, bool TRACK, bool TL = false, int WPG = IPPM_K3_WAVES, int CHN = IPPM_K3_CH, int GO = IPPM_K3_GRID_ORDER>
 __global__ void __launch_bounds__(64 * WPG)
 k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int stage, int rows_per_part, int gy, int gx,
               float* __restrict__ local, const uint8_t* __restrict__ truth, const int64_t* __restrict__ episode,
@@ -384,9 +388,12 @@ k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int sta
   // col_round (cells; VEC = off, 32 = a 128-byte line; dense 16-byte form only): the row segments the workgroups walk are rounded
   // OUTWARDS to whole lines.  The groups this adds lie outside the footprint's columns: loaded, left as they are (`inm` below is 0 for
   // their cells) and stored back, so that every line of the footprint is written whole -- no truth, no code byte, no flag for them.
-  const int cr = (DENSE && VEC == 4 && !MIS) ? col_round : VEC;
+  static_assert(!TL || (DENSE && VEC == 4 && !MIS), "tile storage: dense 16-byte form");
+  const int cr = TL ? 8 : ((DENSE && VEC == 4 && !MIS) ? col_round : VEC);
   const int y0 = yu & ~(cr - 1), tile_y0 = yu & ~3;
-  const int groups = (min(gy, (yd + cr - 1) & ~(cr - 1)) - y0 + VEC - 1) / VEC;
+  // (TL: `groups` = the lane-loads of one ROW OF TILES of the footprint, 8 per tile; `tr0` = its first row of tiles)
+  const int tr0 = xl >> 2;
+  const int groups = TL ? (((yd + 7) >> 3) - (yu >> 3)) * 8 : (min(gy, (yd + cr - 1) & ~(cr - 1)) - y0 + VEC - 1) / VEC;
   // DENSE: the footprint's 4-cell groups in ROW-MAJOR order, T = row * W + group (W = groups per row), are dealt out in runs: a
   // wavefront takes CH * 64 consecutive ones, its lane's loads are T = base + q * 64 + lane -- a load instruction covers 64
   // consecutive groups (2.7 whole 368-byte row segments of a 15 m footprint at 256^2) and every wavefront but a footprint's last
@@ -397,7 +404,7 @@ k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int sta
   int part_rows = rows_per_part;
   if (DENSE) {
     dense_invw = __builtin_amdgcn_rcpf((float)max(groups, 1));   // floor(T / W) = (int)((T + 0.5) / W) exactly for T < 2^20 (ippm_div_small)
-    dense_total = h * groups;
+    dense_total = (TL ? ((xr + 3) >> 2) - tr0 : h) * groups;
     dense_base = (part * WPG + (int)(threadIdx.x >> 6)) * (CH * 64);
     part_rows = h;      // (r0, r1 below only decide whether the workgroup has work: part * WPG * CH * 64 < total)
   }
@@ -435,12 +442,22 @@ k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int sta
     for (int row0 = r0 + (DENSE ? 0 : wv * rpw + sub); row0 < r1; row0 += WPG * rpw) {  // one trip for the common footprints
       CellVec<VEC> m[CH];
       uint32_t tw[CH], fw[CH];
-      int cellv[CH], rowv[CH], yv[CH];
+      int cellv[CH], rowv[CH], yv[CH], poff[CH];
       bool on[CH];
 #pragma unroll
       for (int q = 0; q < CH; ++q) {
         int row, y;
-        if (DENSE) {
+        if (DENSE && TL) {
+          // lane-load T of the footprint's tiles in row-major order of TILES: row of tiles rr, lane-load gi of its 8 per tile --
+          // (gi >> 3) the tile, (gi >> 1) & 3 the row inside it, gi & 1 which half of that row's 8 cells.  One line = 8 consecutive T.
+          const int T = dense_base + q * 64 + lane;
+          const int rr = ippm_div_small(T, dense_invw);
+          const int gi = T - rr * groups;
+          row = ((tr0 + rr) << 2) + ((gi >> 1) & 3) - xl;      // (may lie outside [0, h): an edge tile's rows beyond the footprint)
+          on[q] = T < dense_total;
+          y = y0 + ((gi >> 3) << 3) + ((gi & 1) << 2);
+          poff[q] = ((tr0 + rr) * gy + y0 + gi) * 16;   // a row of tiles is 16 gy bytes, tile c of it at 128 c = 16 (8 c) bytes, lane-load g of the row of tiles at 16 g
+        } else if (DENSE) {
           const int T = dense_base + q * 64 + lane;
           const int rr = ippm_div_small(T, dense_invw);
           const int gi = T - rr * groups;
@@ -456,8 +473,9 @@ k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int sta
         const int x = xl + row;
         const int cell = x * gy + y;
         cellv[q] = cell; rowv[q] = row; yv[q] = y;
+        if (!TL) poff[q] = cell * 4;
         if (VEC == 4) {
-          const ippm_k3_u4 t = __builtin_amdgcn_raw_buffer_load_b128(rmap, on[q] ? cell * 4 : IPPM_K3_OOB, 0, IPPM_K3_LOAD_AUX);
+          const ippm_k3_u4 t = __builtin_amdgcn_raw_buffer_load_b128(rmap, on[q] ? poff[q] : IPPM_K3_OOB, 0, IPPM_K3_LOAD_AUX);
           m[q].v[0] = __uint_as_float(t.x); m[q].v[1 % VEC] = __uint_as_float(t.y);
           m[q].v[2 % VEC] = __uint_as_float(t.z); m[q].v[3 % VEC] = __uint_as_float(t.w);
         } else {
@@ -466,7 +484,7 @@ k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int sta
         // (grids not a multiple of 4 wide: a group's four truth bits may straddle a byte -- two bytes at any byte address)
         tw[q] = mis ? (uint32_t)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rtruth, on[q] ? (cell >> 3) : IPPM_K3_OOB, 0, 0)
                     : (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rtruth, on[q] ? (cell >> 3) : IPPM_K3_OOB, 0, 0);
-        fw[q] = FLIPS ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rflip, on[q] ? (int)tile_index<VEC>(row, y - tile_y0, S) : IPPM_K3_OOB, 0, 0)
+        fw[q] = FLIPS ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rflip, on[q] && (!TL || (unsigned)row < (unsigned)h) ? (int)tile_index<VEC>(row, y - tile_y0, S) : IPPM_K3_OOB, 0, 0)
                       : 0u;
       }
 #pragma unroll
@@ -494,6 +512,7 @@ k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int sta
         uint32_t inm = 0;  // cells of the group inside the footprint's columns (edge groups)
 #pragma unroll
         for (int j = 0; j < VEC; ++j) inm |= ((unsigned)(y + j - yu) < (unsigned)w) ? (1u << j) : 0u;
+        if (TL) inm = (unsigned)row < (unsigned)h ? inm : 0u;   // ... and rows (an edge tile's rows above / below the footprint)
         const uint32_t obs = (tbits ^ flipbits) & inm;
         // mappings.py:109-124 in log-odds: clip the prior belief, add the measurement's log-odds (minus logit(prior))
         float dsig[VEC];
@@ -521,7 +540,7 @@ k_sense_tiles(const int32_t* __restrict__ rect_in, int n, int agent_sel, int sta
           if (v10 != 0.f) atomicAdd(pa + IPPM_AREA_LD, (double)v10);
           if (v11 != 0.f) atomicAdd(pa + IPPM_AREA_LD + 1, (double)v11);
         }
-        const int off = on[q] ? cell * 4 : IPPM_K3_OOB;
+        const int off = on[q] ? poff[q] : IPPM_K3_OOB;
         if (VEC == 4) {
           ippm_k3_u4 t;
           t.x = __float_as_uint(m[q].v[0]); t.y = __float_as_uint(m[q].v[1 % VEC]);
@@ -575,7 +594,7 @@ __global__ void __launch_bounds__(256)
 k_reset_maps(const ippm_config* __restrict__ c, const int64_t* __restrict__ episode, const int32_t* __restrict__ pos,
              const uint8_t* __restrict__ truth, float* __restrict__ local, float* __restrict__ global, const uint8_t* __restrict__ flips,
              uint8_t* __restrict__ code, const int32_t* __restrict__ rect, int32_t* __restrict__ ws, int full, int fill_chunks,
-             const int32_t* __restrict__ n_active, int col_align, int32_t* __restrict__ slabs, int n_slabs) {
+             const int32_t* __restrict__ n_active, int col_align, int32_t* __restrict__ slabs, int n_slabs, int tl) {
   const int n = c->n_agents, gx = c->grid_x, gy = c->grid_y, S = c->tile_stride;
   const int e = blockIdx.z, m = blockIdx.y;
   const bool is_global = m == n;
@@ -642,6 +661,24 @@ k_reset_maps(const ippm_config* __restrict__ c, const int64_t* __restrict__ epis
     constexpr int RPW = IPPM_RESET_ROWS / 4;
     const int xw = blockIdx.x * IPPM_RESET_ROWS + wv * RPW;
     if (xw >= bx1 || xw + RPW <= bx0) return;
+    if (tl) {
+      // tile storage: the wavefront's 8 rows are two rows of tiles; it writes every TILE that meets the box (whole lines: an edge tile's cells
+      // outside the box hold the prior already) except the tiles that meet the start footprint -- those belong to the SENSE workgroups, whole.
+      const int G0 = (by0 >> 3) << 3, G1 = ((by1 + 7) >> 3) << 3;                        // lane-loads of a row of tiles: 8 per tile
+      const int fR0 = xl >> 2, fR1 = (xr + 3) >> 2, fG0 = (yu >> 3) << 3, fG1 = ((yd + 7) >> 3) << 3;   // the footprint's tiles (empty footprint: fR1 <= fR0 or fG1 <= fG0)
+      const bool fp_some = xr > xl && yd > yu;
+#pragma unroll
+      for (int u = 0; u < RPW / 4; ++u) {
+        const int R = (xw >> 2) + u;
+        if (R * 4 >= bx1 || R * 4 + 4 <= bx0 || R * 4 >= gx) continue;
+        const bool fp_row = fp_some && R >= fR0 && R < fR1;
+        for (int G = G0 + lane; G < G1; G += 64) {
+          const bool skip = fp_row && G >= fG0 && G < fG1;
+          __builtin_amdgcn_raw_buffer_store_b128(t, rmap, skip ? IPPM_K3_OOB : (R * gy + G) * 16, 0, 2);
+        }
+      }
+      return;
+    }
     for (int g = (by0 >> 2) + lane; g < ((by1 + 3) >> 2); g += 64) {
       const int y = g * 4;
       const bool fp_col = g >= fg0 && g < fg1;
@@ -668,8 +705,9 @@ k_reset_maps(const ippm_config* __restrict__ c, const int64_t* __restrict__ epis
   if (is_global) return;
   const int part = (int)blockIdx.x - fill_chunks;
   const int h = xr - xl, wdt = yd - yu;
-  const int r0 = part * 32, r1 = min(h, r0 + 32);
-  if (wdt <= 0 || r0 >= r1) return;
+  // (tile storage: a part is 8 rows of the footprint's TILES, rows [r0, r1) relative to xl may start above the footprint)
+  const int r0 = tl ? ((xl >> 2) + part * 8) * 4 - xl : part * 32, r1 = tl ? min(((xr + 3) >> 2) * 4 - xl, r0 + 32) : min(h, r0 + 32);
+  if (wdt <= 0 || h <= 0 || r0 >= r1) return;
   const int32_t* p = pos + (size_t)(e * n + m) * 3;
   const int k = ippm_alt_index(c, p[2]);
   const float lc = c->logit_clip;
@@ -682,6 +720,35 @@ k_reset_maps(const ippm_config* __restrict__ c, const int64_t* __restrict__ epis
   const size_t TB = ippm_tile_bytes(S, 4);
   const __amdgpu_buffer_rsrc_t rcode = IPPM_K3_RSRC(code + (size_t)(e * n + m) * TB, TB);
   const __amdgpu_buffer_rsrc_t rflip = IPPM_K3_RSRC(flips ? flips + (size_t)(e * n + m) * TB : code, flips ? TB : 0);
+  if (tl) {
+    // every tile the footprint meets, whole: a wavefront takes rows of tiles, its lanes their lane-loads; cells outside the footprint get the prior
+    const int G0 = (yu >> 3) << 3, G1 = ((yd + 7) >> 3) << 3, y0c = yu & ~3;
+    for (int R = ((xl + r0) >> 2) + wv; R * 4 < xl + r1; R += 4) {
+      for (int G = G0 + lane; G < G1; G += 64) {
+        const int x = (R << 2) + ((G >> 1) & 3), y = ((G >> 3) << 3) + ((G & 1) << 2);
+        const int row = x - xl;
+        const int cell = x * gy + y;
+        const uint32_t tw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rtruth, cell >> 3, 0, 0);
+        const uint32_t tbits = (tw >> (cell & 7)) & 0xFu;
+        uint32_t inm = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) inm |= ((unsigned)(y + j - yu) < (unsigned)wdt) ? (1u << j) : 0u;
+        inm = (unsigned)row < (unsigned)h ? inm : 0u;
+        uint32_t flipbits;
+        if (flips) flipbits = inm ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rflip, (int)tile_index<4>(row, y - y0c, S), 0, 0) & 0xFu : 0u;
+        else flipbits = philox_flip_bits4((uint32_t)cell, (uint32_t)ep, sw, (uint32_t)(ep >> 32), k0, k1, thr, false);
+        const uint32_t obs = (tbits ^ flipbits) & inm;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = ((inm >> j) & 1u) ? ippm_clampl(lp, lc) + (((obs >> j) & 1u) ? lm1 : lm0) : lp;
+        ippm_k3_u4 t;
+        t.x = __float_as_uint(v[0]); t.y = __float_as_uint(v[1]); t.z = __float_as_uint(v[2]); t.w = __float_as_uint(v[3]);
+        __builtin_amdgcn_raw_buffer_store_b128(t, rmap, (R * gy + G) * 16, 0, 0);
+        if (inm) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)obs, rcode, (int)tile_index<4>(row, y - y0c, S), 0, 0);
+      }
+    }
+    return;
+  }
   const int y0 = yu & ~3, groups = fg1 - fg0;
   int shift = 3;
   while (shift < 6 && ((groups + (1 << shift) - 1) >> shift) > 3) ++shift;
@@ -729,7 +796,7 @@ k_reset_maps(const ippm_config* __restrict__ c, const int64_t* __restrict__ epis
 // full-grid weighted entropy per map (initialisation of T, evaluation metrics)
 __global__ void __launch_bounds__(256)
 k_weighted_entropy(const ippm_config* __restrict__ c, const float* __restrict__ maps, const uint8_t* __restrict__ truth,
-                   double* __restrict__ out, int maps_per_truth) {
+                   double* __restrict__ out, int maps_per_truth, int tl) {
   const int m = blockIdx.y;
   const size_t total = (size_t)c->grid_x * c->grid_y;
   const float* p = maps + (size_t)m * total;
@@ -738,7 +805,7 @@ k_weighted_entropy(const ippm_config* __restrict__ c, const float* __restrict__ 
   float acc = 0.f;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const float v = p[i];
-    const float wgt = t ? (float)ippm_truth1(t, i) : ippm_weight_l(v, wt);
+    const float wgt = t ? (float)ippm_truth1(t, ippm_stored_cell(i, c->grid_y, tl)) : ippm_weight_l(v, wt);
     acc += wgt * ippm_entropy_l(v, lc);
   }
   acc = ippm_wave_sum(acc);
@@ -807,10 +874,11 @@ extern "C" int ippm_reset_maps(ippm_ctx* ctx, const int64_t* episode, const int3
   IPPM_LAUNCH_CHECK("footprint");
   int h_max = 1;
   for (int k = 0; k < c.space_z; ++k) h_max = std::max(h_max, 2 * c.radius_x[k]);
-  const int fill_chunks = (c.grid_x + IPPM_RESET_ROWS - 1) / IPPM_RESET_ROWS, sense_parts = (h_max + 31) / 32;
+  // (tile storage: a SENSE part is 8 rows of tiles, and a footprint of h rows meets up to h / 4 + 1 of them)
+  const int fill_chunks = (c.grid_x + IPPM_RESET_ROWS - 1) / IPPM_RESET_ROWS, sense_parts = ctx->tl ? ((h_max + 3) / 4 + 1 + 7) / 8 : (h_max + 31) / 32;
   dim3 grid((unsigned)(fill_chunks + sense_parts), (unsigned)(c.n_agents + 1), (unsigned)n_envs);
   IPPM_LAUNCH(ctx, IPPM_T_RESET_MAPS, k_reset_maps, grid, dim3(256), S_(stream), ctx->dcfg, episode, pos, truth, local, global, flips, code, rect,
-              ws, full ? 1 : 0, fill_chunks, ctx->n_active, (c.grid_y % 32 == 0) ? ctx->knob_reset_align : 0, ctx->slabs, ippm_slab_count(ctx));
+              ws, full ? 1 : 0, fill_chunks, ctx->n_active, (c.grid_y % 32 == 0 && !ctx->tl) ? ctx->knob_reset_align : 0, ctx->slabs, ippm_slab_count(ctx), ctx->tl);
   IPPM_LAUNCH_CHECK("reset_maps");
   return 0;
 }
@@ -828,6 +896,29 @@ extern "C" int ippm_prob_to_logodds(ippm_ctx* ctx, const float* src, float* dst,
   if (n <= 0) return 0;
   hipLaunchKernelGGL(k_prob_to_logodds, dim3(std::min(4096, grid1((size_t)n))), dim3(256), 0, S_(stream), src, dst, (size_t)n);
   IPPM_LAUNCH_CHECK("prob_to_logodds");
+  return 0;
+}
+
+// row-major <-> tile storage, 16 bytes per lane: lane-load g of the tile-storage order is cells (x, y .. y + 3)
+__global__ void __launch_bounds__(256) k_maps_relayout(const float4* __restrict__ src, float4* __restrict__ dst, int gy, size_t groups_per_map,
+                                                       size_t total, int to_tiled) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const size_t m = i / groups_per_map, g = i - m * groups_per_map;     // g: 16-byte slot of the map in tile-storage order
+  const size_t cell = ippm_stored_cell(g * 4, gy, 1);                  // its first cell's row-major number
+  const size_t rm = m * groups_per_map + cell / 4;
+  if (to_tiled) dst[i] = src[rm]; else dst[rm] = src[i];
+}
+
+extern "C" int ippm_maps_relayout(ippm_ctx* ctx, const float* src, float* dst, int32_t n_maps, int32_t to_tiled, void* stream) {
+  if (!ctx || !src || !dst || src == dst) { ippm_set_error("ippm_maps_relayout: null argument or src == dst"); return -1; }
+  const ippm_config& c = ctx->cfg;
+  if (c.grid_x % 4 || c.grid_y % 8) { ippm_set_error("ippm_maps_relayout: the grid is not made of whole tiles (grid_x % 4, grid_y % 8)"); return -2; }
+  if (n_maps <= 0) return 0;
+  const size_t gpm = (size_t)c.grid_x * c.grid_y / 4, total = gpm * (size_t)n_maps;
+  hipLaunchKernelGGL(k_maps_relayout, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, S_(stream), reinterpret_cast<const float4*>(src),
+                     reinterpret_cast<float4*>(dst), c.grid_y, gpm, total, to_tiled ? 1 : 0);
+  IPPM_LAUNCH_CHECK("maps_relayout");
   return 0;
 }
 
@@ -875,7 +966,7 @@ extern "C" int ippm_sense_step(ippm_ctx* ctx, const int64_t* episode, const int3
   const int maps = agent_sel >= 0 ? n_envs : n_envs * ctx->cfg.n_agents;
   const int tail = sums ? grid1(n_envs) : 0;
   dim3 block(256);
-  if ((!area || ctx->vec == 4) && !env_int("IPPM_K3_CLASSIC", 0)) {
+  if ((!area || ctx->vec == 4) && (ctx->tl || !env_int("IPPM_K3_CLASSIC", 0))) {
     // tile form: one trip per workgroup for the common footprints (rows_per_part = 4 wavefronts x 8 rows); with the area sums
     // tracked in its TRACK instantiation (16-byte layout only: k_sense_update below keeps the narrow grids)
     const ippm_config& c = ctx->cfg;
@@ -891,11 +982,19 @@ extern "C" int ippm_sense_step(ippm_ctx* ctx, const int64_t* episode, const int3
     int parts = (h_max + rows_per_part - 1) / rows_per_part;
     // dense lane mapping (k_sense_tiles<..., DENSE>): a part is a run of wpg * chn * 64 of the footprint's row-major 4-cell groups
     // (W per row: one more than its width needs when it starts off a group boundary)
-    const bool dense = ctx->vec == 4 && ctx->knob_k3_dense != 0;
+    const bool tl = ctx->tl != 0;     // tile storage (ippm_set_map_layout): always the dense form
+    const bool dense = ctx->vec == 4 && (ctx->knob_k3_dense != 0 || tl);
     // row segments rounded outwards to whole 128-byte lines (k_sense_tiles): dense form, rows a multiple of 32 cells long; on by default for
     // rows of at least 512 cells (IPPM_K3_ROUND forces it on / off) -- profiles/r06/tile_round_ab.txt
-    const int col_round = (dense && (c.grid_y % 32) == 0 && ctx->knob_k3_round > 0) ? ippm_round_cells(ctx->knob_k3_round) : 4;
-    if (dense) {
+    const int col_round = (dense && !tl && (c.grid_y % 32) == 0 && ctx->knob_k3_round > 0) ? ippm_round_cells(ctx->knob_k3_round) : 4;
+    if (dense && tl) {
+      int need = 1;    // lane-loads of the largest footprint's tiles: rows of tiles x 8 per tile, one more of either than its size needs
+      for (int k = 0; k < c.space_z; ++k) {
+        const int ht = std::min(c.grid_x / 4, (2 * c.radius_x[k] + 3) / 4 + 1), wt = std::min(c.grid_y / 8, (2 * c.radius_y[k] + 7) / 8 + 1);
+        need = std::max(need, (ht * wt * 8 + wpg * chn * 64 - 1) / (wpg * chn * 64));
+      }
+      parts = need;
+    } else if (dense) {
       int need = 1;
       for (int k = 0; k < c.space_z; ++k) {
         int wmax = (2 * c.radius_y[k] + 3) / 4 + 1;
@@ -910,28 +1009,38 @@ extern "C" int ippm_sense_step(ippm_ctx* ctx, const int64_t* episode, const int3
     dim3 grid = go == 1 ? dim3(g_agents, (unsigned)parts, (unsigned)n_envs)
               : (go == 2 ? dim3(g_agents, (unsigned)n_envs, (unsigned)parts) : dim3((unsigned)parts, g_agents, (unsigned)n_envs));
     int32_t* rect_out = rect_in == rect ? nullptr : rect;
-#define IPPM_K3T___(V, M, F, R, D, T, ...)                                                                                       \
-  IPPM_LAUNCH(ctx, IPPM_T_SENSE, (k_sense_tiles<V, M, F, R, D, T __VA_OPT__(,) __VA_ARGS__>), grid, block, S_(stream), rect_in, c.n_agents, agent_sel, stage, rows_per_part, \
+#define IPPM_K3T____(V, M, F, R, D, T, L, ...)                                                                                       \
+  IPPM_LAUNCH(ctx, IPPM_T_SENSE, (k_sense_tiles<V, M, F, R, D, T, L __VA_OPT__(,) __VA_ARGS__>), grid, block, S_(stream), rect_in, c.n_agents, agent_sel, stage, rows_per_part, \
               c.grid_y, c.grid_x, local, truth, episode, code, c.tile_stride, c.logit_clip, (uint32_t)c.philox_seed,                 \
               (uint32_t)(c.philox_seed >> 32), ctx->dcfg, pos, flips, rect_out, ws, sums, reward, ctx->dcounters, area, ctx->n_active, col_round)
+#define IPPM_K3T___(V, M, F, R, D, T, ...) IPPM_K3T____(V, M, F, R, D, T, false __VA_OPT__(,) __VA_ARGS__)
 #define IPPM_K3T__(V, M, F, R, D) do { if (area) IPPM_K3T___(V, M, F, R, D, true); else IPPM_K3T___(V, M, F, R, D, false); } while (0)
+#define IPPM_K3TL_(F, R) do { if (area) IPPM_K3T____(4, false, F, R, true, true, true); else IPPM_K3T____(4, false, F, R, true, false, true); } while (0)
+#define IPPM_K3TL(F) do { if (rect_in) IPPM_K3TL_(F, true); else IPPM_K3TL_(F, false); } while (0)
 #define IPPM_K3T_(V, M, F, R) do { if (dense) IPPM_K3T__(V, M, F, R, true); else IPPM_K3T__(V, M, F, R, false); } while (0)
 #define IPPM_K3T(V, M, F) do { if (rect_in) IPPM_K3T_(V, M, F, true); else IPPM_K3T_(V, M, F, false); } while (0)
     if (shaped && !(wpg == IPPM_K3_WAVES && chn == IPPM_K3_CH && go == IPPM_K3_GRID_ORDER)) {   // the closing K3 of the env-only step in another workgroup shape / order
-#define IPPM_K3S(W_, C_, G_) if (wpg == W_ && chn == C_ && go == G_) { IPPM_K3T___(4, false, false, true, true, false, W_, C_, G_); IPPM_LAUNCH_CHECK("sense_tiles"); return 0; }
+#define IPPM_K3S(W_, C_, G_) if (wpg == W_ && chn == C_ && go == G_) { \
+        if (tl) IPPM_K3T____(4, false, false, true, true, false, true, W_, C_, G_); else IPPM_K3T____(4, false, false, true, true, false, false, W_, C_, G_); \
+        IPPM_LAUNCH_CHECK("sense_tiles"); return 0; }
       IPPM_K3S(2, 2, 1) IPPM_K3S(2, 2, 0) IPPM_K3S(1, 3, 0) IPPM_K3S(2, 3, 0) IPPM_K3S(1, 4, 0) IPPM_K3S(2, 4, 0) IPPM_K3S(4, 4, 0) IPPM_K3S(4, 2, 0) IPPM_K3S(4, 3, 1)
 #undef IPPM_K3S
       ippm_set_error("ippm_sense_step: no instantiation for this K3 shape (IPPM_K3_WPG x IPPM_K3_CHN)");
       return -1;
     }
     const bool mis = (c.grid_y & 3) != 0;
-    if (ctx->vec == 4) {
+    if (tl) {
+      if (flips) IPPM_K3TL(true); else IPPM_K3TL(false);
+    } else if (ctx->vec == 4) {
       if (flips) { if (mis) IPPM_K3T(4, true, true); else IPPM_K3T(4, false, true); }
       else { if (mis) IPPM_K3T(4, true, false); else IPPM_K3T(4, false, false); }
     } else {
       if (flips) IPPM_K3T___(1, false, true, false, false, false); else IPPM_K3T___(1, false, false, false, false, false);
     }
+#undef IPPM_K3T____
 #undef IPPM_K3T___
+#undef IPPM_K3TL_
+#undef IPPM_K3TL
 #undef IPPM_K3T__
 #undef IPPM_K3T_
 #undef IPPM_K3T
@@ -972,7 +1081,7 @@ extern "C" int ippm_weighted_entropy(ippm_ctx* ctx, const float* maps, const uin
   IPPM_HIP(hipMemsetAsync(out, 0, sizeof(double) * n_maps, S_(stream)));
   const size_t cells = (size_t)ctx->cfg.grid_x * ctx->cfg.grid_y;
   hipLaunchKernelGGL(k_weighted_entropy, dim3(std::min(32, grid1(cells)), n_maps), dim3(256), 0, S_(stream), ctx->dcfg, maps, truth,
-                     out, maps_per_truth > 0 ? maps_per_truth : 1);
+                     out, maps_per_truth > 0 ? maps_per_truth : 1, ctx->tl);
   IPPM_LAUNCH_CHECK("weighted_entropy");
   return 0;
 }

@@ -33,7 +33,7 @@ __device__ __forceinline__ int overlap11(int a, int b, int bin, int n) {
 template <int VEC, bool SIGMOID>
 __global__ void __launch_bounds__(256)
 k_area_sums(const float* __restrict__ maps, double* __restrict__ area, int gx, int gy, int chunk_rows, int maps_per_env,
-            int slots_per_env, int slot0) {
+            int slots_per_env, int slot0, int tl) {
   const int m = blockIdx.y;
   const int r0 = blockIdx.x * chunk_rows, r1 = min(gx, r0 + chunk_rows);
   if (r0 >= r1) return;
@@ -58,7 +58,8 @@ k_area_sums(const float* __restrict__ maps, double* __restrict__ area, int gx, i
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         const int rr = row + u * stride;
-        if (rr < r1) v[u] = load_cells_row<VEC>(map + (size_t)rr * gy, y, gy);
+        if (rr < r1) v[u] = tl ? load_cells<VEC>(map + ippm_cell_index(rr, y, gy, 1))   // tile storage (whole tiles: no row tail)
+                               : load_cells_row<VEC>(map + (size_t)rr * gy, y, gy);
       }
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
@@ -416,12 +417,12 @@ static int feature_checks(const ippm_ctx* ctx, const char* who) {
 }
 
 static int launch_area_sums(const float* maps, double* area, int rows, int cols, int n_maps, int maps_per_env, int slots_per_env,
-                            int slot0, bool sigmoid, hipStream_t st) {
+                            int slot0, bool sigmoid, hipStream_t st, int tl = 0) {
   const int chunk_rows = 32;
   dim3 grid((rows + chunk_rows - 1) / chunk_rows, n_maps), block(256);
   const bool v4 = cols >= 4 * IPPM_FEAT;   // 16-byte groups at any row alignment (a row's last group is read cell by cell)
 #define IPPM_AS(V, SG) \
-  hipLaunchKernelGGL((k_area_sums<V, SG>), grid, block, 0, st, maps, area, rows, cols, chunk_rows, maps_per_env, slots_per_env, slot0)
+  hipLaunchKernelGGL((k_area_sums<V, SG>), grid, block, 0, st, maps, area, rows, cols, chunk_rows, maps_per_env, slots_per_env, slot0, v4 ? tl : 0)
   if (v4) { if (sigmoid) IPPM_AS(4, true); else IPPM_AS(4, false); }
   else { if (sigmoid) IPPM_AS(1, true); else IPPM_AS(1, false); }
 #undef IPPM_AS
@@ -447,7 +448,7 @@ extern "C" int ippm_area_sums(ippm_ctx* ctx, const float* maps, double* area, in
     IPPM_HIP(hipMemset2DAsync(area + (size_t)slot0 * FEAT2, sizeof(double) * FEAT2 * per, 0, sizeof(double) * FEAT2 * maps_per_env, envs,
                               S_(stream)));
   }
-  return launch_area_sums(maps, area, c.grid_x, c.grid_y, n_maps, maps_per_env, per, slot0, true, S_(stream));
+  return launch_area_sums(maps, area, c.grid_x, c.grid_y, n_maps, maps_per_env, per, slot0, true, S_(stream), ctx->tl);
 }
 
 __global__ void k_area_scale(const double* __restrict__ src, float* __restrict__ dst, double scale, int n) {

@@ -53,6 +53,7 @@ struct WaveCtx {   // what a wave needs while it walks its rows
   double* s_area;
   double* sums_env;  // this env's reward sums (global map only), nullptr otherwise
   int gx, gy, row_bytes;
+  int tl;            // tile storage of the maps (ippm_internal.h): a cell's address goes through ippm_cell_index
   float lc, wt, lp, inv_gx, inv_gy;
   double lp64;       // logit(prior) as the reference holds it (a Python float): the SHIFT chain subtracts it per message
   int lane;
@@ -187,7 +188,7 @@ __device__ __forceinline__ void walk_slab(const WaveCtx& w, const OpTable& t, Wa
 #pragma unroll
       for (int u = 0; u < FU; ++u) {
         const int row = min(row0 + u, re - 1);  // past the block's end: the last row again (its results are dropped below)
-        mvu[u] = buf_load_cells<VEC>(w.map, row * gybyte + ybyte);
+        mvu[u] = buf_load_cells<VEC>(w.map, w.tl ? ippm_cell_index(row, y, w.gy, 1) * 4 : row * gybyte + ybyte);
         const int rowoff = row * w.row_bytes + ycode;
 #pragma unroll
         for (int k = 0; k < NA; ++k) cwu[u][k] = __builtin_amdgcn_raw_buffer_load_b8(w.code, rowoff + cshift[k], 0, 0);
@@ -237,7 +238,7 @@ __device__ __forceinline__ void walk_slab(const WaveCtx& w, const OpTable& t, Wa
           if (TRACK) d[q] = valid && (!SHIFT || ((vm >> q) & 1u)) ? sigmoid_diff(a, bsave[q]) : 0.f;
         }
         {
-          const int soff = valid ? row * gybyte + ybyte : 0x7FFFFFF0;
+          const int soff = valid ? (w.tl ? ippm_cell_index(row, y, w.gy, 1) * 4 : row * gybyte + ybyte) : 0x7FFFFFF0;
           if (VEC == 4 && (w.gy & 3) != 0) {
             // (uniform) rows are not a multiple of 4 wide: the last group of a row hangs over into the next row -- its cells go
             // out one by one, another lane owns the rest
@@ -318,7 +319,7 @@ __device__ __forceinline__ void fuse_item(const ippm_config* __restrict__ c, flo
                                           const uint8_t* __restrict__ code, const int32_t* __restrict__ plan_ro,
                                           int32_t* __restrict__ ws, double* __restrict__ sums, double* __restrict__ area,
                                           unsigned long long* __restrict__ counters, double* s_area, int wave_rows, int min_ops,
-                                          int n_envs_total, int e, int slot, int chunk, int cslot) {
+                                          int n_envs_total, int e, int slot, int chunk, int cslot, int tl) {
   const int n = c->n_agents;
   const bool is_global = slot == n;
   const size_t wbase = (size_t)(e * (n + 1) + slot) * IPPM_WS_WORDS;
@@ -384,6 +385,7 @@ __device__ __forceinline__ void fuse_item(const ippm_config* __restrict__ c, flo
   WaveCtx w;
   w.gx = gx; w.gy = gy;
   w.row_bytes = row_bytes;
+  w.tl = tl;
   w.map = IPPM_RSRC(is_global ? global + (size_t)e * gx * gy : local + (size_t)(e * n + slot) * gx * gy, (size_t)gx * gy * 4);
   w.code = IPPM_RSRC(code, (size_t)n_envs_total * n * TB);
   w.s_area = s_area;
@@ -472,7 +474,7 @@ k_fuse_rows(const ippm_config* __restrict__ c, float* __restrict__ local, float*
             const uint8_t* __restrict__ code, const int32_t* __restrict__ plan_ro, int32_t* __restrict__ ws,
             double* __restrict__ sums, double* __restrict__ area, unsigned long long* __restrict__ counters,
             const int32_t* __restrict__ work, int wave_rows, int chunks, int min_ops, int local_units, int agent_sel,
-            int n_envs_total, int env_cap) {
+            int n_envs_total, int env_cap, int tl) {
   __shared__ double s_area[TRACK ? (IPPM_FEAT + 1) * IPPM_AREA_LD : 1];
   const int n = c->n_agents;
   if (work) {  // gridDim.x is a multiple of the env count: wavefront b serves an env of row b / E, taking every (gridDim.x / E)-th item
@@ -491,7 +493,7 @@ k_fuse_rows(const ippm_config* __restrict__ c, float* __restrict__ local, float*
       const int item = items[i];
       const int m = item >> 8;
       fuse_item<VEC, TRACK, NAMAX, SHIFT>(c, local, global, code, plan_ro, ws, sums, area, counters, s_area, wave_rows, min_ops, n_envs_total,
-                                   m / (n + 1), m % (n + 1), item & 0xFF, blockIdx.x);
+                                   m / (n + 1), m % (n + 1), item & 0xFF, blockIdx.x, tl);
     }
     return;
   }
@@ -502,7 +504,7 @@ k_fuse_rows(const ippm_config* __restrict__ c, float* __restrict__ local, float*
   else if (agent_sel >= 0) { e = unit; slot = agent_sel; }
   else { e = unit / n; slot = unit % n; }
   fuse_item<VEC, TRACK, NAMAX, SHIFT>(c, local, global, code, plan_ro, ws, sums, area, counters, s_area, wave_rows, min_ops, n_envs_total, e, slot,
-                               chunk, blockIdx.x);
+                               chunk, blockIdx.x, tl);
 }
 
 __global__ void k_reward_finalize(const ippm_config* __restrict__ c, double* __restrict__ sums,
@@ -554,7 +556,7 @@ static int launch_fuse(ippm_ctx* ctx, float* local, float* global, const uint8_t
   dim3 grid(work ? (unsigned)pgrid : (unsigned)units * chunks), block(64);
 #define IPPM_FUSE(V, T, NA, SH, MINOPS)                                                                                  \
   IPPM_LAUNCH(ctx, IPPM_T_FUSE, (k_fuse_rows<V, T, NA, SH>), grid, block, st, ctx->dcfg, local, global, code, ws, ws, sums, area, \
-              ctx->dcounters, work, wave_rows, chunks, MINOPS, local_units, agent_sel, n_envs_total, ippm_work_env_cap(ctx, n_envs_total))
+              ctx->dcounters, work, wave_rows, chunks, MINOPS, local_units, agent_sel, n_envs_total, ippm_work_env_cap(ctx, n_envs_total), ctx->tl)
 #define IPPM_FUSE_ALL(V, T)                                  \
   do {                                                       \
     if (c.logit_prior != 0.f) {                              \

@@ -114,7 +114,10 @@ struct TileAcc {   // per wavefront, over all its items (all of one env)
 // One item with at most NA ops (spare slots first) and SLOTS loads in flight per lane.
 // The item is a RUN of `cnt` lane-loads of its region (rows from x0 on, groups [g0, g0 + W)) in row-major order, starting at group
 // `gs` of row x0: lane-load t = q * 64 + lane (t < cnt) is element gs + t of that order.
-template <int NA, int SLOTS, bool MIS, bool TRACK>
+// TL (tile storage of the maps, ippm_internal.h): the item is a run of lane-loads of ROWS OF TILES -- x0 a row of tiles, g0 / W / gs lane-loads of it (8 per
+// tile: lane-load G of a row of tiles is row (G >> 1) & 3 of tile G >> 3, cells 4 (G & 1) .. + 3 of that row) -- so consecutive lanes cover whole lines.  A row of
+// tiles holds 4 map rows: whether an op meets a lane's ROW is then a per-lane question as well (the slabs are cut at rows of tiles).
+template <int NA, int SLOTS, bool MIS, bool TRACK, bool TL>
 __device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e, int slot, int x0, int cnt, int gs, int g0, int W, unsigned active) {
   const int map_abs = e * (w.n + 1) + slot;
   const bool is_global = slot == w.n;
@@ -129,20 +132,21 @@ __device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e,
   // Uniform addresses, scalar loads: the fields stay in SGPRs (NA <= 6; items met by more ops: tile_item_long).
   static_assert(NA <= 6, "straight-line chains are compiled for up to six ops");
   const int pad = NA - __popc(active);
-  int s_yu[NA], s_yd[NA], cs[NA];
+  int s_yu[NA], s_yd[NA], cs[NA], s_xl[NA], s_xh[NA];
   float s_lm0[NA], s_lm1[NA];
   int keep_slot = -1;
   {
     unsigned rem = active;
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
-      if (k < pad) { s_yu[k] = 0; s_yd[k] = 0; cs[k] = 0; s_lm0[k] = 0.f; s_lm1[k] = 0.f; continue; }
+      if (k < pad) { s_yu[k] = 0; s_yd[k] = 0; cs[k] = 0; s_lm0[k] = 0.f; s_lm1[k] = 0.f; s_xl[k] = 0; s_xh[k] = 0; continue; }
       const int idx = __ffs(rem) - 1;
       rem &= rem - 1u;
       const int4 a = *reinterpret_cast<const int4*>(plan + WS_OPS + idx * OP_WORDS);       // {type, src, lm0, yu}
       const int4 b = *reinterpret_cast<const int4*>(plan + WS_OPS + idx * OP_WORDS + 4);   // {yd, xl, xr, lm1}
       const bool isf = a.x != 0;
       s_yu[k] = a.w; s_yd[k] = b.x;
+      s_xl[k] = b.y; s_xh[k] = b.z - b.y;      // (TL) the op's rows [xl, xl + xh)
       s_lm0[k] = isf ? __int_as_float(a.z) : 0.f;
       s_lm1[k] = isf ? __int_as_float(b.w) : 0.f;
       // byte of group (row, g) in the source's code tile = (row * row_bytes + g) + cs; a clamp-only op reads some byte of the
@@ -155,15 +159,24 @@ __device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e,
   // -> (row tt / W, group tt % W); tt < 512, W <= 256: floor(tt / W) = (int)((tt + 0.5) * (1 / W)) exactly (ippm_div_small).
   const float inv_w = __builtin_amdgcn_rcpf((float)W);
   CellVec<4> mv[SLOTS];
-  int off[SLOTS], coff[SLOTS], ycol[SLOTS];
+  int off[SLOTS], coff[SLOTS], ycol[SLOTS], xrow[SLOTS];
 #pragma unroll
   for (int q = 0; q < SLOTS; ++q) {
     const int t = q * 64 + w.lane;
     const int r = ippm_div_small(gs + t, inv_w);
     const int gi = gs + t - r * W;
     const bool valid = t < cnt;
-    const int row = x0 + r, g = g0 + gi;
-    off[q] = valid ? (row * w.gy + g * 4) * 4 : IPPM_T_OOB;
+    int row, g;
+    if (TL) {
+      const int G = g0 + gi;                       // lane-load of the row of tiles x0 + r
+      row = ((x0 + r) << 2) + ((G >> 1) & 3);
+      g = ((G >> 3) << 1) + (G & 1);
+      off[q] = valid ? ((x0 + r) * w.gy + G) * 16 : IPPM_T_OOB;
+    } else {
+      row = x0 + r; g = g0 + gi;
+      off[q] = valid ? (row * w.gy + g * 4) * 4 : IPPM_T_OOB;
+    }
+    xrow[q] = row;
     coff[q] = row * w.row_bytes + g;
     ycol[q] = valid ? g * 4 : IPPM_T_FAR;
     const ippm_t_u4 v = __builtin_amdgcn_raw_buffer_load_b128(rmap, off[q], 0, IPPM_T_LOAD_AUX);
@@ -192,7 +205,8 @@ __device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e,
       const float lm0 = s_lm0[k], lm1 = s_lm1[k];
       // cells y .. y+3 of my group inside [yu, yd): bits [lo, hi)
       const int lo = min(max(yu - ycol[q], 0), 4), hi = min(max(yd - ycol[q], 0), 4);
-      const unsigned cm = ((1u << (hi - lo)) - 1u) << lo;
+      unsigned cm = ((1u << (hi - lo)) - 1u) << lo;
+      if (TL) cm = (unsigned)(xrow[q] - s_xl[k]) < (unsigned)s_xh[k] ? cm : 0u;   // ... and my row inside the op's rows
       touched |= cm;
       keepm = k == keep_slot ? cm : keepm;
       opcells += (lm0 != 0.f || lm1 != 0.f) ? __popc(cm) : 0;
@@ -233,7 +247,7 @@ __device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e,
         __builtin_amdgcn_raw_buffer_store_b128(v, rmap, off[q], 0, IPPM_T_STORE_AUX);
       }
     }
-    if (TRACK) tile_area_slot<MIS>(w, x0 + ippm_div_small(gs + q * 64 + w.lane, inv_w), ycol[q] == IPPM_T_FAR ? 0 : ycol[q], mv[q].v, out);
+    if (TRACK) tile_area_slot<MIS>(w, xrow[q], ycol[q] == IPPM_T_FAR ? 0 : ycol[q], mv[q].v, out);
     if (IPPM_X_REWARD && is_global) {
       // information-gain terms (utils/reward.py:68-82) of the cells the step changed; an untouched cell contributes exact zeros
       // (same weight, same entropy).  Slots whose touched cells all have weight 0 before and after (believed free, still
@@ -271,7 +285,7 @@ __device__ __forceinline__ void tile_item(const TileCtx& w, TileAcc& acc, int e,
 // the registers of a six-op item whatever the team size; round 4 compiled straight-line chains of 8 / 10 / 14 / 18 ops into the
 // kernels of larger teams: 94 VGPRs, five wavefronts per SIMD, for every item of config 4 because one item in a thousand meets
 // seven ops.  Same arithmetic: the spare slots of a straight-line chain are clips ahead of a real op's own clip.
-template <bool MIS, bool TRACK>
+template <bool MIS, bool TRACK, bool TL>
 __device__ __forceinline__ void tile_item_long(const TileCtx& w, TileAcc& acc, int e, int slot, int x0, int cnt, int gs, int g0, int W, unsigned active) {
   constexpr int SLOTS = 2;
   const int map_abs = e * (w.n + 1) + slot;
@@ -285,7 +299,7 @@ __device__ __forceinline__ void tile_item_long(const TileCtx& w, TileAcc& acc, i
   const float inv_w = __builtin_amdgcn_rcpf((float)W);
   CellVec<4> mv[SLOTS];
   float L[SLOTS][4];
-  int off[SLOTS], coff[SLOTS], ycol[SLOTS];
+  int off[SLOTS], coff[SLOTS], ycol[SLOTS], xrow[SLOTS];
   unsigned touched[SLOTS], keepm[SLOTS];
 #pragma unroll
   for (int q = 0; q < SLOTS; ++q) {
@@ -293,8 +307,17 @@ __device__ __forceinline__ void tile_item_long(const TileCtx& w, TileAcc& acc, i
     const int r = ippm_div_small(gs + t, inv_w);
     const int gi = gs + t - r * W;
     const bool valid = t < cnt;
-    const int row = x0 + r, g = g0 + gi;
-    off[q] = valid ? (row * w.gy + g * 4) * 4 : IPPM_T_OOB;
+    int row, g;
+    if (TL) {
+      const int G = g0 + gi;
+      row = ((x0 + r) << 2) + ((G >> 1) & 3);
+      g = ((G >> 3) << 1) + (G & 1);
+      off[q] = valid ? ((x0 + r) * w.gy + G) * 16 : IPPM_T_OOB;
+    } else {
+      row = x0 + r; g = g0 + gi;
+      off[q] = valid ? (row * w.gy + g * 4) * 4 : IPPM_T_OOB;
+    }
+    xrow[q] = row;
     coff[q] = row * w.row_bytes + g;
     ycol[q] = valid ? g * 4 : IPPM_T_FAR;
     touched[q] = 0; keepm[q] = 0;
@@ -302,7 +325,7 @@ __device__ __forceinline__ void tile_item_long(const TileCtx& w, TileAcc& acc, i
     mv[q].v[0] = __uint_as_float(v.x); mv[q].v[1] = __uint_as_float(v.y); mv[q].v[2] = __uint_as_float(v.z); mv[q].v[3] = __uint_as_float(v.w);
   }
   // one op: its record (two 16-byte scalar loads) and its code byte per slot
-  struct OpIn { int idx, yu, yd; float lm0, lm1; uint32_t cw[SLOTS]; };
+  struct OpIn { int idx, yu, yd, xl, xh; float lm0, lm1; uint32_t cw[SLOTS]; };
   unsigned rem = active;
   auto fetch = [&](OpIn& o) __attribute__((always_inline)) {
     o.idx = __ffs(rem) - 1;
@@ -311,6 +334,7 @@ __device__ __forceinline__ void tile_item_long(const TileCtx& w, TileAcc& acc, i
     const int4 b = *reinterpret_cast<const int4*>(plan + WS_OPS + o.idx * OP_WORDS + 4);   // {yd, xl, xr, lm1}
     const bool isf = a.x != 0;
     o.yu = a.w; o.yd = b.x;
+    o.xl = b.y; o.xh = b.z - b.y;
     o.lm0 = isf ? __int_as_float(a.z) : 0.f;
     o.lm1 = isf ? __int_as_float(b.w) : 0.f;
     const int cs = isf ? (e * w.n + a.y) * w.TB - b.y * w.row_bytes - (a.w >> 2) : 0;
@@ -333,7 +357,8 @@ __device__ __forceinline__ void tile_item_long(const TileCtx& w, TileAcc& acc, i
 #pragma unroll
     for (int q = 0; q < SLOTS; ++q) {
       const int lo = min(max(cur.yu - ycol[q], 0), 4), hi = min(max(cur.yd - ycol[q], 0), 4);
-      const unsigned cm = ((1u << (hi - lo)) - 1u) << lo;
+      unsigned cm = ((1u << (hi - lo)) - 1u) << lo;
+      if (TL) cm = (unsigned)(xrow[q] - cur.xl) < (unsigned)cur.xh ? cm : 0u;
       touched[q] |= cm;
       keepm[q] = is_last ? cm : keepm[q];
       opcells += (cur.lm0 != 0.f || cur.lm1 != 0.f) ? __popc(cm) : 0;
@@ -371,7 +396,7 @@ __device__ __forceinline__ void tile_item_long(const TileCtx& w, TileAcc& acc, i
         __builtin_amdgcn_raw_buffer_store_b128(v, rmap, off[q], 0, IPPM_T_STORE_AUX);
       }
     }
-    if (TRACK) tile_area_slot<MIS>(w, x0 + ippm_div_small(gs + q * 64 + w.lane, inv_w), ycol[q] == IPPM_T_FAR ? 0 : ycol[q], mv[q].v, out);
+    if (TRACK) tile_area_slot<MIS>(w, xrow[q], ycol[q] == IPPM_T_FAR ? 0 : ycol[q], mv[q].v, out);
     if (IPPM_X_REWARD && is_global) {   // the reward terms, as in tile_item
       float wa[4], wb[4], wsum = 0.f;
 #pragma unroll
@@ -407,7 +432,7 @@ __device__ __forceinline__ void tile_item_long(const TileCtx& w, TileAcc& acc, i
 #ifndef IPPM_TILE_WAVES_PER_EU
 #define IPPM_TILE_WAVES_PER_EU 5
 #endif
-template <bool MIS, bool TRACK>
+template <bool MIS, bool TRACK, bool TL = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(!MIS && !TRACK ? 6 : (TRACK ? 4 : IPPM_TILE_WAVES_PER_EU), 8)))
 k_fuse_tiles(const int32_t* __restrict__ work, int n_envs, int env_cap, int rot, int n, int gx, int gy, int row_bytes, int TB, float lc, float wt,
              const int32_t* __restrict__ plan_ro, float* __restrict__ local, float* __restrict__ global,
@@ -464,12 +489,12 @@ k_fuse_tiles(const int32_t* __restrict__ work, int n_envs, int env_cap, int rot,
     const int slot = (unsigned)it.w >> 24, gs = it.x & 0xFFFF, cnt = (unsigned)it.x >> 16, x0 = it.y, g0 = it.z & 0xFFFF, W = (unsigned)it.z >> 16;
     const unsigned active = (unsigned)it.w & 0x00FFFFFFu;
     const int na = __popc(active);
-    if (na == 1) tile_item<1, 4, MIS, TRACK>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
-    else if (na == 2) tile_item<2, 4, MIS, TRACK>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
-    else if (na == 3) tile_item<3, 4, MIS, TRACK>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
-    else if (na == 4) tile_item<4, 4, MIS, TRACK>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
-    else if (na <= 6) tile_item<6, 2, MIS, TRACK>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
-    else tile_item_long<MIS, TRACK>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
+    if (na == 1) tile_item<1, 4, MIS, TRACK, TL>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
+    else if (na == 2) tile_item<2, 4, MIS, TRACK, TL>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
+    else if (na == 3) tile_item<3, 4, MIS, TRACK, TL>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
+    else if (na == 4) tile_item<4, 4, MIS, TRACK, TL>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
+    else if (na <= 6) tile_item<6, 2, MIS, TRACK, TL>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
+    else tile_item_long<MIS, TRACK, TL>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
     it = nx;
   }
   // the wavefront's reward terms and work counters: one atomic per quantity
@@ -522,13 +547,16 @@ int ippm_launch_fuse_tiles(ippm_ctx* ctx, float* local, float* global, const uin
   }
   dim3 grid((unsigned)n_envs, (unsigned)per_env), block(64);
 #define IPPM_FT_(M, T) \
-  IPPM_LAUNCH(ctx, IPPM_T_FUSE, (k_fuse_tiles<M, T>), grid, block, st, work, n_envs, env_cap, rot, c.n_agents, c.grid_x, c.grid_y, c.tile_stride >> 2, \
+  do { if (ctx->tl) IPPM_FT__(M, T, true); else IPPM_FT__(M, T, false); } while (0)
+#define IPPM_FT__(M, T, L) \
+  IPPM_LAUNCH(ctx, IPPM_T_FUSE, (k_fuse_tiles<M, T, (L) && !(M)>), grid, block, st, work, n_envs, env_cap, rot, c.n_agents, c.grid_x, c.grid_y, c.tile_stride >> 2, \
               (int)ippm_tile_bytes(c.tile_stride, 4), c.logit_clip, c.logit_weight_thr, ws, local, global, code, ws, sums, ctx->dcounters, area)
 #define IPPM_FT(M) do { if (area) IPPM_FT_(M, true); else IPPM_FT_(M, false); } while (0)
   // rows only 4-byte aligned (grid_y not a multiple of 4): the instantiation with the cell-by-cell row-tail stores
   if ((c.grid_y & 3) != 0) IPPM_FT(true); else IPPM_FT(false);
 #undef IPPM_FT
 #undef IPPM_FT_
+#undef IPPM_FT__
   IPPM_LAUNCH_CHECK("fuse_tiles");
   return 0;
 }

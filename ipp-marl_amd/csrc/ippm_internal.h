@@ -74,6 +74,7 @@ struct ippm_ctx {
   int k3_wpg, k3_chn, k3_go;        // workgroup shape of the env-only step's K3 (wavefronts per workgroup, loads in flight per lane)
   float2* d_roots;           // e^{2 pi i k / 1024}, k = 0..1023: the twiddle table of the terrain transforms (terrain.hip)
   int tiles;                 // the config can take the one-trip tile form of the fusion (16-byte lane groups, prior 0.5)
+  int tl = 0;                // TILE STORAGE of the maps (ippm_set_map_layout): 128-byte tiles of 4 rows x 8 cells instead of row-major rows
   // kernel timing (ippm_kernel_timing): per kernel class a pool of event pairs attached to the dispatches themselves
   int timing;
   hipEvent_t* ev[IPPM_TIMED_CLASSES];
@@ -117,6 +118,17 @@ int ippm_launch_fuse_tiles(ippm_ctx* ctx, float* local, float* global, const uin
 __host__ __device__ inline int ippm_tile_slots(int na) { return na <= 4 ? 4 : 2; }
 int ippm_launch_plan(ippm_ctx* ctx, const int32_t* rect, const int32_t* pos, const uint8_t* comm, int32_t* ws, int global_maps,
                      int n_envs, int agent_sel, hipStream_t st);
+// ---- TILE STORAGE of the maps (ippm_ctx::tl, ippm_set_map_layout) ---------------------------------------------------------------------
+// A map of gx x gy float32 cells is stored as 128-byte tiles of 4 rows x 8 cells, the tiles in row-major order: cell (x, y) is float
+//   (x >> 2) * 4 gy + (y >> 3) * 32 + (x & 3) * 8 + (y & 7)
+// of its map -- a row of tiles (4 map rows) is 4 gy floats, a tile one 128-byte line, a row's 8 cells inside a tile 32 contiguous bytes, so a
+// grid-aligned 4-cell group stays one 16-byte access.  Why: a footprint of 90 x 90 cells at an arbitrary position touches 23-24 x 12-13 whole lines
+// instead of 90 row segments of 3-4 lines with a partial line at either end; a bare read-modify-write of that shape runs 15-28 % faster
+// (tools/probe/rmw_ceiling.cpp, profiles/r06/rmw_ceiling.txt).  Same bytes per map, nothing else changes: truth bits, code bytes, Philox counters, plans, boxes
+// and area sums keep their (row, column) meaning.  Needs whole tiles (gx % 4 == 0, gy % 8 == 0) and the tile form of the fusion.
+static inline bool ippm_tile_storage_ok(const ippm_ctx* ctx) {
+  return ctx->tiles && ctx->vec == 4 && ctx->cfg.grid_x % 4 == 0 && ctx->cfg.grid_y % 8 == 0;
+}
 int ippm_check_hip(hipError_t err, const char* what);
 #define IPPM_HIP(call)                                       \
   do {                                                       \
@@ -127,6 +139,19 @@ int ippm_check_hip(hipError_t err, const char* what);
 
 // ---- device helpers ------------------------------------------------------------------------------------
 #ifdef __HIPCC__
+
+// float index of cell (x, y) inside its map, row-major (tl == 0) or tile storage (tl != 0); y .. y + 3 of a grid-aligned 4-cell group are
+// contiguous in both
+__host__ __device__ __forceinline__ int ippm_cell_index(int x, int y, int gy, int tl) {
+  return tl ? ((x >> 2) * gy << 2) + ((y >> 3) << 5) + ((x & 3) << 3) + (y & 7) : x * gy + y;
+}
+// the (row-major) linear cell number x * gy + y of the cell stored at float index i of a map
+__host__ __device__ __forceinline__ size_t ippm_stored_cell(size_t i, int gy, int tl) {
+  if (!tl) return i;
+  const size_t rt = i / ((size_t)gy * 4), rem = i - rt * (size_t)gy * 4;
+  const int within = (int)(rem & 31);
+  return (rt * 4 + (size_t)(within >> 3)) * (size_t)gy + (rem >> 5) * 8 + (size_t)(within & 7);
+}
 
 // ---- bit-packed byte planes ------------------------------------------------------------------------------------
 // truth: one bit per cell, cell (x,y) -> bit (x*gy + y) of the env's bit string (bytes = ceil(gx*gy/32)*4).
@@ -205,8 +230,11 @@ struct Philox4 {
 };
 __host__ __device__ __forceinline__ Philox4 ippm_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                                         uint32_t k1) {
+#ifndef IPPM_X_PHILOX_ROUNDS      // measurement-only variants (make VARIANT=ph2 EXTRA=-DIPPM_X_PHILOX_ROUNDS=2): what K3 takes with a cheaper generator
+#define IPPM_X_PHILOX_ROUNDS 10
+#endif
 #pragma unroll
-  for (int r = 0; r < 10; ++r) {
+  for (int r = 0; r < IPPM_X_PHILOX_ROUNDS; ++r) {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
     uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
     uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;

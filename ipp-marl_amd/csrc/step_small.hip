@@ -289,11 +289,17 @@ __device__ __forceinline__ void tile_emit_region(int4* items, int env_cap, int32
 // G groups of a row, before they are merged -- so that a row segment of an item starts and ends on line boundaries and every line
 // it touches is written whole.  The cells this adds are met by no op: the fusion clips them (as the reference clips EVERY cell of a map
 // at every fusion, mappings.py:110-111) and writes them back; intervals whose rounded ranges touch are merged, so no cell is in two items.
+// round_mask < 0: TILE STORAGE of the maps (ippm_internal.h).  The same walk in units of tiles: a rectangle's rows become the rows of tiles it meets
+// ([xl >> 2, (xr + 3) >> 2)), its columns the lane-loads of those tiles in a row of tiles (8 per tile: [8 (yu >> 3), 8 ((yd + 7) >> 3)), G = 8 tiles per
+// row = grid_y of them).  Slabs are then rows of tiles with one set of ops, intervals runs of whole tiles, an item a run of whole 128-byte lines; the
+// fusion's lanes test their own row and cells against each op of the mask (an edge tile holds cells of the slab's ops and cells of none).
 __device__ __forceinline__ void tile_build_map(const int4* s_ops, int nops, int env, int slot, int4* items, int env_cap, int32_t* s_items,
                                                int lane, int round_mask, int G) {
   const int n_edges = 2 * nops;
+  const bool tl = round_mask < 0;
   int4 rc = make_int4(0, 0, 0, 0);
   if (lane < nops) rc = s_ops[lane];
+  if (tl) { rc.z >>= 2; rc.w = (rc.w + 3) >> 2; round_mask = 0; }
   const int r_yu = rc.x, r_yd = rc.y, r_xl = rc.z, r_xr = rc.w;
   // lane l holds edge l = xl / xr of op l >> 1
   int edge = 0;
@@ -326,7 +332,8 @@ __device__ __forceinline__ void tile_build_map(const int4* s_ops, int nops, int 
       o = tb_lane_i(order, r);  // op with the r-th smallest first column
       const int yu = tb_lane_i(r_yu, o), yd = tb_lane_i(r_yd, o), xl = tb_lane_i(r_xl, o), xr = tb_lane_i(r_xr, o);
       in = slab_on && xl <= xa && xa < xr;
-      lo = (yu >> 2) & ~round_mask; hi = min(G, (((yd + 3) >> 2) + round_mask) & ~round_mask);
+      if (tl) { lo = (yu >> 3) << 3; hi = ((yd + 7) >> 3) << 3; }
+      else { lo = (yu >> 2) & ~round_mask; hi = min(G, (((yd + 3) >> 2) + round_mask) & ~round_mask); }
       done = in && mask != 0 && lo > g1;  // a gap of at least one group: the interval so far is complete
     }
     // finished intervals go out now.  A small region (config 2: three items on average) is written by its own lane, all lanes
@@ -702,7 +709,7 @@ extern "C" int ippm_plan_step(ippm_ctx* ctx, const int64_t* episode, int32_t* po
                      ctx->dcfg, episode, comm_range, draws, comm, probs, action_in, mask, action, fault, rect_next, -1, plans ? work : nullptr,
                      ippm_fuse_wave_rows(ctx, n_envs), (flags & IPPM_STEP_TILES) ? ippm_tile_env_cap(ctx) : ippm_work_env_cap(ctx, n_envs),
                      ctx->dcounters, ctx->n_active, ctx->slabs, ippm_slab_count(ctx),
-                     (ctx->cfg.grid_y % 32 == 0 && ctx->knob_tile_round > 0) ? ippm_round_cells(ctx->knob_tile_round) / 4 - 1 : 0);
+                     ctx->tl ? -1 : ((ctx->cfg.grid_y % 32 == 0 && ctx->knob_tile_round > 0) ? ippm_round_cells(ctx->knob_tile_round) / 4 - 1 : 0));
   IPPM_LAUNCH_CHECK("plan_step");
   return 0;
 }

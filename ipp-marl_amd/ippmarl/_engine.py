@@ -38,7 +38,8 @@ class Measurement(np.ndarray):
 class EpisodeEngine:
     def __init__(self, params: Dict, episode: int, device: str = "cuda:0", philox_seed: int = _ENGINE_SEED):
         # maps of this engine can be replaced from outside (set_local / set_global): the K6 area sums are rebuilt on demand
-        self.env = VecEnv(params, 1, device=device, philox_seed=philox_seed, track_area=False)
+        # (row-major maps: set_local / set_global / the Mapping objects hand them over as the reference's [gx, gy] arrays)
+        self.env = VecEnv(params, 1, device=device, philox_seed=philox_seed, track_area=False, map_layout="rows")
         self.d = self.env.d
         self.episode = int(episode)
         env = self.env

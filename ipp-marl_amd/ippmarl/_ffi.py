@@ -72,6 +72,10 @@ PROTOTYPES = {
     "ippm_set_team_sizes": [P, P],
     "ippm_dirty_slab_words": [P, I32, P],
     "ippm_set_dirty_slabs": [P, P],
+    "ippm_set_map_layout": [P, I32],
+    "ippm_map_layout": [P, P],
+    "ippm_map_layout_advice": [P, P],
+    "ippm_maps_relayout": [P, P, P, I32, I32, P],
     "ippm_plan_step": [P, P, P, P, P, P, P, P, I32, I32, P, P, I32, P, P, P, P, P, I32, P],
     "ippm_fuse_step": [P, P, P, P, P, P, P, P, I32, P],
     "ippm_reward_finalize": [P, P, P, I32, P],

@@ -50,7 +50,28 @@ def placement_alive_cap(free_bytes: int, arena_bytes: int) -> int:
     return max(2, int(0.5 * free_bytes // (arena_bytes + ((PLACEMENT_SLACK_MB * 15) << 20))) + 1)
 
 
-def placement_stop_reason(scores) -> Optional[str]:
+def rows_view(t: torch.Tensor, tiled: bool) -> torch.Tensor:
+    """The [.., gx, gy] row-major picture of maps stored as `t` [.., gx, gy] (a copy when `tiled`: tile (R, C) of a map = its rows 4R..4R+3,
+    columns 8C..8C+7, stored as 32 consecutive floats, tiles in row-major order)."""
+    if not tiled:
+        return t
+    gx, gy = t.shape[-2:]
+    lead = t.shape[:-2]
+    k = len(lead)
+    return t.reshape(*lead, gx // 4, gy // 8, 4, 8).permute(*range(k), k, k + 2, k + 1, k + 3).reshape(*lead, gx, gy)
+
+
+def tiles_view(t: torch.Tensor, tiled: bool) -> torch.Tensor:
+    """Inverse of rows_view: the storage form of row-major maps `t` [.., gx, gy]."""
+    if not tiled:
+        return t
+    gx, gy = t.shape[-2:]
+    lead = t.shape[:-2]
+    k = len(lead)
+    return t.reshape(*lead, gx // 4, 4, gy // 8, 8).permute(*range(k), k, k + 2, k + 1, k + 3).reshape(*lead, gx, gy)
+
+
+def placement_stop_reason(scores, jumps: int = 0) -> Optional[str]:
     """Why VecEnv.tune_placement may stop after the draws ``scores`` (us per step of the two map kernels), or None to go on.
     The two kinds of allocation are 7-8 % apart and each is sharp to ~1 %:
       * a draw well below the MEDIAN of the draws is a fast one among slow ones (below the worst is not enough: a slow outlier among
@@ -58,7 +79,8 @@ def placement_stop_reason(scores) -> Optional[str]:
       * when fast draws are the majority the median is a fast score and that rule cannot fire: then BOTH kinds must have shown twice --
         two draws within 2 % of the best, and two draws more than 6 % above it that agree with each other to 2 % (113, 114, 122, 122.5:
         stop at the fourth draw; 121, 121.5, 129 is one slow outlier among slow draws, not a second kind: go on);
-      * twelve draws in a row within 2 % of each other: the box has one kind only, nothing to search for."""
+      * twelve draws in a row within 2 % of each other -- and, when the search jumps (tune_placement), at least two jumps among them: the
+        box has one kind only, nothing to search for."""
     k = len(scores)
     if k < 2:
         return None
@@ -68,14 +90,14 @@ def placement_stop_reason(scores) -> Optional[str]:
     slow = sorted(v for v in scores if v > 1.06 * best)
     if sum(1 for v in scores if v <= 1.02 * best) >= 2 and any(b <= 1.02 * a for a, b in zip(slow, slow[1:])):
         return "a fast allocation found"
-    if k >= 12 and max(scores) < 1.02 * best:
+    if k >= 12 and max(scores) < 1.02 * best and (jumps == 0 or jumps >= 2):
         return "no spread between the first draws"
     return None
 
 
 class VecEnv:
     def __init__(self, params: Dict, n_envs: int, device: str = "cuda:0", philox_seed: int = 3, terrain: str = "split",
-                 track_area: bool = True, team_sizes=None):
+                 track_area: bool = True, team_sizes=None, map_layout: str = "auto"):
         if not torch.cuda.is_available():
             raise _ffi.IppmError("VecEnv needs an AMD GPU (HIP): there is no CPU path for the env step")
         self.params = params
@@ -84,6 +106,32 @@ class VecEnv:
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         self.ctx = _ffi.Context(self.d)
+        # STORAGE LAYOUT of the belief maps (ippm_set_map_layout): "rows" = row-major [gx, gy], the reference's numpy layout; "tiles" = 128-byte
+        # tiles of 4 rows x 8 cells (a footprint then touches whole lines only, DESIGN.md "tile storage"); "auto" = tiles where the library
+        # says they pay (ippm_map_layout_advice: footprint rows of 129 .. 256 cells, i.e. BASELINE config 4's grid) -- or wherever the
+        # configuration can take them with IPPM_MAP_TILED=1, nowhere with IPPM_MAP_TILED=0 (the GPU suite runs under both).  `local` / `glob`
+        # ARE the storage: rows_view() gives the [.., gx, gy] picture of either layout (posterior_local / posterior_global go through it).
+        if map_layout not in ("auto", "rows", "tiles"):
+            raise ValueError(f"map_layout: 'auto', 'rows' or 'tiles', not {map_layout!r}")
+        self.tiled = False
+        want = map_layout == "tiles"
+        if map_layout == "auto":
+            forced = os.environ.get("IPPM_MAP_TILED", "")
+            if forced in ("0", "1"):
+                want = forced == "1"
+            else:
+                advice = np.zeros(1, dtype=np.int32)
+                self.ctx.call("ippm_map_layout_advice", advice.ctypes.data)
+                want = bool(advice[0])
+        if want:
+            try:
+                self.ctx.call("ippm_set_map_layout", 1)
+                self.tiled = True
+            except _ffi.IppmError:
+                if map_layout == "tiles":
+                    raise
+        else:
+            self.ctx.call("ippm_set_map_layout", 0)
         d, E, dev = self.d, self.E, self.device
         N, A, S = d.n_agents, d.n_actions, d.tile_stride
         z = lambda *shape, dtype: torch.zeros(*shape, dtype=dtype, device=dev)  # noqa: E731
@@ -209,7 +257,16 @@ class VecEnv:
     def state_bytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in vars(self).values() if isinstance(t, torch.Tensor))
 
+    def rows_view(self, maps: torch.Tensor) -> torch.Tensor:
+        """Row-major [.., gx, gy] picture of maps held in this env's storage layout (the tensor itself when the layout is row-major)."""
+        return rows_view(maps, self.tiled)
+
+    def tiles_view(self, maps: torch.Tensor) -> torch.Tensor:
+        """Storage form of row-major maps [.., gx, gy] (what may be copied into `local` / `glob`)."""
+        return tiles_view(maps, self.tiled)
+
     def _to_prob(self, logodds: torch.Tensor) -> torch.Tensor:
+        logodds = self.rows_view(logodds).contiguous()
         out = torch.empty_like(logodds)
         self.ctx.call("ippm_logodds_to_prob", self._p(logodds), self._p(out), logodds.numel(), self.stream)
         return out
@@ -542,12 +599,30 @@ class VecEnv:
         max_alive = placement_alive_cap(free_b, total)     # (the arena in use counts as one)
         scores, arenas = [score()], [self._arena]      # arenas[k] is None once released
         stopped = "draws exhausted"
+        # JUMPS (round 6): the kind of an allocation comes in streaks -- neighbouring requests land in the same region of physical memory --
+        # and a streak can outlast the search (24 slow draws in a row for one sub-batch, a fast one at the second draw of the next, on one
+        # box).  After every `jump_after` draws that look alike (within 2 % of each other: one kind so far) a block of ballast is taken
+        # and held until the search ends, so that the next draws come from somewhere else.  IPPM_PLACEMENT_JUMP_GB (default 12; 0: no jumps).
+        ballast, jump_after, since_jump = [], 4, 0
+        jump_gb = float(os.environ.get("IPPM_PLACEMENT_JUMP_GB", "12"))
+        jumps = 0
         for k in range(1, draws):
             if not os.environ.get("IPPM_PLACEMENT_NO_EARLY"):
-                why = placement_stop_reason(scores)
+                why = placement_stop_reason(scores, jumps)
                 if why:
                     stopped = why
                     break
+            since_jump += 1
+            if jump_gb > 0 and since_jump >= jump_after and max(scores) < 1.02 * min(scores):
+                free_now, _ = torch.cuda.mem_get_info(self.device)
+                want = int(min(jump_gb * 2 ** 30, 0.25 * free_now))
+                if want > (1 << 30):
+                    try:
+                        ballast.append(torch.empty(want, dtype=torch.uint8, device=self.device))
+                        jumps += 1
+                        since_jump = 0
+                    except torch.cuda.OutOfMemoryError:
+                        pass
             alive = [i for i, a in enumerate(arenas) if a is not None]
             if len(alive) >= max_alive:    # hand the slowest candidates back (never the best one)
                 best_now = min(alive, key=scores.__getitem__)
@@ -563,15 +638,17 @@ class VecEnv:
                 break
             arenas.append(self._arena)
             scores.append(score())
+            if os.environ.get("IPPM_PLACEMENT_TRACE"):
+                print(f"placement draw {k}: arena {self._arena.data_ptr():#x} + {self._arena.numel() / 2 ** 20:.0f} MB -> {scores[-1]:.1f} us", flush=True)
         best = min((i for i, a in enumerate(arenas) if a is not None), key=scores.__getitem__)
         self._use_arena(arenas[best])
-        del arenas
+        del arenas, ballast
         torch.cuda.empty_cache()           # the rejected allocations go back to the driver
         self._boxes_valid = False
         self._pending_t = None
         self._obs_t = None
         return {"draws": len(scores), "max_draws": draws, "kept": best, "map_kernels_us_per_step": [round(v, 1) for v in scores],
-                "stopped": stopped, "max_candidates_alive": max_alive}
+                "stopped": stopped, "max_candidates_alive": max_alive, "jumps": jumps}
 
     def event_times_us(self, clear: bool = True) -> Dict[str, Dict[str, float]]:
         """{kernel class: {"launches", "avg_us", "min_us", "kernel"}} of the launches made while ``profile`` was set
@@ -627,7 +704,7 @@ class SplitVecEnv:
     through one actor batch and use ``VecEnv`` directly."""
 
     def __init__(self, params: Dict, n_envs: int, parts: int = 2, device: str = "cuda:0", philox_seed: int = 3, terrain: str = "split",
-                 track_area: bool = False, team_sizes=None):
+                 track_area: bool = False, team_sizes=None, map_layout: str = "auto"):
         if parts < 1 or n_envs < parts:
             raise ValueError("SplitVecEnv: 1 <= parts <= n_envs")
         self.device = torch.device(device)
@@ -643,9 +720,10 @@ class SplitVecEnv:
         for k, (n, off) in enumerate(zip(self.sizes, self.offsets)):
             with torch.cuda.stream(self.streams[k]):
                 self.parts.append(VecEnv(params, n, device=device, philox_seed=philox_seed, terrain=terrain, track_area=track_area,
-                                         team_sizes=None if ts is None else ts[off:off + n]))
+                                         team_sizes=None if ts is None else ts[off:off + n], map_layout=map_layout))
         self.E = int(n_envs)
         self.d = self.parts[0].d
+        self.tiled = self.parts[0].tiled
         self.params = params
 
     # -- stream plumbing ------------------------------------------------------------------------------
@@ -796,6 +874,9 @@ class SplitVecEnv:
                 acc["launches"] += rec["launches"]
                 acc["min_us"] = min(acc["min_us"], rec["min_us"])
         return out
+
+    def rows_view(self, maps: torch.Tensor) -> torch.Tensor:
+        return rows_view(maps, self.tiled)
 
     def _cat(self, name):
         self.join()

@@ -321,7 +321,7 @@ def test_batched_ig_policy_matches_oracle(name="small", over=None, seed=5, first
         env.build_observations(t, features=False)
         # the beliefs the planner sees, as float64 probabilities of the stored log-odds (a float32 probability of a saturated cell,
         # 0.9999, keeps three digits of 1 - p, and a candidate over nothing but saturated cells has a gain made of exactly that)
-        local = 1.0 / (1.0 + np.exp(-env.local.cpu().numpy().astype(np.float64)))
+        local = 1.0 / (1.0 + np.exp(-env.rows_view(env.local).cpu().numpy().astype(np.float64)))
         pos = env.pos.cpu().numpy()
         acts = env.ig_actions(communication=True)
         gains, chosen = env.ig_gains.cpu().numpy(), acts.cpu().numpy()

@@ -708,7 +708,7 @@ def test_reset_leaves_nothing_of_the_last_episode(name, over, n_envs, slabs, mon
     for wave in range(3):
         env.reset(np.arange(1, n_envs + 1) + 1000 * wave)
         rect = env.rect.cpu().numpy()                      # [E, N, (yu, yd, xl, xr)] of the start positions
-        local = env.local.cpu().numpy()
+        local = env.rows_view(env.local).cpu().numpy()
         assert not env.glob.ne(0).any(), wave
         inside = np.zeros(local.shape, dtype=bool)
         for e in range(n_envs):
@@ -732,7 +732,7 @@ def test_reset_leaves_nothing_of_the_last_episode(name, over, n_envs, slabs, mon
             env.steps(t, policy=POLICY_UNIFORM, features=False)
         if slabs:     # what the episode marked covers what it wrote
             sl = env.slabs.view(n_envs, d.n_agents + 1, 2, -1).cpu().numpy()
-            maps = np.concatenate([env.local.cpu().numpy(), env.glob.cpu().numpy()[:, None]], axis=1) != 0      # [E, N+1, gx, gy]
+            maps = np.concatenate([env.rows_view(env.local).cpu().numpy(), env.rows_view(env.glob).cpu().numpy()[:, None]], axis=1) != 0      # [E, N+1, gx, gy]
             cols = np.arange(d.grid_y)
             for k in range(sl.shape[-1]):
                 written = maps[:, :, 16 * k:16 * k + 16].any(axis=2)                                           # [E, N+1, gy]

@@ -210,6 +210,16 @@ int main() {
   runs<2944, 8192, 12, 128>(buf, 12288, "runs: 12 x 2944 B at 8 KiB pitch (tiles of 8 rows x 4 cells), 12288 maps");
   runs<11776, 32768, 3, 128>(buf, 12288, "runs: 3 x 11776 B at 32 KiB pitch (tiles of 32 rows x 1 cell-group... i.e. column-blocked), 12288 maps");
   runs<35328, 65536, 1, 128>(buf, 12288, "runs: 1 x 35328 B (a footprint stored contiguously), 12288 maps");
+  // (round 6, second session) the same comparison at K3's own launch size (4096 maps) and for the smaller footprints: rows against 4 x 8-cell tiles
+  runs<368, 1024, 90, 16>(buf, 4096, "runs: 90 x 368 B at 1 KiB pitch, 16-byte phase, 4096 maps");
+  runs<1536, 4096, 23, 128>(buf, 4096, "runs: 23 x 1536 B at 4 KiB pitch (4 x 8 tiles, 15 m), 4096 maps");
+  runs<1664, 4096, 24, 128>(buf, 4096, "runs: 24 x 1664 B at 4 KiB pitch (4 x 8 tiles, 15 m, worst-case phase: 24 x 13 tiles), 4096 maps");
+  runs<240, 1024, 60, 16>(buf, 12288, "runs: 60 x 240 B at 1 KiB pitch, 16-byte phase (10 m rows), 12288 maps");
+  runs<1152, 4096, 16, 128>(buf, 12288, "runs: 16 x 1152 B at 4 KiB pitch (4 x 8 tiles, 10 m: 16 x 9 tiles), 12288 maps");
+  runs<240, 1024, 60, 16>(buf, 4096, "runs: 60 x 240 B at 1 KiB pitch, 16-byte phase (10 m rows), 4096 maps");
+  runs<1152, 4096, 16, 128>(buf, 4096, "runs: 16 x 1152 B at 4 KiB pitch (4 x 8 tiles, 10 m), 4096 maps");
+  runs<128, 1024, 30, 16>(buf, 24576, "runs: 30 x 128 B at 1 KiB pitch, 16-byte phase (5 m rows), 24576 maps");
+  runs<640, 4096, 9, 128>(buf, 24576, "runs: 9 x 640 B at 4 KiB pitch (4 x 8 tiles, 5 m: 9 x 5 tiles), 24576 maps");
   CHECK(hipFree(buf));
   return 0;
 }
