@@ -360,6 +360,7 @@ def main():
         env = VecEnv(params, args.envs, device=device, philox_seed=3, terrain=args.terrain, track_area=False, team_sizes=teams)
     # The roofline leg measures the kernels ONE LAUNCH AT A TIME at the full batch: with sub-batches on several streams that is a
     # second, whole-batch VecEnv (same config, same library, its own placement search), stepped on one stream after the timed loops.
+    map_layout = "tiles: 128-byte tiles of 4 rows x 8 cells (ippm_set_map_layout)" if env.tiled else "rows: row-major [grid_x, grid_y]"
     roof_env = VecEnv(params, args.envs, device=device, philox_seed=3, terrain=args.terrain, track_area=False, team_sizes=teams) \
         if split and args.roofline_steps > 0 else env
     first = roof_env if split and args.roofline_steps > 0 else (env.parts[0] if split else env)   # (copy-rate yardstick, PMC calibration)
@@ -758,6 +759,7 @@ def main():
                        "streams": args.streams if split else 1, "staggered_episodes": bool(split and args.stagger), "envs_per_launch": sub_envs,
                        "launches_per_step": 3 * (args.streams if split else 1), "stream_check": stream_check, "hip_graphs": bool(args.graphs),
                        "roofline_steps": args.roofline_steps,
+                       "map_layout": map_layout,
                        "terrain_prefetch": bool(args.terrain_prefetch and args.terrain == "random_field")},
             "ranks": world,
             "resets_timed": resets_timed,

@@ -546,17 +546,14 @@ int ippm_launch_fuse_tiles(ippm_ctx* ctx, float* local, float* global, const uin
     if (ctx->knob_tile_rotate > 0) rot = std::min(ctx->knob_tile_rotate, 6);
   }
   dim3 grid((unsigned)n_envs, (unsigned)per_env), block(64);
-#define IPPM_FT_(M, T) \
-  do { if (ctx->tl) IPPM_FT__(M, T, true); else IPPM_FT__(M, T, false); } while (0)
-#define IPPM_FT__(M, T, L) \
-  IPPM_LAUNCH(ctx, IPPM_T_FUSE, (k_fuse_tiles<M, T, (L) && !(M)>), grid, block, st, work, n_envs, env_cap, rot, c.n_agents, c.grid_x, c.grid_y, c.tile_stride >> 2, \
+#define IPPM_FT_L(...) IPPM_LAUNCH(ctx, IPPM_T_FUSE, (k_fuse_tiles<__VA_ARGS__>), grid, block, st, work, n_envs, env_cap, rot, c.n_agents, c.grid_x, c.grid_y, c.tile_stride >> 2, \
               (int)ippm_tile_bytes(c.tile_stride, 4), c.logit_clip, c.logit_weight_thr, ws, local, global, code, ws, sums, ctx->dcounters, area)
-#define IPPM_FT(M) do { if (area) IPPM_FT_(M, true); else IPPM_FT_(M, false); } while (0)
-  // rows only 4-byte aligned (grid_y not a multiple of 4): the instantiation with the cell-by-cell row-tail stores
-  if ((c.grid_y & 3) != 0) IPPM_FT(true); else IPPM_FT(false);
-#undef IPPM_FT
-#undef IPPM_FT_
-#undef IPPM_FT__
+  // (the kernel's name as written here is what ippm_read_kernel_times reports: <rows only 4-byte aligned, area sums tracked[, tile storage]>)
+  const bool mis = (c.grid_y & 3) != 0;   // the instantiation with the cell-by-cell row-tail stores
+  if (ctx->tl) { if (area) IPPM_FT_L(false, true, true); else IPPM_FT_L(false, false, true); }
+  else if (mis) { if (area) IPPM_FT_L(true, true); else IPPM_FT_L(true, false); }
+  else { if (area) IPPM_FT_L(false, true); else IPPM_FT_L(false, false); }
+#undef IPPM_FT_L
   IPPM_LAUNCH_CHECK("fuse_tiles");
   return 0;
 }

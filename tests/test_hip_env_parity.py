@@ -1037,9 +1037,10 @@ def test_kernel_timing_reports_dispatch_durations():
     times = env.event_times_us()
     assert {"sense", "fuse", "plan"} <= set(times)
     # (template arguments as the launch site spells them: K3 <cells per lane, misaligned rows, explicit flips, sense records, dense lane
-    #  mapping, area sums[, wavefronts per workgroup, loads in flight per lane]>, the fusion <misaligned rows, area sums>)
-    for cls, kernel in (("sense", "k_sense_tiles<4, false, false, true, true, false"), ("fuse", "k_fuse_tiles<false, false>"),
-                        ("plan", "k_plan_step")):
+    #  mapping, area sums, tile storage[, wavefronts per workgroup, loads in flight per lane]>, the fusion <misaligned rows, area sums[, tile storage]>)
+    tl = "true" if env.tiled else "false"
+    for cls, kernel in (("sense", f"k_sense_tiles<4, false, false, true, true, false, {tl}"),
+                        ("fuse", "k_fuse_tiles<false, false, true>" if env.tiled else "k_fuse_tiles<false, false>"), ("plan", "k_plan_step")):
         rec = times[cls]
         assert rec["launches"] == 5 and rec["kernel"].startswith(kernel) and rec["kernel"].endswith(">" if "<" in kernel else "p"), (cls, rec)
         assert 1.0 < rec["min_us"] <= rec["avg_us"] < 2000.0, (cls, rec)
