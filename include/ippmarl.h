@@ -289,14 +289,15 @@ int ippm_set_dirty_slabs(ippm_ctx* ctx, int32_t* slabs);
  * tiles in row-major order: cell (x, y) at float (x >> 2) * 4 grid_y + (y >> 3) * 32 + (x & 3) * 8 + (y & 7).  Same size, same values; every
  * entry point that takes maps reads and writes them in the context's layout (ippm_maps_relayout converts between the two), everything
  * else -- truth bits, code tiles, footprints, plans, area sums, features -- is unchanged.  A footprint then touches whole lines only, which
- * is what the map kernels' HBM traffic is bounded by (DESIGN.md "tile storage").  Needs the tile form (ippm_tile_form) and grid_x % 4 ==
+ * keeps its price however many maps a launch ranges over (DESIGN.md "tile storage").  Needs the tile form (ippm_tile_form) and grid_x % 4 ==
  * 0, grid_y % 8 == 0: rc -2 otherwise.  Set it BEFORE the maps are first written; switching with live maps needs ippm_maps_relayout. */
 int ippm_set_map_layout(ippm_ctx* ctx, int32_t tiled);
 int ippm_map_layout(ippm_ctx* ctx, int32_t* tiled);
-/* 1 where the configuration can take tile storage AND it has been measured to pay (footprint rows of 129 .. 256 cells: BASELINE config 4's
- * 512 x 512 grid, env step -16 %; not config 2's 256 x 256 or config 5's 1024 x 1024, where it costs 3 %) -- what the Python host's
- * map_layout="auto" follows. */
-int ippm_map_layout_advice(ippm_ctx* ctx, int32_t* tiled);
+/* 1 where the configuration can take tile storage AND it has been measured to pay for a batch of n_envs envs: the batch's maps take 2 GB or more and
+ * footprint rows are at most 256 cells (row-major rows cost the more per cell the more maps a launch ranges over, whole lines keep their price: BASELINE
+ * config 4's per-GPU shape -8 .. -16 % per env step, config 2's shape -7 % at 2048 envs and -15 % at 4096 but +3 % at its 1024, config 5's 1024 x 1024
+ * grid +3 %) -- what the Python host's map_layout="auto" follows. */
+int ippm_map_layout_advice(ippm_ctx* ctx, int32_t n_envs, int32_t* tiled);
 /* n_maps maps of grid_x * grid_y floats from `src` to `dst` (src != dst): to_tiled = 1 row-major -> tile storage, 0 the other way
  * (whatever the context's own layout is). */
 int ippm_maps_relayout(ippm_ctx* ctx, const float* src, float* dst, int32_t n_maps, int32_t to_tiled, void* stream);

@@ -160,18 +160,22 @@ extern "C" int ippm_set_map_layout(ippm_ctx* ctx, int32_t tiled) {
   return 0;
 }
 
-// Where tile storage has been measured to pay (profiles/r06/tile_storage_ab.txt; MI355X, env-only step, alternating processes on one box):
-//   256^2 x 4 UAVs x 1024 envs (rows of up to 90 cells)    K3 33.3 -> 36.2 us, fusion 74.3 -> 77.6, reset fill 139 -> 131: step +3 %  -> rows
-//   512^2 x 8 UAVs x 1024 envs (rows of up to 180 cells)   K3 256 -> 243, fusion 970 -> 880, reset fill 1300 -> 1125: step -16 %     -> TILES
-//   1024^2 x 16 UAVs x 64 envs (rows of up to 360 cells)   K3 101.5 -> 100.1, fusion 592 -> 602, reset fill 578 -> 513: step +3 %   -> rows
-// A tile walk takes 8-11 % more lane-loads than a row walk on the small footprints (edge tiles) and the kernels' time follows their lane-loads
-// there, whatever the lines cost; on rows of 12 lines the partial lines at the ends are little to begin with.  In between -- footprint rows of
-// 129 .. 256 cells -- the whole lines win.
-extern "C" int ippm_map_layout_advice(ippm_ctx* ctx, int32_t* tiled) {
+// Where tile storage has been measured to pay (profiles/r06/tile_storage_ab.txt; MI355X, env-only step, alternating processes on one box; step = steady state):
+//   256^2 x 4 UAVs:  512 envs (0.7 GB of maps) equal; 1024 envs (1.3 GB) K3 33.3 -> 36.2 us, fusion 74.3 -> 77.6: step +3 %; 2048 envs (2.7 GB) K3 71 -> 66, fusion 172 -> 141: -7 %;
+//                    4096 envs (5.4 GB) K3 152 -> 133, fusion 367 -> 292: -15 %
+//   256^2 x 8 UAVs x 1024 envs (2.4 GB)   K3 73 -> 66, fusion 285 -> 220, reset fill 330 -> 255: step -10 %
+//   512^2 x 4 UAVs x 1024 envs (5.2 GB)   K3 121 -> 114, fusion 291 -> 259: -6 %
+//   512^2 x 8 UAVs: 256 envs (2.4 GB) -3 %; 1024 envs (9.4 GB, BASELINE config 4's per-GPU shape) K3 256 -> 239, fusion 970 -> 873, fill 1300 -> 1100: -8 .. -16 %
+//   1024^2 x 16 UAVs x 64 envs (4.6 GB)   K3 101.5 -> 100.1, fusion 592 -> 602: +3 % (rows of up to 360 cells = 11-12 lines, written whole by the rounded row segments already)
+// Row-major rows cost the more per cell the more maps a launch ranges over -- per env the fusion takes 0.073 us at 1024 envs of config 2's shape, 0.084 at 2048, 0.090 at
+// 4096 -- while the tile walk gets cheaper (0.076, 0.069, 0.071): whole lines keep their price, partial lines do not.  Below ~2 GB of maps the 8-11 % more lane-loads of a tile walk
+// on small footprints are what shows.  Hence: tiles when the batch's maps take 2 GB or more and footprint rows are at most 256 cells.
+extern "C" int ippm_map_layout_advice(ippm_ctx* ctx, int32_t n_envs, int32_t* tiled) {
   if (!ctx || !tiled) { ippm_set_error("ippm_map_layout_advice: null argument"); return -1; }
   int wmax = 0;
   for (int k = 0; k < ctx->cfg.space_z; ++k) wmax = std::max(wmax, 2 * ctx->cfg.radius_y[k]);
-  *tiled = (ippm_tile_storage_ok(ctx) && wmax > 128 && wmax <= 256) ? 1 : 0;
+  const double map_bytes = 4.0 * ctx->cfg.grid_x * ctx->cfg.grid_y * (ctx->cfg.n_agents + 1.0) * std::max(n_envs, 0);
+  *tiled = (ippm_tile_storage_ok(ctx) && wmax <= 256 && map_bytes >= 2147483648.0) ? 1 : 0;
   return 0;
 }
 

@@ -466,6 +466,10 @@ k_fuse_tiles(const int32_t* __restrict__ work, int n_envs, int env_cap, int rot,
   const int count = tag & IPPM_WORK_COUNT;
   if (first >= count) return;
   __shared__ double s_area[TRACK ? IPPM_FEAT * IPPM_AREA_LD + IPPM_AREA_LD : 1];
+#ifdef IPPM_X_LDS_PAD   // measurement-only variants (make VARIANT=occN EXTRA=-DIPPM_X_LDS_PAD=bytes): LDS nobody needs, to cap the wavefronts a CU holds (160 KB / bytes)
+  __shared__ int s_pad[IPPM_X_LDS_PAD / 4];
+  if (n_envs < 0) { s_pad[threadIdx.x] = first; __syncthreads(); if (counters) counters[0] += s_pad[(threadIdx.x + 1) & 63]; }
+#endif
   if (TRACK) {
     for (int k = lane; k < IPPM_FEAT * IPPM_AREA_LD + IPPM_AREA_LD; k += 64) s_area[k] = 0.0;
     __syncthreads();

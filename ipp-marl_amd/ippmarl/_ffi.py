@@ -74,7 +74,7 @@ PROTOTYPES = {
     "ippm_set_dirty_slabs": [P, P],
     "ippm_set_map_layout": [P, I32],
     "ippm_map_layout": [P, P],
-    "ippm_map_layout_advice": [P, P],
+    "ippm_map_layout_advice": [P, I32, P],
     "ippm_maps_relayout": [P, P, P, I32, I32, P],
     "ippm_plan_step": [P, P, P, P, P, P, P, P, I32, I32, P, P, I32, P, P, P, P, P, I32, P],
     "ippm_fuse_step": [P, P, P, P, P, P, P, P, I32, P],

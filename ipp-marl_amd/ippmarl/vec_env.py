@@ -97,7 +97,7 @@ def placement_stop_reason(scores, jumps: int = 0) -> Optional[str]:
 
 class VecEnv:
     def __init__(self, params: Dict, n_envs: int, device: str = "cuda:0", philox_seed: int = 3, terrain: str = "split",
-                 track_area: bool = True, team_sizes=None, map_layout: str = "auto"):
+                 track_area: bool = True, team_sizes=None, map_layout: str = "auto", layout_envs: Optional[int] = None):
         if not torch.cuda.is_available():
             raise _ffi.IppmError("VecEnv needs an AMD GPU (HIP): there is no CPU path for the env step")
         self.params = params
@@ -108,9 +108,11 @@ class VecEnv:
         self.ctx = _ffi.Context(self.d)
         # STORAGE LAYOUT of the belief maps (ippm_set_map_layout): "rows" = row-major [gx, gy], the reference's numpy layout; "tiles" = 128-byte
         # tiles of 4 rows x 8 cells (a footprint then touches whole lines only, DESIGN.md "tile storage"); "auto" = tiles where the library
-        # says they pay (ippm_map_layout_advice: footprint rows of 129 .. 256 cells, i.e. BASELINE config 4's grid) -- or wherever the
-        # configuration can take them with IPPM_MAP_TILED=1, nowhere with IPPM_MAP_TILED=0 (the GPU suite runs under both).  `local` / `glob`
-        # ARE the storage: rows_view() gives the [.., gx, gy] picture of either layout (posterior_local / posterior_global go through it).
+        # says they pay (ippm_map_layout_advice: the batch's maps take 2 GB or more and footprint rows are at most 256 cells -- BASELINE
+        # config 4's per-GPU shape, not config 2's 1024 envs; `layout_envs` = the batch the question is asked for when this env is one
+        # sub-batch of it) -- or wherever the configuration can take them with IPPM_MAP_TILED=1, nowhere with IPPM_MAP_TILED=0 (the GPU
+        # suite runs under both).  `local` / `glob` ARE the storage: rows_view() gives the [.., gx, gy] picture of either layout
+        # (posterior_local / posterior_global go through it).
         if map_layout not in ("auto", "rows", "tiles"):
             raise ValueError(f"map_layout: 'auto', 'rows' or 'tiles', not {map_layout!r}")
         self.tiled = False
@@ -121,7 +123,7 @@ class VecEnv:
                 want = forced == "1"
             else:
                 advice = np.zeros(1, dtype=np.int32)
-                self.ctx.call("ippm_map_layout_advice", advice.ctypes.data)
+                self.ctx.call("ippm_map_layout_advice", int(layout_envs if layout_envs is not None else self.E), advice.ctypes.data)
                 want = bool(advice[0])
         if want:
             try:
@@ -720,7 +722,7 @@ class SplitVecEnv:
         for k, (n, off) in enumerate(zip(self.sizes, self.offsets)):
             with torch.cuda.stream(self.streams[k]):
                 self.parts.append(VecEnv(params, n, device=device, philox_seed=philox_seed, terrain=terrain, track_area=track_area,
-                                         team_sizes=None if ts is None else ts[off:off + n], map_layout=map_layout))
+                                         team_sizes=None if ts is None else ts[off:off + n], map_layout=map_layout, layout_envs=int(n_envs)))
         self.E = int(n_envs)
         self.d = self.parts[0].d
         self.tiled = self.parts[0].tiled

@@ -533,8 +533,9 @@ def test_full_size_properties(name, over, E, bench_form):
     assert env.counters()["work_list_rejects"] == 0 and small.counters()["work_list_rejects"] == 0
     # (1) sharding independence: an episode's trajectory does not depend on the batch it runs in -- maps, positions and
     # measurement codes bit for bit; the returns to the summation order of the float64 reward atomics
-    assert torch.equal(env.local[pick - 1], small.local)
-    assert torch.equal(env.glob[pick - 1], small.glob)
+    # (through rows_view: the large batch may live in tile storage, the small one in rows -- map_layout="auto" goes by the batch's size)
+    assert torch.equal(env.rows_view(env.local[pick - 1]), small.rows_view(small.local))
+    assert torch.equal(env.rows_view(env.glob[pick - 1]), small.rows_view(small.glob))
     assert torch.equal(env.pos[pick - 1], small.pos)
     assert torch.equal(env.code[pick - 1], small.code)
     torch.testing.assert_close(returns[pick - 1], small_returns, rtol=1e-6, atol=1e-6)
@@ -556,8 +557,8 @@ def test_full_size_properties(name, over, E, bench_form):
     # (5) determinism: same episodes again -> identical bits
     env.reset(eps)
     episode(env)
-    assert torch.equal(env.glob[pick - 1], small.glob)
-    assert torch.equal(env.local[pick - 1], small.local)
+    assert torch.equal(env.rows_view(env.glob[pick - 1]), small.rows_view(small.glob))
+    assert torch.equal(env.rows_view(env.local[pick - 1]), small.rows_view(small.local))
 
 
 def test_td_lambda_and_advantage_kernels(golden):
@@ -772,8 +773,8 @@ def test_staggered_sub_batches_fly_the_same_episodes(parts):
                 r1, _, _ = one.steps(t, policy=POLICY_UNIFORM, features=False)
             sl = slice(off, off + n)
             assert torch.equal(env.episode, one.episode[sl]) and torch.equal(env.pos, one.pos[sl]), (k, done)
-            assert torch.equal(env.local, one.local[sl]), (k, done)
-            assert torch.equal(env.glob, one.glob[sl]), (k, done)
+            assert torch.equal(env.rows_view(env.local), one.rows_view(one.local[sl])), (k, done)
+            assert torch.equal(env.rows_view(env.glob), one.rows_view(one.glob[sl])), (k, done)
             assert torch.equal(env.rect, one.rect[sl]), (k, done)      # (the code plane keeps stale bytes outside the current footprints)
             if r1 is not None:
                 assert torch.equal(env.action, one.action[sl]) and torch.equal(env.reward, r1[sl]), (k, done)

@@ -3,9 +3,9 @@
 # bench line, kernel trace of the loop, FETCH / WRITE) and with rows forced; the default lines (config 2: rows, unchanged code path) and config 5's.  $1 = tag
 TAG=${1:-r6tiles}
 OUT=gpurun_out/$TAG; mkdir -p $OUT
-( time IPPM_MAP_TILED=1 timeout 1500 python -m pytest tests -m gpu -x -q -p no:cacheprovider ) 2>&1 | tail -4 | tee $OUT/pytest_gpu_forced_tiles.txt
-( time IPPM_MAP_TILED=0 timeout 1500 python -m pytest tests -m gpu -x -q -p no:cacheprovider ) 2>&1 | tail -4 | tee $OUT/pytest_gpu_forced_rows.txt
-( time timeout 1500 python -m pytest tests -m gpu -x -q -p no:cacheprovider ) 2>&1 | tail -4 | tee $OUT/head_pytest_gpu.txt
+( time IPPM_MAP_TILED=1 timeout 1500 python -m pytest tests -m gpu -x -q -p no:cacheprovider ) 2>&1 | tail -9 | tee $OUT/pytest_gpu_forced_tiles.txt
+( time IPPM_MAP_TILED=0 timeout 1500 python -m pytest tests -m gpu -x -q -p no:cacheprovider ) 2>&1 | tail -9 | tee $OUT/pytest_gpu_forced_rows.txt
+( time timeout 1500 python -m pytest tests -m gpu -x -q -p no:cacheprovider ) 2>&1 | tail -9 | tee $OUT/head_pytest_gpu.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | tee $OUT/head_smoke.txt
 SHAPES="c4" NO_SQ=1 bash tools/gpu_r5_shapes.sh $TAG 2>&1 | cut -c1-220
 for k in 1 2; do
