@@ -286,6 +286,8 @@ def main():
     ap.add_argument("--steady-episodes", type=int, default=20, help="whole episodes of the steady-state leg that follows the timed region "
                     "(exactly one reset per episode; 20 episodes = 300 steps, ~45 ms at config 2)")
     ap.add_argument("--no-dropin-seam", action="store_true", help="skip the timing of the drop-in object surface (EpisodeGenerator.execute, one env)")
+    ap.add_argument("--no-batch-leg", dest="batch_leg", action="store_false", help="skip the leg that steps the same shape at twice the batch "
+                    "(roofline.batch_leg: where tile storage of the maps takes over from row-major rows)")
     ap.add_argument("--calib", action="store_true", help="PMC calibration: 3 device-to-device copies of the local maps (known "
                     "bytes read and written by a 16 B/lane streaming kernel) before the timed loop")
     args = ap.parse_args()
@@ -610,6 +612,54 @@ def main():
                                          "min_launch_us": times[cls]["min_us"], "timed_launches": times[cls]["launches"],
                                          "us_per_step": times[cls]["avg_us"] * times[cls]["launches"] / args.roofline_steps})
 
+    # Batch leg: the same shape at TWICE the metric's batch (config 2: 2048 envs).  Row-major rows get dearer per cell as a launch's maps grow, the
+    # 128-byte tiles of ippm_set_map_layout do not, and map_layout="auto" takes them from 2 GB of maps on -- so the chip has more to give than the
+    # metric's 1024 envs show.  NOT the metric's configuration: reported beside it under roofline.batch_leg, never as `value`.
+    batch_leg = None
+    if args.batch_leg and world == 1 and not args.graphs and not teams:
+        try:
+            env = roof_env = first = None
+            torch.cuda.empty_cache()
+            big_E = 2 * args.envs
+            big = SplitVecEnv(params, big_E, parts=max(args.streams, 1), device=device, philox_seed=3, terrain=args.terrain) if split else \
+                VecEnv(params, big_E, device=device, philox_seed=3, terrain=args.terrain, track_area=False)
+            if args.placement_draws > 1:
+                for part in (big.parts if split else [big]):
+                    part.tune_placement(args.placement_draws)
+            bwave = [0]
+            if split:
+                big.start(lambda w: episode_ids(1, w, big_E, rank, world))
+                bstep = lambda: big.advance(POLICY_UNIFORM)   # noqa: E731
+            else:
+                bt = {"t": 0}
+                big.reset(episode_ids(1, 0, big_E, rank, world))
+
+                def bstep():
+                    big.steps(bt["t"], policy=POLICY_UNIFORM, features=False)
+                    bt["t"] += 1
+                    if bt["t"] == T:
+                        bwave[0] += 1
+                        big.reset(episode_ids(1, bwave[0], big_E, rank, world))
+                        bt["t"] = 0
+            for _ in range(T):
+                bstep()
+            torch.cuda.synchronize()
+            b0 = time.perf_counter()
+            b_steps = 10 * T
+            for _ in range(b_steps):
+                bstep()
+            torch.cuda.synchronize()
+            b_dt = time.perf_counter() - b0
+            batch_leg = {"envs_per_gpu": big_E, "value": big_E * N * b_steps / b_dt, "unit": "agent-env steps/s", "ms_per_step": 1e3 * b_dt / b_steps,
+                         "steps": b_steps, "episodes": 10, "resets": 10, "faults": int(big.fault.abs().sum()),
+                         "map_layout": "tiles" if big.tiled else "rows",
+                         "note": f"the same shape and loop at {big_E} envs (twice the metric's batch): 10 whole episodes, one reset per episode; NOT the metric's configuration"}
+            big = None
+            torch.cuda.empty_cache()
+        except Exception as exc:   # noqa: BLE001  (an extra leg must never cost the line)
+            batch_leg = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+    if batch_leg is not None and isinstance(roofline, dict):
+        roofline["batch_leg"] = batch_leg
     coma = collective = None
     if args.train_rounds > 0:
         # BASELINE configs[2]: full COMA actor + counterfactual critic training on the same env config

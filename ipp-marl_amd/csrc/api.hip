@@ -60,6 +60,28 @@ extern "C" int ippm_host_truth_params(int64_t episode, int32_t* out2) {
   return 0;
 }
 
+// Workgroup shape of the env-only step's K3 (wavefronts per workgroup x loads in flight per lane) and the order of its workgroups, by the width of the widest
+// footprint row in 4-cell groups and the maps' storage layout; called at ippm_ctx_create and whenever the layout changes (ippm_set_map_layout).
+static void ippm_resolve_k3_shape(ippm_ctx* ctx) {
+  const ippm_config& c = ctx->cfg;
+  auto knob = [](const char* name, int dflt) { const char* v = getenv(name); return v && *v ? atoi(v) : dflt; };
+  int wmax = 1;
+  for (int k = 0; k < c.space_z; ++k) wmax = std::max(wmax, (2 * c.radius_y[k] + 3) / 4 + 1);
+  const bool narrow = wmax <= 64;
+  // Row-major, measured on one allocation per grid, alternating episodes (tools/ab_knobs.py, profiles/r05/k3_workgroup_shapes.txt): 256^2 (W = 23): (4,3) 35.2 us,
+  // (2,2) 34.4; 512^2 (W = 46): (4,3) 67.6, (2,2) 64.2, (1,3) 69.9; 1024^2 (W = 91): (4,3) 94.5, (2,3) 93.8, (2,2) 100.4, (4,4) 162.7.  Short rows: many small
+  // workgroups with two loads in flight; long rows (a load instruction no longer spans a row segment): fewer, with three.
+  // ... and the order of its workgroups: with rows of up to 32 groups (256^2) consecutive workgroups take the agents of an env (a map's parts n workgroups
+  // apart): 33.94 - 34.04 -> 33.54 - 33.70 us in four alternating processes; 512^2 63.0 -> 63.5, 1024^2 91.3 -> 96.6: the parts of a footprint first there.
+  int wpg = narrow ? 2 : 4, chn = narrow ? 2 : 3, go = wmax <= 32 ? 1 : 0;
+  // Tile storage on 256^2-class grids: whole lines cost the memory side less, and a third load in flight per lane pays (profiles/r06/tile_storage_ab.txt:
+  // 2048 envs x 4 UAVs (2,2,1) 66.2 us, (1,3,0) 57.7, (2,3,0) 57.7, (2,4,0) 60.8; 1024 envs x 8 UAVs 66.2 / 58.1 / 61.6 / 61.3); at 512^2 (2,2,0) stays (239 us; (1,3,0) 245).
+  if (ctx->tl && wmax <= 32) { wpg = 1; chn = 3; go = 0; }
+  ctx->k3_wpg = knob("IPPM_K3_WPG", wpg);
+  ctx->k3_chn = knob("IPPM_K3_CHN", chn);
+  ctx->k3_go = knob("IPPM_K3_GO", go);
+}
+
 extern "C" int ippm_ctx_create(const ippm_config* cfg, ippm_ctx** out) {
   if (!cfg || !out) { ippm_set_error("ippm_ctx_create: null argument"); return -1; }
   const ippm_config& c = *cfg;
@@ -104,17 +126,7 @@ extern "C" int ippm_ctx_create(const ippm_config* cfg, ippm_ctx** out) {
   // profiles/r05/k3_workgroup_shapes.txt): 256^2 (W = 23): (4,3) 35.2 us, (2,2) 34.4; 512^2 (W = 46): (4,3) 67.6, (2,2) 64.2, (1,3)
   // 69.9; 1024^2 (W = 91): (4,3) 94.5, (2,3) 93.8, (2,2) 100.4, (4,4) 162.7.  Short rows: many small workgroups with two loads in
   // flight; long rows (a load instruction no longer spans a row segment): fewer, with three.
-  {
-    int wmax = 1;
-    for (int k = 0; k < c.space_z; ++k) wmax = std::max(wmax, (2 * c.radius_y[k] + 3) / 4 + 1);
-    const bool narrow = wmax <= 64;
-    ctx->k3_wpg = knob("IPPM_K3_WPG", narrow ? 2 : 4);
-    ctx->k3_chn = knob("IPPM_K3_CHN", narrow ? 2 : 3);
-    // ... and the order of its workgroups: with rows of up to 32 groups (256^2) consecutive workgroups take the agents of an env
-    // (a map's parts n workgroups apart): 33.94 - 34.04 -> 33.54 - 33.70 us in four alternating processes; 512^2 63.0 -> 63.5,
-    // 1024^2 91.3 -> 96.6: the parts of a footprint first there
-    ctx->k3_go = knob("IPPM_K3_GO", wmax <= 32 ? 1 : 0);
-  }
+  ippm_resolve_k3_shape(ctx);
   // the tile fusion's column intervals rounded outwards to whole 128-byte lines (step_small.hip, tile_build_map): 1 on, 0 off, default: on
   // for rows of at least 512 cells.  Measured (round 6, profiles/r06/tile_round_ab.txt): 512^2 x 8 UAVs fusion 1045 -> 1024 us and the K3
   // behind it 286 -> 275; 256^2 x 4 UAVs fusion 74.7 -> 83-87 us (a 90-cell row grows from 3.7 to 4.7 lines' worth of lane-loads there)
@@ -129,6 +141,7 @@ extern "C" int ippm_ctx_create(const ippm_config* cfg, ippm_ctx** out) {
   ctx->tiles = (ctx->vec == 4 && c.logit_prior == 0.f && c.grid_x < 32768 && c.grid_y <= 1024 && !knob("IPPM_NO_TILES", 0)) ? 1 : 0;
   // tile storage of the maps (ippm_set_map_layout); IPPM_MAP_TILED=1 turns it on at creation where the configuration can take it
   ctx->tl = (knob("IPPM_MAP_TILED", 0) > 0 && ippm_tile_storage_ok(ctx)) ? 1 : 0;
+  ippm_resolve_k3_shape(ctx);
   int rc = ippm_check_hip(hipMalloc(&ctx->dcfg, sizeof(ippm_config)), "hipMalloc(cfg)");
   if (!rc) rc = ippm_check_hip(hipMemcpy(ctx->dcfg, cfg, sizeof(ippm_config), hipMemcpyHostToDevice), "hipMemcpy(cfg)");
   if (!rc) rc = ippm_check_hip(hipMalloc(&ctx->dcounters, IPPM_COUNTER_SLOTS * 8 * sizeof(unsigned long long)), "hipMalloc(counters)");
@@ -157,6 +170,7 @@ extern "C" int ippm_set_map_layout(ippm_ctx* ctx, int32_t tiled) {
     return -2;
   }
   ctx->tl = tiled ? 1 : 0;
+  ippm_resolve_k3_shape(ctx);   // (K3's workgroup shape goes by the layout on 256^2-class grids)
   return 0;
 }
 

@@ -22,3 +22,11 @@ timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_window.jso
 python tools/bench_brief.py $OUT/bench_driver_window.json | grep -E "value|steady|whole_step"
 timeout 600 python bench.py --envs 64 --agents 16 --grid 1024 --actions 27 --episode-comm-range --steps 30 --warmup 15 --no-cpu-baseline --train-rounds 0 > $OUT/bench_c5.json 2> $OUT/bench_c5.err
 python tools/bench_brief.py $OUT/bench_c5.json | grep -E "value|steady|k_sense|k_fuse|whole_step"
+# the same shape at other batches and team sizes (map_layout="auto": tiles from 2 GB of maps on), and rows forced beside them
+for a in "--envs 2048" "--envs 4096" "--envs 1024 --agents 8"; do
+  n=$(echo $a | tr -d ' -')
+  timeout 600 python bench.py $a --steps 30 --warmup 15 --no-cpu-baseline --train-rounds 0 --no-dropin-seam --no-batch-leg > $OUT/bench_$n.json 2> $OUT/bench_$n.err
+  python tools/bench_brief.py $OUT/bench_$n.json | grep -E "value|steady|k_sense|k_fuse|whole_step"
+  IPPM_MAP_TILED=0 timeout 600 python bench.py $a --steps 30 --warmup 15 --no-cpu-baseline --train-rounds 0 --no-dropin-seam --no-batch-leg > $OUT/bench_${n}_rows.json 2> $OUT/bench_${n}_rows.err
+  python tools/bench_brief.py $OUT/bench_${n}_rows.json | grep -E "value|steady|k_sense|k_fuse|whole_step"
+done
