@@ -497,7 +497,7 @@ k_fuse_tiles(const int32_t* __restrict__ work, int n_envs, int env_cap, int rot,
     else if (na == 2) tile_item<2, 4, MIS, TRACK, TL>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
     else if (na == 3) tile_item<3, 4, MIS, TRACK, TL>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
     else if (na == 4) tile_item<4, 4, MIS, TRACK, TL>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
-    else if (na <= 6) tile_item<6, 2, MIS, TRACK, TL>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
+    else if (na <= 6) tile_item<6, IPPM_X_SLOTS56, MIS, TRACK, TL>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
     else tile_item_long<MIS, TRACK, TL>(w, acc, env, slot, x0, cnt, gs, g0, W, active);
     it = nx;
   }

@@ -115,7 +115,10 @@ int ippm_launch_fuse_tiles(ippm_ctx* ctx, float* local, float* global, const uin
 #define IPPM_WORK_COUNT 0x0FFFFFFF
 // loads in flight per lane of a tile item, by the number of ops that meet it (the code bytes of every op are in flight too)
 // (4 for up to four ops, 2 beyond: items of more than six ops run their chain six ops at a time, fuse_tiles.hip)
-__host__ __device__ inline int ippm_tile_slots(int na) { return na <= 4 ? 4 : 2; }
+#ifndef IPPM_X_SLOTS56     // measurement-only variants (make VARIANT=slots4 EXTRA=-DIPPM_X_SLOTS56=4): loads in flight per lane of an item met by five or six ops
+#define IPPM_X_SLOTS56 2
+#endif
+__host__ __device__ inline int ippm_tile_slots(int na) { return na <= 4 ? 4 : (na <= 6 ? IPPM_X_SLOTS56 : 2); }
 int ippm_launch_plan(ippm_ctx* ctx, const int32_t* rect, const int32_t* pos, const uint8_t* comm, int32_t* ws, int global_maps,
                      int n_envs, int agent_sel, hipStream_t st);
 // ---- TILE STORAGE of the maps (ippm_ctx::tl, ippm_set_map_layout) ---------------------------------------------------------------------
