@@ -9,7 +9,7 @@ env = VecEnv(bench_params(A), 1024, philox_seed=3, terrain="random_field", track
 env.reset(list(range(1,1025)))
 for t in range(env.d.budget+1): env.steps(t, policy=POLICY_UNIFORM, features=False)
 torch.cuda.synchronize()
-loc=(env.local!=0); glo=(env.glob!=0)
+loc=(env.rows_view(env.local)!=0); glo=(env.rows_view(env.glob)!=0)     # (rows_view: the [.., gx, gy] picture whatever the storage layout)
 print("written fraction local", float(loc.float().mean()), "global", float(glo.float().mean()))
 ws=env.ws.cpu().numpy()
 import numpy as np
