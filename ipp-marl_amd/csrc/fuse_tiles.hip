@@ -432,8 +432,14 @@ __device__ __forceinline__ void tile_item_long(const TileCtx& w, TileAcc& acc, i
 #ifndef IPPM_TILE_WAVES_PER_EU
 #define IPPM_TILE_WAVES_PER_EU 5
 #endif
+// (the untracked tile-storage instantiation needs 84 registers for its six wavefronts' 80: four are spilled (20 bytes of scratch, re-read around the items).
+//  Measured alternatives, profiles/r06/tile_storage_ab.txt: five wavefronts per SIMD and no spill 149 against 141 us at 2048 envs x 4 UAVs x 256^2, 865 against 873 at config
+//  4's shape; the row packed into the column register: nine spills, 157 us; per-slot row masks built before the chain: twenty-eight.)
+#ifndef IPPM_TL_WAVES_PER_EU
+#define IPPM_TL_WAVES_PER_EU 6
+#endif
 template <bool MIS, bool TRACK, bool TL = false>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(!MIS && !TRACK ? 6 : (TRACK ? 4 : IPPM_TILE_WAVES_PER_EU), 8)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(!MIS && !TRACK ? (TL ? IPPM_TL_WAVES_PER_EU : 6) : (TRACK ? 4 : IPPM_TILE_WAVES_PER_EU), 8)))
 k_fuse_tiles(const int32_t* __restrict__ work, int n_envs, int env_cap, int rot, int n, int gx, int gy, int row_bytes, int TB, float lc, float wt,
              const int32_t* __restrict__ plan_ro, float* __restrict__ local, float* __restrict__ global,
              const uint8_t* __restrict__ code, int32_t* __restrict__ ws, double* __restrict__ sums,
