@@ -69,6 +69,34 @@ def test_relayout_entry_point_and_layout_query():
         VecEnv(dflt, 1, map_layout="tiles", track_area=False)
 
 
+@pytest.mark.gpu
+def test_layout_advice_goes_by_the_batch():
+    """ippm_map_layout_advice (what map_layout="auto" follows): tiles when the batch's maps take 2 GB or more and footprint rows are at most 256
+    cells -- BASELINE config 2 as quoted (1024 envs: 1.3 GB) stays row-major, the same shape at 2048 envs and config 4's per-GPU shape take tiles,
+    config 5's 1024 x 1024 grid (rows of up to 360 cells) and grids that are not made of whole tiles never do."""
+    from ippmarl.vec_env import VecEnv
+
+    def advice(name, n_envs, **over):
+        env = VecEnv(make_params(name, **over), 1, map_layout="rows", track_area=False)
+        out = np.zeros(1, dtype=np.int32)
+        env.ctx.call("ippm_map_layout_advice", n_envs, out.ctypes.data)
+        return int(out[0])
+    assert advice("c2", 1024) == 0 and advice("c2", 2048) == 1 and advice("c2", 4096) == 1
+    assert advice("c2", 1024, experiment__missions__n_agents=8) == 1
+    assert advice("c4", 1024) == 1 and advice("c4", 128) == 0
+    assert advice("c5", 64) == 0 and advice("c5", 4096) == 0
+    assert advice("default", 100000) == 0
+    # ... and the sub-batches of a split batch are asked about the WHOLE batch
+    from ippmarl.vec_env import SplitVecEnv
+    old = os.environ.pop("IPPM_MAP_TILED", None)
+    try:
+        small = SplitVecEnv(make_params("c4"), 8, parts=2)
+        assert not small.tiled and not VecEnv(make_params("c2"), 16, track_area=False).tiled
+    finally:
+        if old is not None:
+            os.environ["IPPM_MAP_TILED"] = old
+
+
 CASES = {
     "c2": ("c2", {}, 6),
     "c2_9actions_failures": ("c2", {"experiment__constraints__num_actions": 9, "experiment__uav__failure_rate": 0.2,
