@@ -28,6 +28,9 @@ The JSON line also carries
   resets_timed, steady_state : how many episode resets the timed window held, and the same loop's rate over --steady-episodes (20)
                      whole episodes right after it (exactly one reset per episode): the figure to quote for sustained throughput
                      (also under roofline.steady_state, which the driver's record keeps)
+  roofline.batch_leg, config.map_layout : the same shape and loop at TWICE the batch (2048 envs by default; ten whole episodes; one GPU only), where
+                     map_layout="auto" stores the maps as 128-byte tiles (ippm_set_map_layout: row-major rows get dearer per cell as a launch's maps
+                     grow past ~2 GB, whole lines do not) -- NOT the metric's configuration, never `value`; and the layout the timed envs used
   per_rank         : every rank's own ms_per_step / rate / placement-search outcome; value_sum_of_ranks next to value_from_max_time
   ranks, rank_devices, collective : who took part (one entry per rank) and the gradient all-reduces RCCL carried in the
                      COMA leg (backend, calls, bytes)
