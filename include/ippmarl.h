@@ -296,7 +296,9 @@ int ippm_map_layout(ippm_ctx* ctx, int32_t* tiled);
 /* 1 where the configuration can take tile storage AND it has been measured to pay for a batch of n_envs envs: the batch's maps take 2 GB or more and
  * footprint rows are at most 256 cells (row-major rows cost the more per cell the more maps a launch ranges over, whole lines keep their price: BASELINE
  * config 4's per-GPU shape -8 .. -16 % per env step, config 2's shape -7 % at 2048 envs and -15 % at 4096 but +3 % at its 1024, config 5's 1024 x 1024
- * grid +3 %) -- what the Python host's map_layout="auto" follows. */
+ * grid +3 %) -- what the Python host's map_layout="auto" follows for envs WITHOUT tracked area sums.  The advice is about the env-only kernels
+ * (area == NULL): with area sums tracked, a tile walk's lanes fall into a third as many area bins per instruction as a row walk's and their LDS atomics
+ * queue up (K3 85 -> 190 us, fusion 198 -> 232 at 2048 envs of config 2's shape), so a training rollout keeps rows. */
 int ippm_map_layout_advice(ippm_ctx* ctx, int32_t n_envs, int32_t* tiled);
 /* n_maps maps of grid_x * grid_y floats from `src` to `dst` (src != dst): to_tiled = 1 row-major -> tile storage, 0 the other way
  * (whatever the context's own layout is). */

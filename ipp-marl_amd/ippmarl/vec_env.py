@@ -122,9 +122,12 @@ class VecEnv:
             if forced in ("0", "1"):
                 want = forced == "1"
             else:
+                # (the advice is for the env-only kernels.  With tracked area sums -- the training rollout -- tiles are SLOWER: the lanes of a tile
+                #  walk fall into a third as many area bins per instruction as the lanes of a row walk, and their LDS atomics queue up: K3 85 -> 190 us,
+                #  fusion 198 -> 232 at 2048 envs x 4 UAVs x 256^2, profiles/r06/tile_storage_ab.txt -- so a tracked env keeps rows unless forced)
                 advice = np.zeros(1, dtype=np.int32)
                 self.ctx.call("ippm_map_layout_advice", int(layout_envs if layout_envs is not None else self.E), advice.ctypes.data)
-                want = bool(advice[0])
+                want = bool(advice[0]) and not track_area
         if want:
             try:
                 self.ctx.call("ippm_set_map_layout", 1)

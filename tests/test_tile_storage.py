@@ -92,6 +92,9 @@ def test_layout_advice_goes_by_the_batch():
     try:
         small = SplitVecEnv(make_params("c4"), 8, parts=2)
         assert not small.tiled and not VecEnv(make_params("c2"), 16, track_area=False).tiled
+        # ... and an env with tracked area sums (the training rollout) keeps rows whatever the batch: its LDS atomics are slower on tiles
+        assert VecEnv(make_params("c4"), 2, track_area=False, layout_envs=1024).tiled
+        assert not VecEnv(make_params("c4"), 2, track_area=True, layout_envs=1024).tiled
     finally:
         if old is not None:
             os.environ["IPPM_MAP_TILED"] = old
